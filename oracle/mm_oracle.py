@@ -1,0 +1,454 @@
+"""CPU oracle for the late-fusion fine-tuning path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (fp32, CPU) restatement of the algorithm that the
+reference executes for `models/mm_late.py:MM_Model.forward` and the train-step
+body of `models/mm_late.py:MMLate_Model.train`.  It is the checker for the HIP
+path: only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline`
+leg may import it.  The product path (`smtc_amd`) never imports anything from
+`oracle/` and fails loudly when the HIP library is missing.
+
+Parity status: PINNED.  `tests/golden/make_golden.py` imports the reference's
+own `MM_Model` (behind a shim for packages the container lacks),
+loads the weights produced by `make_params()` below into it, runs it, and
+commits inputs + outputs under `tests/golden/*.npz`.  `tests/test_oracle_golden.py`
+checks this restatement against those vectors on CPU.
+
+The encoders' arithmetic is not in the reference repo; it lives in
+`transformers==4.25.1` (timrel-env.yml:122), un-vendored.  The restated
+algorithm follows (HF = transformers, as installed 5.15.0, same mathematics):
+  * ViT-B/16        HF:models/vit/modeling_vit.py:42-69,72-161,192-301,336-388
+  * BERT / XLM-R    HF:models/bert/modeling_bert.py:98-108,111-203,282-351,451-463
+                    HF:models/xlm_roberta/modeling_xlm_roberta.py:56-155 (position ids)
+  * dual encoder    HF:models/vision_text_dual_encoder/modeling_vision_text_dual_encoder.py:244-292
+  * fusion + heads  reference models/mm_late.py:91-113,148-210
+  * losses          reference models/utils.py:225-231, models/run_mm_late.py:85,97,
+                    models/mm_late.py:471-487
+  * ITM sampling    reference models/mm_late.py:389-414
+  * optimizer       reference models/utils.py:280-292, models/mm_late.py:420-422 (torch AdamW)
+
+Parameter names are the reference checkpoint's `state_dict` keys
+(transformers 4.25.1 naming).
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from dataclasses import dataclass, field, asdict
+from typing import Callable, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------
+# configuration
+# --------------------------------------------------------------------------------------
+@dataclass
+class OracleConfig:
+    hidden: int = 768           # models/config.py:82-84 hard-wires 768
+    heads: int = 12
+    inter: int = 3072
+    layers_txt: int = 12
+    layers_img: int = 12
+    vocab: int = 250002         # Bernice (XLM-R tokenizer); BERT: 30522
+    max_pos: int = 130          # XLM-R needs T+2 rows for T=128; BERT: 512
+    type_vocab: int = 1         # XLM-R: 1, BERT: 2
+    txt_kind: str = "xlmr"      # "xlmr" (bernice/roberta/bertweet) | "bert"
+    pad_id: int = 1             # XLM-R pad id 1; BERT 0
+    ln_eps_txt: float = 1e-5    # XLM-R 1e-5; BERT 1e-12
+    ln_eps_img: float = 1e-12
+    image: int = 224
+    patch: int = 16
+    proj_dim: int = 512
+    num_labels: int = 2
+    fusion: str = "attention"   # "attention" | "concat"
+    p_hidden: float = 0.1       # text hidden dropout
+    p_attn: float = 0.1         # text attention-prob dropout
+    p_head: float = 0.05        # --dropout
+
+    @property
+    def n_patches(self) -> int:
+        return (self.image // self.patch) ** 2
+
+    @property
+    def img_tokens(self) -> int:
+        return self.n_patches + 1
+
+
+# --------------------------------------------------------------------------------------
+# deterministic parameter recipe (shared by golden generation, oracle and the HIP tests)
+# --------------------------------------------------------------------------------------
+def param_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
+    """state_dict keys (transformers 4.25.1 naming) -> shapes, in checkpoint order."""
+    H, I = cfg.hidden, cfg.inter
+    s: Dict[str, Tuple[int, ...]] = {}
+    de = "dual_encoder."
+    s[de + "logit_scale"] = ()
+    vm = de + "vision_model."
+    s[vm + "embeddings.cls_token"] = (1, 1, H)
+    s[vm + "embeddings.position_embeddings"] = (1, cfg.img_tokens, H)
+    s[vm + "embeddings.patch_embeddings.projection.weight"] = (H, 3, cfg.patch, cfg.patch)
+    s[vm + "embeddings.patch_embeddings.projection.bias"] = (H,)
+    for l in range(cfg.layers_img):
+        p = f"{vm}encoder.layer.{l}."
+        for n in ("query", "key", "value"):
+            s[p + f"attention.attention.{n}.weight"] = (H, H)
+            s[p + f"attention.attention.{n}.bias"] = (H,)
+        s[p + "attention.output.dense.weight"] = (H, H)
+        s[p + "attention.output.dense.bias"] = (H,)
+        s[p + "intermediate.dense.weight"] = (I, H)
+        s[p + "intermediate.dense.bias"] = (I,)
+        s[p + "output.dense.weight"] = (H, I)
+        s[p + "output.dense.bias"] = (H,)
+        s[p + "layernorm_before.weight"] = (H,)
+        s[p + "layernorm_before.bias"] = (H,)
+        s[p + "layernorm_after.weight"] = (H,)
+        s[p + "layernorm_after.bias"] = (H,)
+    s[vm + "layernorm.weight"] = (H,)
+    s[vm + "layernorm.bias"] = (H,)
+    s[vm + "pooler.dense.weight"] = (H, H)
+    s[vm + "pooler.dense.bias"] = (H,)
+    tm = de + "text_model."
+    s[tm + "embeddings.word_embeddings.weight"] = (cfg.vocab, H)
+    s[tm + "embeddings.position_embeddings.weight"] = (cfg.max_pos, H)
+    s[tm + "embeddings.token_type_embeddings.weight"] = (cfg.type_vocab, H)
+    s[tm + "embeddings.LayerNorm.weight"] = (H,)
+    s[tm + "embeddings.LayerNorm.bias"] = (H,)
+    for l in range(cfg.layers_txt):
+        p = f"{tm}encoder.layer.{l}."
+        for n in ("query", "key", "value"):
+            s[p + f"attention.self.{n}.weight"] = (H, H)
+            s[p + f"attention.self.{n}.bias"] = (H,)
+        s[p + "attention.output.dense.weight"] = (H, H)
+        s[p + "attention.output.dense.bias"] = (H,)
+        s[p + "attention.output.LayerNorm.weight"] = (H,)
+        s[p + "attention.output.LayerNorm.bias"] = (H,)
+        s[p + "intermediate.dense.weight"] = (I, H)
+        s[p + "intermediate.dense.bias"] = (I,)
+        s[p + "output.dense.weight"] = (H, I)
+        s[p + "output.dense.bias"] = (H,)
+        s[p + "output.LayerNorm.weight"] = (H,)
+        s[p + "output.LayerNorm.bias"] = (H,)
+    s[tm + "pooler.dense.weight"] = (H, H)
+    s[tm + "pooler.dense.bias"] = (H,)
+    s[de + "visual_projection.weight"] = (cfg.proj_dim, H)
+    s[de + "text_projection.weight"] = (cfg.proj_dim, H)
+    # heads, reference models/mm_late.py:73-89
+    for n, shp in (("fc_Q", (H, H)), ("fc_K", (H, H)), ("fc_V", (H, H)), ("aspectattention", (1, H)),
+                   ("linear_fusion", (H, 2 * H)), ("linear_cls", (cfg.num_labels, H)),
+                   ("linear_tim", (2, H)), ("linear_iadds", (2, H)),
+                   ("linear_gmu_t", (2 * H, H)), ("linear_gmu_v", (2 * H, H))):
+        s[n + ".weight"] = shp
+        s[n + ".bias"] = (shp[0],)
+    return s
+
+
+def make_param(name: str, shape: Tuple[int, ...], seed: int) -> Tensor:
+    """Value of one parameter: depends only on (name, shape, seed).
+
+    Weights ~ N(0, 0.02) (HF initializer_range), LayerNorm weights 1 + 0.1 N(0,1),
+    biases 0.02 N(0,1) (non-zero on purpose so bias paths are exercised), the word-embedding
+    padding row is left random (the forward reads it for pad tokens; its gradient is zero).
+    """
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(name.encode()) + 1000003 * seed) % (2 ** 63))
+    if name.endswith("logit_scale"):
+        return torch.tensor(2.6592)
+    x = torch.randn(shape, generator=g, dtype=torch.float32)
+    if ("LayerNorm.weight" in name or "layernorm" in name and name.endswith(".weight")):
+        return 1.0 + 0.1 * x
+    return 0.02 * x
+
+
+def make_params(cfg: OracleConfig, seed: int = 0) -> Dict[str, Tensor]:
+    return {k: make_param(k, shp, seed) for k, shp in param_shapes(cfg).items()}
+
+
+# --------------------------------------------------------------------------------------
+# dropout: counter-based hash shared bit-for-bit with the HIP kernels
+# (socialmedia-textimage-classification-auxlosses_amd/csrc/mmhip_common.h: mm_rng_u32)
+# --------------------------------------------------------------------------------------
+STREAM_EMBED = 1
+STREAM_HEAD = 2
+
+
+def stream_attn(layer: int) -> int:
+    return 16 + 4 * layer
+
+
+def stream_attn_out(layer: int) -> int:
+    return 16 + 4 * layer + 1
+
+
+def stream_ffn_out(layer: int) -> int:
+    return 16 + 4 * layer + 2
+
+
+def rng_u32(idx: np.ndarray, stream: int, seed: int) -> np.ndarray:
+    x = idx.astype(np.uint32) ^ np.uint32(seed & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        x = x * np.uint32(0x9E3779B1)
+        x ^= x >> np.uint32(15)
+        x = x + np.uint32((stream * 0x85EBCA77 + ((seed >> 32) & 0xFFFFFFFF)) & 0xFFFFFFFF)
+        x ^= x >> np.uint32(13)
+        x = x * np.uint32(0xC2B2AE3D)
+        x ^= x >> np.uint32(16)
+    return x
+
+
+def drop_threshold(p: float) -> int:
+    return min(int(p * 4294967296.0), 0xFFFFFFFF)
+
+
+def hash_keep_mask(n: int, offset: int, stream: int, seed: int, p: float) -> np.ndarray:
+    """keep[i] for linear element indices offset..offset+n-1 (True = kept)."""
+    idx = (np.arange(n, dtype=np.uint64) + np.uint64(offset)).astype(np.uint32)
+    return rng_u32(idx, stream, seed) >= np.uint32(drop_threshold(p))
+
+
+class Dropout:
+    """mode 'none' (eval / p=0), 'torch' (torch RNG), 'hash' (the HIP kernels' masks)."""
+
+    def __init__(self, mode: str = "none", seed: int = 0):
+        self.mode, self.seed = mode, seed
+
+    def __call__(self, x: Tensor, p: float, stream: int, offset: int = 0) -> Tensor:
+        if self.mode == "none" or p <= 0.0:
+            return x
+        if self.mode == "torch":
+            return F.dropout(x, p, training=True)
+        keep = torch.from_numpy(hash_keep_mask(x.numel(), offset, stream, self.seed, p)).view(x.shape)
+        return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
+
+
+# --------------------------------------------------------------------------------------
+# encoders
+# --------------------------------------------------------------------------------------
+def _lin(x: Tensor, P: Dict[str, Tensor], name: str) -> Tensor:
+    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+
+
+def _ln(x: Tensor, P: Dict[str, Tensor], name: str, eps: float) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], eps)
+
+
+def _heads(x: Tensor, nh: int) -> Tensor:
+    B, S, H = x.shape
+    return x.view(B, S, nh, H // nh).permute(0, 2, 1, 3)
+
+
+def vit_forward(P: Dict[str, Tensor], pixels: Tensor, cfg: OracleConfig,
+                collect: Optional[list] = None) -> Tuple[Tensor, Tensor]:
+    """HF:models/vit/modeling_vit.py:373-388 (ViTModel.forward); all dropouts are 0.0."""
+    vm = "dual_encoder.vision_model."
+    B = pixels.shape[0]
+    w = P[vm + "embeddings.patch_embeddings.projection.weight"]
+    b = P[vm + "embeddings.patch_embeddings.projection.bias"]
+    x = F.conv2d(pixels, w, b, stride=cfg.patch).flatten(2).transpose(1, 2)           # :60,69
+    x = torch.cat([P[vm + "embeddings.cls_token"].expand(B, -1, -1), x], dim=1)        # :146-150
+    x = x + P[vm + "embeddings.position_embeddings"]                                   # :153-155
+    scale = (cfg.hidden // cfg.heads) ** -0.5
+    for l in range(cfg.layers_img):
+        p = f"{vm}encoder.layer.{l}."
+        h = _ln(x, P, p + "layernorm_before", cfg.ln_eps_img)                           # :274
+        q = _heads(_lin(h, P, p + "attention.attention.query"), cfg.heads)              # :216-218
+        k = _heads(_lin(h, P, p + "attention.attention.key"), cfg.heads)
+        v = _heads(_lin(h, P, p + "attention.attention.value"), cfg.heads)
+        a = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)                      # :164-189
+        c = (a @ v).permute(0, 2, 1, 3).reshape(B, -1, cfg.hidden)
+        x = x + _lin(c, P, p + "attention.output.dense")                                # :236,276-277
+        h = _ln(x, P, p + "layernorm_after", cfg.ln_eps_img)                            # :281
+        h = F.gelu(_lin(h, P, p + "intermediate.dense"))                                # :250-251 (erf)
+        x = x + _lin(h, P, p + "output.dense")                                          # :252,283-284
+        if collect is not None:
+            collect.append(x)
+    x = _ln(x, P, vm + "layernorm", cfg.ln_eps_img)                                     # :385
+    pooled = torch.tanh(_lin(x[:, 0], P, vm + "pooler.dense"))                          # :289-301
+    return x, pooled
+
+
+def text_position_ids(ids: Tensor, cfg: OracleConfig) -> Tensor:
+    if cfg.txt_kind == "xlmr":   # HF:models/xlm_roberta/modeling_xlm_roberta.py:142-155
+        m = (ids != cfg.pad_id).to(torch.int64)
+        return torch.cumsum(m, dim=1) * m + cfg.pad_id
+    return torch.arange(ids.shape[1], dtype=torch.int64).unsqueeze(0).expand_as(ids)
+
+
+def text_forward(P: Dict[str, Tensor], ids: Tensor, mask: Tensor, cfg: OracleConfig,
+                 drop: Optional[Dropout] = None, post_offset: int = 0,
+                 collect: Optional[list] = None) -> Tuple[Tensor, Tensor]:
+    """BertModel / XLMRobertaModel forward (post-LN).  `post_offset` = index of this call's first
+    post inside the batched text pass of the HIP engine (ITM rows follow the original rows)."""
+    drop = drop or Dropout("none")
+    tm = "dual_encoder.text_model."
+    B, T = ids.shape
+    H, nh = cfg.hidden, cfg.heads
+    pos = text_position_ids(ids, cfg)
+    x = (P[tm + "embeddings.word_embeddings.weight"][ids]
+         + P[tm + "embeddings.token_type_embeddings.weight"][0]
+         + P[tm + "embeddings.position_embeddings.weight"][pos])
+    x = _ln(x, P, tm + "embeddings.LayerNorm", cfg.ln_eps_txt)
+    x = drop(x, cfg.p_hidden, STREAM_EMBED, post_offset * T * H)
+    bias = (1.0 - mask.to(torch.float32))[:, None, None, :] * torch.finfo(torch.float32).min
+    scale = (H // nh) ** -0.5
+    for l in range(cfg.layers_txt):
+        p = f"{tm}encoder.layer.{l}."
+        q = _heads(_lin(x, P, p + "attention.self.query"), nh)
+        k = _heads(_lin(x, P, p + "attention.self.key"), nh)
+        v = _heads(_lin(x, P, p + "attention.self.value"), nh)
+        a = torch.softmax(q @ k.transpose(-1, -2) * scale + bias, dim=-1)
+        a = drop(a, cfg.p_attn, stream_attn(l), post_offset * nh * T * T)
+        c = (a @ v).permute(0, 2, 1, 3).reshape(B, T, H)
+        o = drop(_lin(c, P, p + "attention.output.dense"), cfg.p_hidden, stream_attn_out(l), post_offset * T * H)
+        a1 = _ln(o + x, P, p + "attention.output.LayerNorm", cfg.ln_eps_txt)
+        h = F.gelu(_lin(a1, P, p + "intermediate.dense"))
+        f = drop(_lin(h, P, p + "output.dense"), cfg.p_hidden, stream_ffn_out(l), post_offset * T * H)
+        x = _ln(f + a1, P, p + "output.LayerNorm", cfg.ln_eps_txt)
+        if collect is not None:
+            collect.append(x)
+    pooled = torch.tanh(_lin(x[:, 0], P, tm + "pooler.dense"))
+    return x, pooled
+
+
+def itc_logits(P: Dict[str, Tensor], t_pool: Tensor, v_pool: Tensor) -> Tensor:
+    """logits_per_text; HF dual encoder :261-274."""
+    img = F.linear(v_pool, P["dual_encoder.visual_projection.weight"])
+    txt = F.linear(t_pool, P["dual_encoder.text_projection.weight"])
+    img = img / img.norm(dim=-1, keepdim=True)
+    txt = txt / txt.norm(dim=-1, keepdim=True)
+    return txt @ img.t() * P["dual_encoder.logit_scale"].exp()
+
+
+def mm_fusion(P: Dict[str, Tensor], x_t: Tensor, x_v: Tensor, cfg: OracleConfig) -> Tensor:
+    """reference models/mm_late.py:91-113 + Scaled_Dot_Product_Attention :195-210."""
+    if cfg.fusion == "concat":
+        z = torch.cat((x_t[:, 0, :], x_v[:, 0, :]), dim=1)
+        return F.relu(_lin(z, P, "linear_fusion"))
+    if cfg.fusion == "attention":
+        N, L, E = x_t.shape
+        Q, K, V = _lin(x_t, P, "fc_Q"), _lin(x_v, P, "fc_K"), _lin(x_v, P, "fc_V")
+        scale = K.shape[-1] ** -0.5
+        att = torch.softmax(Q @ K.permute(0, 2, 1) * scale, dim=-1)
+        ctx = (att @ V).view(N, L, E)
+        z = torch.cat((x_t[:, 0, :], ctx[:, 0, :]), dim=1)
+        return F.relu(_lin(z, P, "linear_fusion"))
+    raise ValueError(cfg.fusion)
+
+
+def mm_forward(P: Dict[str, Tensor], ids: Tensor, mask: Tensor, pixels: Tensor, cfg: OracleConfig,
+               tim_inputs: Optional[Tuple[Tensor, Tensor]] = None, drop: Optional[Dropout] = None,
+               collect: Optional[dict] = None):
+    """reference models/mm_late.py:148-193 -> (out_cls, logits_per_text, out_tim, None, mm_features)."""
+    drop = drop or Dropout("none")
+    cv = collect.setdefault("vit_layers", []) if collect is not None else None
+    ct = collect.setdefault("txt_layers", []) if collect is not None else None
+    B = ids.shape[0]
+    x_v, v_pool = vit_forward(P, pixels, cfg, cv)
+    x_t, t_pool = text_forward(P, ids, mask, cfg, drop, 0, ct)
+    logits_per_text = itc_logits(P, t_pool, v_pool)
+    feats = mm_fusion(P, x_t, x_v, cfg)
+    out_cls = _lin(drop(feats, cfg.p_head, STREAM_HEAD, 0), P, "linear_cls")
+    out_tim = None
+    if tim_inputs is not None:
+        tim_ids, tim_mask = tim_inputs
+        # second dual-encoder call; the frozen, dropout-free ViT output is identical
+        x_t2, _ = text_forward(P, tim_ids, tim_mask, cfg, drop, B, None)
+        out_tim = _lin(mm_fusion(P, x_t2, x_v, cfg), P, "linear_tim")      # no dropout, :181-182
+    return out_cls, logits_per_text, out_tim, None, feats
+
+
+# --------------------------------------------------------------------------------------
+# losses, ITM sampling, optimizer
+# --------------------------------------------------------------------------------------
+def clip_loss(sim: Tensor) -> Tensor:
+    """reference models/utils.py:225-231."""
+    tgt = torch.arange(len(sim))
+    return (F.cross_entropy(sim, tgt) + F.cross_entropy(sim.t(), tgt)) / 2.0
+
+
+def cls_loss(out: Tensor, onehot: Tensor, weight: Optional[Tensor]) -> Tensor:
+    """nn.CrossEntropyLoss(weight=w)(out, float one-hot): -(1/B) sum_b sum_c w_c y_bc logsoftmax(out)_bc
+    (models/run_mm_late.py:85 with models/mm_late.py:471; SURVEY §8c known answer (1))."""
+    lsm = torch.log_softmax(out, dim=1)
+    w = torch.ones(out.shape[1]) if weight is None else weight
+    return -(onehot.to(out.dtype) * lsm * w).sum() / out.shape[0]
+
+
+def itm_loss(out_tim: Tensor, lbl: Tensor) -> Tensor:
+    return F.cross_entropy(out_tim, lbl)
+
+
+def mix_loss(out_cls, onehot, weight, logits_per_text, out_tim, lbl_tim,
+             use_itc: bool, use_itm: bool, beta_itc: float = 0.1, beta_itm: float = 0.1) -> Tensor:
+    """reference models/mm_late.py:473-487."""
+    lc = cls_loss(out_cls, onehot, weight)
+    if use_itc and use_itm:
+        return (1 - (beta_itc + beta_itm)) * lc + beta_itc * clip_loss(logits_per_text) + beta_itm * itm_loss(out_tim, lbl_tim)
+    if use_itc:
+        return (1 - beta_itc) * lc + beta_itc * clip_loss(logits_per_text)
+    if use_itm:
+        return (1 - beta_itm) * lc + beta_itm * itm_loss(out_tim, lbl_tim)
+    return lc
+
+
+def prepare_itm_inputs(ids: Tensor, mask: Tensor):
+    """reference models/mm_late.py:389-414 (numpy global RNG; same call order)."""
+    tim_ids, tim_mask = ids.clone(), mask.clone()
+    labels = []
+    B = ids.shape[0]
+    if B > 1:
+        for idx in range(B):
+            if np.random.choice([True, False]):
+                labels.append(0)
+                new_idx = np.random.choice(list(set(range(B)) - {idx}))
+                tim_ids[idx] = ids[new_idx]
+                tim_mask[idx] = mask[new_idx]
+            else:
+                labels.append(1)
+    else:
+        labels.append(1)
+    return tim_ids, tim_mask, torch.tensor(labels, dtype=torch.long)
+
+
+def trainable(name: str) -> bool:
+    """reference models/mm_late.py:67-69: every dual_encoder parameter with 'vision' in its name is frozen."""
+    return not (name.startswith("dual_encoder.") and "vision" in name)
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, wd: float,
+               b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
+    """torch.optim.AdamW single-tensor update (in place)."""
+    p.mul_(1 - lr * wd)
+    m.lerp_(g, 1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# --------------------------------------------------------------------------------------
+# synthetic posts (BASELINE.md §3 / SURVEY §8d)
+# --------------------------------------------------------------------------------------
+def synthetic_batch(cfg: OracleConfig, B: int, T: int = 128, seed: int = 1234, pad: bool = False):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, cfg.vocab, (B, T), generator=g, dtype=torch.int64)
+    cls_id, eos_id = (0, 2) if cfg.txt_kind == "xlmr" else (101, 102)
+    ids[:, 0] = cls_id
+    mask = torch.ones(B, T, dtype=torch.int64)
+    if pad:
+        lens = torch.randint(4, T + 1, (B,), generator=g)
+        lens[0] = T
+        for b in range(B):
+            n = int(lens[b])
+            ids[b, n - 1] = eos_id
+            ids[b, n:] = cfg.pad_id
+            mask[b, n:] = 0
+    else:
+        ids[:, T - 1] = eos_id
+    pixels = torch.rand(B, 3, cfg.image, cfg.image, generator=g) * 2 - 1
+    labels = torch.randint(0, cfg.num_labels, (B,), generator=g)
+    onehot = F.one_hot(labels, cfg.num_labels).to(torch.int64)
+    return ids, mask, pixels, onehot

@@ -1,0 +1,116 @@
+"""CPU: the oracle (oracle/mm_oracle.py) against vectors produced by the reference's own code
+(tests/golden/make_golden.py).  Tolerances are fp32 round-off of two implementations of one algorithm."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mm_oracle as O
+
+torch.set_num_threads(max(1, os.cpu_count() or 1))
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+    cfg = O.OracleConfig(**ast.literal_eval(str(z["cfg"]))) if "cfg" in z.files else None
+    return z, cfg
+
+
+def t(z, k):
+    return torch.from_numpy(z[k])
+
+
+def pixels_of(cfg, z):
+    return O.synthetic_batch(cfg, int(z["B"]), int(z["T"]), int(z["seed_x"]), bool(z["pad"]) if "pad" in z.files else True)[2]
+
+
+@pytest.mark.parametrize("name", ["fwd_small_xlmr", "fwd_small_bert", "fwd_small_concat", "fwd_full_xlmr"])
+def test_forward_matches_reference(golden_dir, name):
+    z, cfg = load(golden_dir, name + ".npz")
+    P = O.make_params(cfg, int(z["seed_w"]))
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, int(z["B"]), int(z["T"]), int(z["seed_x"]), bool(z["pad"]))
+    assert torch.equal(ids, t(z, "ids")) and torch.equal(mask, t(z, "mask")) and torch.equal(onehot, t(z, "onehot"))
+    col = {}
+    with torch.no_grad():
+        out_cls, lpt, out_tim, _, feats = O.mm_forward(P, ids, mask, pixels, cfg, (t(z, "tim_ids"), t(z, "tim_mask")), collect=col)
+    for got, key in ((out_cls, "out_cls"), (lpt, "logits_per_text"), (out_tim, "out_tim"), (feats, "mm_features")):
+        ref = t(z, key)
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-5, (key, err)
+    if "vit_cls_per_layer" in z.files:
+        v = torch.stack([h[:, 0] for h in col["vit_layers"]])
+        x = torch.stack([h[:, 0] for h in col["txt_layers"]])
+        assert (v - t(z, "vit_cls_per_layer")).abs().max() < 2e-4
+        assert (x - t(z, "txt_cls_per_layer")).abs().max() < 2e-5
+
+
+def test_train_losses_and_grads_match_reference(golden_dir):
+    z, cfg = load(golden_dir, "train_small_xlmr.npz")
+    P = {k: v.requires_grad_(O.trainable(k)) for k, v in O.make_params(cfg, int(z["seed_w"])).items()}
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, int(z["B"]), int(z["T"]), int(z["seed_x"]), True)
+    w = t(z, "class_weight")
+    watch = [str(s) for s in z["watch"]]
+    for mix, (itc, itm) in {"plain": (False, False), "itc": (True, False), "itm": (False, True), "itcitm": (True, True)}.items():
+        for p in P.values():
+            p.grad = None
+        tim = (t(z, "tim_ids"), t(z, "tim_mask")) if itm else None
+        out_cls, lpt, out_tim, _, _ = O.mm_forward(P, ids, mask, pixels, cfg, tim)
+        loss = O.mix_loss(out_cls, onehot, w, lpt, out_tim, t(z, "lbl_tim"), itc, itm)
+        loss.backward()
+        assert abs(loss.item() - float(z[f"{mix}.loss"])) < 2e-6 * abs(float(z[f"{mix}.loss"])) + 1e-6
+        none_ref = {str(s) for s in z[f"{mix}.grad_none"]}
+        none_got = {k for k, p in P.items() if p.requires_grad and p.grad is None}
+        # tensors that exist in the reference module but are not on this path never get gradients there either
+        assert none_got == none_ref, (mix, none_got ^ none_ref)
+        for k in watch:
+            key = f"{mix}.gnorm.{k}"
+            if key not in z.files:
+                assert P[k].grad is None, (mix, k)
+                continue
+            g = P[k].grad
+            if k.endswith("key.bias"):      # mathematically zero (softmax shift invariance): round-off only
+                assert g.norm().item() < 1e-7 and float(z[key]) < 1e-7
+                continue
+            assert abs(g.norm().item() - float(z[key])) <= 2e-4 * float(z[key]) + 1e-9, (mix, k)
+            ref = t(z, f"{mix}.gslice.{k}")
+            if k.endswith("word_embeddings.weight"):
+                got = g[t(z, f"{mix}.gslice_rows.{k}")][:, :48]
+                assert g[cfg.pad_id].norm().item() == float(z[f"{mix}.gpad_row_norm"]) == 0.0
+            elif g.dim() == 2:
+                got = g[:8, :48]
+            else:
+                got = g.flatten()[:64]
+            assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-9, (mix, k)
+
+
+def test_itm_sampling_matches_reference(golden_dir):
+    z, _ = load(golden_dir, "itm_sampling.npz")
+    for B in (1, 2, 8, 64):
+        np.random.seed(30)
+        a, b, c = O.prepare_itm_inputs(t(z, f"B{B}.ids"), t(z, f"B{B}.mask"))
+        assert torch.equal(a, t(z, f"B{B}.tim_ids")) and torch.equal(b, t(z, f"B{B}.tim_mask")) and torch.equal(c, t(z, f"B{B}.lbl"))
+    assert z["B8.lbl"].tolist() == [1, 1, 1, 1, 0, 1, 0, 1]          # SURVEY.md §8c known answer (5)
+
+
+def test_adamw_matches_torch(golden_dir):
+    z, _ = load(golden_dir, "adamw.npz")
+    p = t(z, "p0").clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i in range(3):
+        O.adamw_step(p, t(z, "grads")[i], m, v, i + 1, float(z["lr"]), float(z["wd"]))
+        assert (p - t(z, "traj")[i]).abs().max().item() < 1e-8
+
+
+def test_losses_match_reference(golden_dir):
+    z, _ = load(golden_dir, "losses.npz")
+    assert abs(O.cls_loss(t(z, "out"), t(z, "onehot"), t(z, "w")).item() - float(z["l_cls"])) < 1e-6
+    assert abs(O.clip_loss(t(z, "sim")).item() - float(z["l_clip"])) < 1e-6
+
+
+def test_hash_dropout_rate():
+    keep = O.hash_keep_mask(1 << 20, 12345, O.stream_attn(3), 0x1234_5678_9ABC, 0.1)
+    assert abs(keep.mean() - 0.9) < 2e-3
+    k2 = O.hash_keep_mask(1 << 20, 12345, O.stream_attn(4), 0x1234_5678_9ABC, 0.1)
+    assert abs((keep & k2).mean() - 0.81) < 3e-3
