@@ -1,0 +1,139 @@
+/* mmhip -- C ABI of the MI355X-native late-fusion fine-tuning path (libmmhip.so).
+ *
+ * The reference (danaesavi/SocialMedia-TextImage-Classification-AuxLosses) has no FFI: its hot path is the Python
+ * object boundary  MMLate_Model -> MM_Model.forward  (models/mm_late.py:148-193, called at :464-468 / :572-576) plus
+ * loss.backward() / optimizer.step() (models/mm_late.py:489-491).  This header is the boundary a binding for that path
+ * binds: plain pointers and sizes only (device pointers unless said otherwise), no torch types.  Each entry point names
+ * the reference interface it replaces.
+ *
+ * Conventions
+ *   - return value: 0 = ok; < 0 = invalid argument / shape / state (MMHIP_E_*); > 0 = a hipError_t.
+ *   - never throws, never exits, never allocates device memory: the caller owns every buffer (PyTorch's allocator in
+ *     the shipped binding); the library borrows pointers for the duration of a call.
+ *   - all work is enqueued asynchronously on the caller's stream (`void* stream` is a hipStream_t); no host sync.
+ *   - one handle per device and per thread; not thread-safe.
+ */
+#ifndef MMHIP_H
+#define MMHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMHIP_E_INVALID (-1)   /* bad argument / shape outside what the kernels take */
+#define MMHIP_E_STATE (-2)     /* call order (not bound, forward not run, ...) */
+#define MMHIP_E_CAPACITY (-3)  /* batch / sequence longer than the handle was created for, or workspace too small */
+
+enum { MMHIP_BF16 = 0, MMHIP_F16 = 1, MMHIP_F32 = 2 };
+enum { MMHIP_TXT_BERT = 0, MMHIP_TXT_XLMR = 1 };
+enum { MMHIP_FUSION_CONCAT = 0, MMHIP_FUSION_ATTENTION = 1 };
+/* gradient groups: which parameters receive a gradient for a given flag set */
+enum { MMHIP_G_NEVER = 0, MMHIP_G_ITC = 1, MMHIP_G_ITM = 2, MMHIP_G_FUSION_ATT = 3, MMHIP_G_ALWAYS = 4, MMHIP_G_FROZEN = 5 };
+
+typedef struct mmhip_config {
+    int hidden, heads, inter;            /* 768, 12, 3072 (models/config.py:82-84 hard-wires 768) */
+    int layers_txt, layers_img;
+    int vocab, max_pos, type_vocab;
+    int txt_kind, pad_id;                /* MMHIP_TXT_*; XLM-R pad id 1, BERT 0 */
+    float ln_eps_txt, ln_eps_img;
+    int image, patch, proj_dim, num_labels;
+    int fusion;                          /* MMHIP_FUSION_*  (--fusion_name, models/run_mm_late.py:23) */
+    float p_hidden, p_attn, p_head;      /* text hidden / attention-prob dropout, --dropout */
+    int dtype;                           /* MMHIP_BF16 | MMHIP_F16: storage + MFMA operand type of activations */
+    int max_posts, max_text_len;         /* capacity: B <= max_posts, T <= max_text_len (ITM doubles the text rows) */
+} mmhip_config;
+
+typedef struct mmhip_param_info {
+    char name[192];                      /* state_dict key of the reference checkpoint (transformers 4.25.1 naming) */
+    int ndim;
+    int64_t dims[4];
+    int buffer;                          /* 0 = frozen flat buffer (vision tower, mm_late.py:67-69), 1 = trainable */
+    int group;                           /* MMHIP_G_* */
+    uint64_t offset, numel;              /* element offset inside the flat fp32 buffer */
+} mmhip_param_info;
+
+typedef struct mmhip_engine* mmhip_handle;
+
+/* ---- lifetime; replaces MM_Model.__init__ (models/mm_late.py:50-89) minus weight loading */
+int mmhip_create(const mmhip_config* cfg, mmhip_handle* out);
+void mmhip_destroy(mmhip_handle h);
+int mmhip_param_count(mmhip_handle h);
+int mmhip_param_info_at(mmhip_handle h, int index, mmhip_param_info* out);
+uint64_t mmhip_buffer_numel(mmhip_handle h, int buffer);        /* fp32 elements of flat buffer 0 / 1 */
+uint64_t mmhip_workspace_bytes(mmhip_handle h);                 /* activations + 16-bit weight copies */
+/* frozen / train / train_grad are flat fp32 device buffers laid out as mmhip_param_info_at describes */
+int mmhip_bind(mmhip_handle h, float* frozen, float* train, float* train_grad, void* workspace, uint64_t workspace_bytes);
+/* re-derive the 16-bit (and transposed) GEMM operand copies from the fp32 masters: which = 1 frozen, 2 train, 3 both.
+ * Call after load_state_dict (models/mm_late.py:343-345) and after every optimizer step. */
+int mmhip_refresh_weights(mmhip_handle h, int which, void* stream);
+
+/* ---- MM_Model.forward (models/mm_late.py:148-193).  ids/mask/tim_* are int64 [B,T]; pixels fp32 [B,3,image,image];
+ * outputs fp32: out_cls [B,num_labels], logits_per_text [B,B], out_tim [B,2] (only when tim_ids != NULL),
+ * mm_features [B,hidden].  train != 0 applies dropout with masks derived from `seed`. */
+int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
+                  const int64_t* tim_mask, int B, int T, int train, uint64_t seed, float* out_cls, float* logits_per_text,
+                  float* out_tim, float* mm_features, void* stream);
+
+/* ---- loss mixing of MMLate_Model.train (models/mm_late.py:471-487) on the outputs of the last forward, fused with its
+ * own backward: loss[4] = {total, cls, itc, itm}; the output gradients stay inside the handle for mmhip_backward(NULL...).
+ * onehot int64 [B,C] (models/datasets.py one-hot labels), class_w fp32 [C] or NULL (run_mm_late.py:85),
+ * lbl_tim int64 [B] or NULL.  weights: w_cls = 1 - betas, w_itc / w_itm = beta or 0 when the aux loss is off. */
+int mmhip_loss(mmhip_handle h, const int64_t* onehot, const float* class_w, const int64_t* lbl_tim, float w_cls, float w_itc,
+               float w_itm, float* loss, int* n_correct, void* stream);
+
+/* ---- loss.backward() (models/mm_late.py:489): gradients of every trainable parameter, ACCUMULATED into train_grad
+ * (which must be zero where a fresh gradient is wanted).  Pass NULL pointers to use the gradients mmhip_loss left in
+ * the handle, or explicit fp32 output gradients (autograd binding).  Stages let a data-parallel caller start the
+ * all-reduce of finished parameter ranges while later stages run: stage 0 = heads, 1..layers_txt = text layers
+ * last -> first, layers_txt+1 = embeddings.  mmhip_backward runs all of them. */
+int mmhip_backward(mmhip_handle h, const float* d_out_cls, const float* d_logits_per_text, const float* d_out_tim,
+                   const float* d_mm_features, void* stream);
+int mmhip_backward_begin(mmhip_handle h, const float* d_out_cls, const float* d_logits_per_text, const float* d_out_tim,
+                         const float* d_mm_features, void* stream);
+int mmhip_backward_stage(mmhip_handle h, int stage, void* stream);
+int mmhip_num_backward_stages(mmhip_handle h);
+/* element range [begin, end) of the trainable flat buffer whose gradients are final after `stage` */
+int mmhip_stage_grad_range(mmhip_handle h, int stage, uint64_t* begin, uint64_t* end);
+
+/* ---- optimizer.step(): torch.optim.AdamW over a flat range (models/mm_late.py:420-422, models/utils.py:280-292).
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce); zero_grad clears it afterwards. */
+int mmhip_adamw(float* p, float* g, float* m, float* v, uint64_t n, float lr, float beta1, float beta2, float eps,
+                float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+
+/* ---- timing of the dominant kernel for bench.py: HIP events recorded around every MFMA NT-GEMM launch issued by the
+ * handle on its stream while enabled; returns accumulated milliseconds, launches and algorithmic FLOPs since reset. */
+int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_t* launches, double* flops);
+
+/* ---- operator-level entry points (parity tests; the engine calls the same launchers).  dtype = MMHIP_BF16 | MMHIP_F16.
+ * 16-bit matrices are row-major with explicit leading dimensions (elements). */
+/* C[M,N] = epilogue(A[M,K] . B[N,K]^T): + bias[N] (fp32, may be NULL); act: 0 none, 1 exact-erf GELU, 2 tanh;
+ * aux_pre (may be NULL) receives the value before the activation; mul_gelu_grad_of (may be NULL): value *= gelu'(that);
+ * dropout (p > 0) on element index m*N+n with (seed, stream_id); + residual (may be NULL); out_f32 selects fp32 C. */
+int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                     const float* bias, int act, void* aux_pre, int ldaux, const void* mul_gelu_grad_of, int ldmul,
+                     float p_drop, uint64_t seed, uint32_t stream_id, const void* residual, int ldres, int out_f32,
+                     int force_slow, void* stream);
+/* C[Nn,Nc] (fp32) (+)= A[M,Nn]^T . B[M,Nc] */
+int mmhip_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int Nn, int Nc,
+                     int accumulate, int force_slow, void* stream);
+int mmhip_op_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                           int rows, int width, float eps, void* stream);
+int mmhip_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                           void* dx, const void* dres, float* dgamma, float* dbeta, int rows, int width, void* stream);
+/* qkv [posts*S, 3*hidden] packed q|k|v; maskbias fp32 [posts,S] additive (0 / -inf) or NULL; lse fp32 [posts,heads,S] */
+int mmhip_op_attn_fwd(int dtype, const void* qkv, const float* maskbias, void* ctx, float* lse, int posts, int S, int heads,
+                      float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+int mmhip_op_attn_bwd(int dtype, const void* qkv, const float* maskbias, const void* ctx, const void* dctx, const float* lse,
+                      void* dqkv, int posts, int S, int heads, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+int mmhip_op_colsum(int dtype, const void* x, int rows, int cols, int ld, float* out, void* stream);
+int mmhip_op_cast(int dtype, const float* src, void* dst, uint64_t n, int transpose_rows, int transpose_cols, void* stream);
+/* hardware-layout probe: runs one MFMA of each shape and one transposing LDS read on index-coded data and writes what
+ * each lane received (tests/test_hw_layouts.py checks the lane maps every kernel here is built on). out: int32[4096] */
+int mmhip_op_probe_layouts(int32_t* out, void* stream);
+
+const char* mmhip_version(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

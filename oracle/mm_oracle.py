@@ -199,14 +199,22 @@ def rng_u32(idx: np.ndarray, stream: int, seed: int) -> np.ndarray:
     return x
 
 
-def drop_threshold(p: float) -> int:
-    return min(int(p * 4294967296.0), 0xFFFFFFFF)
+def drop_threshold16(p: float) -> int:
+    """element dropped when its 16 random bits < thresh16 (kernels: DropCfg.thresh16)."""
+    return min(int(round(p * 65536.0)), 65535)
 
 
 def hash_keep_mask(n: int, offset: int, stream: int, seed: int, p: float) -> np.ndarray:
-    """keep[i] for linear element indices offset..offset+n-1 (True = kept)."""
-    idx = (np.arange(n, dtype=np.uint64) + np.uint64(offset)).astype(np.uint32)
-    return rng_u32(idx, stream, seed) >= np.uint32(drop_threshold(p))
+    """keep[i] for linear element indices offset..offset+n-1 (True = kept).  Element e uses 16 bits of
+    rng_u32(e >> 1): the low half for even e, the high half for odd e (mmhip_common.h: mm_keep)."""
+    e = (np.arange(n, dtype=np.uint64) + np.uint64(offset)).astype(np.uint32)
+    h = rng_u32(e >> np.uint32(1), stream, seed)
+    r = np.where((e & np.uint32(1)) == 1, h >> np.uint32(16), h & np.uint32(0xFFFF))
+    return r >= np.uint32(drop_threshold16(p))
+
+
+def keep_scale(p: float) -> float:
+    return 1.0 / (1.0 - drop_threshold16(p) / 65536.0)
 
 
 class Dropout:
@@ -221,7 +229,7 @@ class Dropout:
         if self.mode == "torch":
             return F.dropout(x, p, training=True)
         keep = torch.from_numpy(hash_keep_mask(x.numel(), offset, stream, self.seed, p)).view(x.shape)
-        return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
+        return x * keep.to(x.dtype) * keep_scale(p)
 
 
 # --------------------------------------------------------------------------------------

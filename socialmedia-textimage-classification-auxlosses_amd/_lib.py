@@ -1,0 +1,96 @@
+"""ctypes binding of libmmhip.so (include/mmhip.h).  No fallback: if the library is missing or a call fails,
+this raises -- the product path never routes around the HIP kernels."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmmhip.so")
+
+BF16, F16, F32 = 0, 1, 2
+TXT_BERT, TXT_XLMR = 0, 1
+FUSION_CONCAT, FUSION_ATTENTION = 0, 1
+G_NEVER, G_ITC, G_ITM, G_FUSION_ATT, G_ALWAYS, G_FROZEN = range(6)
+
+
+class Config(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("inter", C.c_int), ("layers_txt", C.c_int), ("layers_img", C.c_int),
+                ("vocab", C.c_int), ("max_pos", C.c_int), ("type_vocab", C.c_int), ("txt_kind", C.c_int), ("pad_id", C.c_int),
+                ("ln_eps_txt", C.c_float), ("ln_eps_img", C.c_float), ("image", C.c_int), ("patch", C.c_int),
+                ("proj_dim", C.c_int), ("num_labels", C.c_int), ("fusion", C.c_int), ("p_hidden", C.c_float),
+                ("p_attn", C.c_float), ("p_head", C.c_float), ("dtype", C.c_int), ("max_posts", C.c_int),
+                ("max_text_len", C.c_int)]
+
+
+class ParamInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 192), ("ndim", C.c_int), ("dims", C.c_int64 * 4), ("buffer", C.c_int), ("group", C.c_int),
+                ("offset", C.c_uint64), ("numel", C.c_uint64)]
+
+
+class MMHipError(RuntimeError):
+    pass
+
+
+_lib = None
+P, I, F, U64, U32, I64P = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p
+
+_SIGS = {
+    "mmhip_create": (I, [C.POINTER(Config), C.POINTER(P)]),
+    "mmhip_destroy": (None, [P]),
+    "mmhip_param_count": (I, [P]),
+    "mmhip_param_info_at": (I, [P, I, C.POINTER(ParamInfo)]),
+    "mmhip_buffer_numel": (U64, [P, I]),
+    "mmhip_workspace_bytes": (U64, [P]),
+    "mmhip_bind": (I, [P, P, P, P, P, U64]),
+    "mmhip_refresh_weights": (I, [P, I, P]),
+    "mmhip_forward": (I, [P, P, P, P, P, P, I, I, I, U64, P, P, P, P, P]),
+    "mmhip_loss": (I, [P, P, P, P, F, F, F, P, P, P]),
+    "mmhip_backward": (I, [P, P, P, P, P, P]),
+    "mmhip_backward_begin": (I, [P, P, P, P, P, P]),
+    "mmhip_backward_stage": (I, [P, I, P]),
+    "mmhip_num_backward_stages": (I, [P]),
+    "mmhip_stage_grad_range": (I, [P, I, C.POINTER(U64), C.POINTER(U64)]),
+    "mmhip_adamw": (I, [P, P, P, P, U64, F, F, F, F, F, I, F, I, P]),
+    "mmhip_gemm_timing": (I, [P, I, I, C.POINTER(C.c_double), C.POINTER(U64), C.POINTER(C.c_double)]),
+    "mmhip_op_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, P, I, F, U64, U32, P, I, I, I, P]),
+    "mmhip_op_gemm_tn": (I, [I, P, I, P, I, P, I, I, I, I, I, I, P]),
+    "mmhip_op_layernorm_fwd": (I, [I, P, P, P, P, P, P, I, I, F, P]),
+    "mmhip_op_layernorm_bwd": (I, [I, P, P, P, P, P, P, P, P, P, I, I, P]),
+    "mmhip_op_attn_fwd": (I, [I, P, P, P, P, I, I, I, F, U64, U32, P]),
+    "mmhip_op_attn_bwd": (I, [I, P, P, P, P, P, P, I, I, I, F, U64, U32, P]),
+    "mmhip_op_colsum": (I, [I, P, I, I, I, P, P]),
+    "mmhip_op_cast": (I, [I, P, P, U64, I, I, P]),
+    "mmhip_op_probe_layouts": (I, [P, P]),
+    "mmhip_version": (C.c_char_p, []),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """The loaded library; raises MMHipError when it has not been built (python -m smtc_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MMHipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(hipcc, gfx950). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "invalid state / call order", -3: "capacity exceeded"}.get(rc, f"hipError_t {rc}" if rc > 0 else "error")
+        raise MMHipError(f"mmhip {what} failed: {kind} ({rc})")
+
+
+def ptr(t):
+    """device (or host) pointer of a torch tensor, or NULL."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

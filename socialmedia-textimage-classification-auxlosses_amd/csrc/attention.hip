@@ -1,0 +1,364 @@
+// Fused self-attention forward / backward for one (post, head) per workgroup; head dim 64, S <= 224 keys.
+// The whole K / V of a head stays in LDS (S=128: 16 KB each; S=197: 28 KB each), scores never touch HBM.
+//
+// MFMA 32x32x16.  Forward computes S^T = K.Q^T so a lane owns one query column: the soft-max is a reduction over
+// the lane's registers (+ one cross-half shuffle), and the fp32 accumulator tile P^T is, after conversion, directly
+// the B operand of O^T = V^T.P^T (MI355X guide "accumulator tile as the next MFMA's operand").  V^T fragments come
+// from the row-major V image with the transposing LDS read ds_read_b64_tr_b16.
+//
+// Backward (text tower only, S <= 128): wave w owns key tile w; S = Q.K^T and dP = dO.V^T are computed with the key on
+// the lane, so P and dS are the B operands of dV^T = dO^T.P and dK^T = Q^T.dS; only dS crosses LDS, once, for dQ.
+#include "mmhip_common.h"
+#include "mmhip_kernels.h"
+
+namespace mmhip {
+
+static constexpr int HD = 64;          // head dim
+static constexpr float LOG2E = 1.4426950408889634f;
+
+// byte offset of 16-B chunk `ch` (0..7) of row `row` in a [rows][64] 16-bit image read by rows (ds_read_b128)
+__device__ __forceinline__ int rowimg_off(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
+// ... in an image read with the transposing read (4 rows x 16 cols blocks): flip the 64-B half on rows 2,3 mod 4
+__device__ __forceinline__ int trimg_off(int row, int ch) { return row * 128 + ((ch ^ (((row >> 1) & 1) << 2)) << 4); }
+
+// A-operand fragment X^T (32 "rows" = feature columns c0..c0+31 of the image, k = 16 image rows) for k-order
+// element j of lane half h = image row r0 + 8*(j>>2) + 4*h + (j&3)   (the accumulator-as-operand order)
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v8 tr_frag_acc_order(const char* img, int r0, int c0, int lane) {
+    const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const int col = c0 + 16 * g1 + 4 * p;
+    const int ra = r0 + 4 * h + q, rb = ra + 8;
+    return join_tr<T>(lds_read_tr4(img, trimg_off(ra, col >> 3) + (col & 7) * 2), lds_read_tr4(img, trimg_off(rb, col >> 3) + (col & 7) * 2));
+}
+// same, natural k order: element j of lane half h = image row r0 + 8*h + j
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v8 tr_frag_natural(const char* img, int r0, int c0, int lane) {
+    const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const int col = c0 + 16 * g1 + 4 * p;
+    const int ra = r0 + 8 * h + q, rb = ra + 4;
+    return join_tr<T>(lds_read_tr4(img, trimg_off(ra, col >> 3) + (col & 7) * 2), lds_read_tr4(img, trimg_off(rb, col >> 3) + (col & 7) * 2));
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_image(char* img, const T* src, int ld, int rows_valid, int rows_pad, bool tr_layout, int tid, int nthreads) {
+    typedef typename Vec<T>::v8 v8;
+    for (int idx = tid; idx < rows_pad * 8; idx += nthreads) {
+        const int row = idx >> 3, ch = idx & 7;
+        const int gr = min(row, rows_valid - 1);
+        v8 v = *reinterpret_cast<const v8*>(src + (size_t)gr * ld + ch * 8);
+        *reinterpret_cast<v8*>(img + (tr_layout ? trimg_off(row, ch) : rowimg_off(row, ch))) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T, int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Vec<T>::v8 v8;
+    typedef typename Vec<T>::v4 v4;
+    constexpr int SP = NKT * 32;
+    char* Kimg = smem;                       // [SP][64] row image
+    char* Vimg = smem + SP * 128;            // [SP][64] tr image
+    float* mb = reinterpret_cast<float*>(smem + 2 * SP * 128);   // [SP] additive key bias * log2e
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int head = blockIdx.x, post = blockIdx.y;
+    const int S = a.S;
+    const T* base = (const T*)a.qkv + (size_t)post * S * a.ld_qkv + head * HD;
+    stage_image<T>(Kimg, base + a.hidden, a.ld_qkv, S, SP, false, tid, 256);
+    stage_image<T>(Vimg, base + 2 * a.hidden, a.ld_qkv, S, SP, true, tid, 256);
+    for (int k = tid; k < SP; k += 256) {
+        float b = (k < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f) : -INFINITY;
+        mb[k] = b * LOG2E;
+    }
+    __syncthreads();
+    const int r = lane & 31, h2 = lane >> 5;
+    const float sc = a.scale * LOG2E;
+    const int nqt = (S + 31) / 32;
+    for (int qt = w; qt < nqt; qt += 4) {
+        const int qrow = min(qt * 32 + r, S - 1);
+        const T* qp = base + (size_t)qrow * a.ld_qkv + 8 * h2;
+        v8 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const v8*>(qp + 16 * s);
+        // S^T tiles: acc[kt][reg] = score(key = kt*32 + (reg&3) + 8*(reg>>2) + 4*h2, query = qt*32 + r)
+        f32x16 acc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            acc[kt] = f32x16{};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                v8 kf = lds_read8<T>(Kimg, rowimg_off(kt * 32 + r, 2 * s + h2));
+                acc[kt] = mfma32(kf, qf[s], acc[kt]);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 b = *reinterpret_cast<const f32x4*>(mb + kt * 32 + 8 * g + 4 * h2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[kt][4 * g + e] * sc + b[e];
+                    acc[kt][4 * g + e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float p = exp2f(acc[kt][e] - mx);
+                acc[kt][e] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 32);
+        const int q = qt * 32 + r;
+        if (a.lse && h2 == 0 && q < S) a.lse[((size_t)post * a.heads + head) * S + q] = (mx + log2f(sum)) * (1.0f / LOG2E);
+        const float inv = 1.0f / sum;
+        const bool dropping = a.drop.thresh16 != 0;
+        const uint32_t ebase = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)min(q, S - 1)) * (uint32_t)S;
+        f32x16 oacc[2] = {f32x16{}, f32x16{}};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                v8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int reg = 8 * s2 + j;
+                    float p = acc[kt][reg] * inv;
+                    if (dropping) {
+                        const int key = kt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+                        p = mm_keep(ebase + (uint32_t)key, a.drop) ? p * a.drop.keep_scale : 0.f;
+                    }
+                    pf[j] = from_f<T>(p);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    v8 vf = tr_frag_acc_order<T>(Vimg, kt * 32 + 16 * s2, dt * 32, lane);
+                    oacc[dt] = mfma32(vf, pf, oacc[dt]);
+                }
+            }
+        }
+        // oacc[dt][reg] = O(query q, d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h2)
+        if (q < S) {
+            T* op = (T*)a.ctx + ((size_t)post * S + q) * a.ld_ctx + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    v4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = from_f<T>(oacc[dt][4 * g + e]);
+                    *reinterpret_cast<v4*>(op + dt * 32 + 8 * g + 4 * h2) = o;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// LDS: Qtr, dOtr, Ktr images [SP][64] (tr layout), dS [64][SP] 16-bit row image, lse / D / maskbias floats.
+__device__ __forceinline__ int ds_off(int row, int ch, int sp_chunks) {   // [64 rows][SP keys] 16-bit, 16-B chunks swizzled
+    return row * (sp_chunks * 16) + ((ch ^ (row & (sp_chunks - 1) & 15)) << 4);
+}
+
+template <typename T, int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Vec<T>::v8 v8;
+    typedef typename Vec<T>::v4 v4;
+    constexpr int SP = NKT * 32;
+    constexpr int SPC = SP / 8;                 // 16-B chunks per dS row (4, 8, 16)
+    char* Qtr = smem;
+    char* dOtr = smem + SP * 128;
+    char* Ktr = smem + 2 * SP * 128;
+    char* dSimg = smem + 3 * SP * 128;          // 64 * SP * 2 bytes
+    float* lse2 = reinterpret_cast<float*>(dSimg + 64 * SP * 2);   // lse * log2e
+    float* Dv = lse2 + SP;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int head = blockIdx.x, post = blockIdx.y;
+    const int S = a.S;
+    const size_t row0 = (size_t)post * S;
+    const T* qb = (const T*)a.qkv + row0 * a.ld_qkv + head * HD;
+    const T* kb = qb + a.hidden;
+    const T* vb = qb + 2 * a.hidden;
+    const T* dob = (const T*)a.dctx + row0 * a.ld_ctx + head * HD;
+    const T* ob = (const T*)a.ctx + row0 * a.ld_ctx + head * HD;
+    stage_image<T>(Qtr, qb, a.ld_qkv, S, SP, true, tid, 256);
+    stage_image<T>(dOtr, dob, a.ld_ctx, S, SP, true, tid, 256);
+    stage_image<T>(Ktr, kb, a.ld_qkv, S, SP, true, tid, 256);
+    for (int q = tid; q < SP; q += 256) {
+        float d = 0.f, l = 0.f;
+        if (q < S) {
+            const T* o = ob + (size_t)q * a.ld_ctx;
+            const T* g = dob + (size_t)q * a.ld_ctx;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                v8 ov = *reinterpret_cast<const v8*>(o + c * 8), gv = *reinterpret_cast<const v8*>(g + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += to_f<T>(ov[e]) * to_f<T>(gv[e]);
+            }
+            l = a.lse[((size_t)post * a.heads + head) * S + q] * LOG2E;
+        }
+        Dv[q] = d;
+        lse2[q] = l;
+    }
+    const int r = lane & 31, h2 = lane >> 5;
+    const bool has_keys = w < NKT;              // wave w owns keys 32w .. 32w+31
+    const int key = w * 32 + r;
+    const int krow = min(key, S - 1);
+    v8 kf[4], vf[4];
+    float mbk = 0.f;
+    if (has_keys) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = *reinterpret_cast<const v8*>(kb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2);
+            vf[s] = *reinterpret_cast<const v8*>(vb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2);
+        }
+        mbk = (key < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + key] : 0.f) : -INFINITY;
+        mbk *= LOG2E;
+    }
+    __syncthreads();
+    const float sc = a.scale * LOG2E;
+    const bool dropping = a.drop.thresh16 != 0;
+    f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
+    constexpr int NQT = NKT;
+    for (int pair = 0; pair < (NQT + 1) / 2; ++pair) {
+        if (has_keys) {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int qt = pair * 2 + t2;
+                if (qt >= NQT) break;
+                const int q0 = qt * 32;
+                const int qrow = min(q0 + r, S - 1);
+                f32x16 sacc = f32x16{}, pacc = f32x16{};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    v8 qf = *reinterpret_cast<const v8*>(qb + (size_t)qrow * a.ld_qkv + 16 * s + 8 * h2);
+                    v8 gf = *reinterpret_cast<const v8*>(dob + (size_t)qrow * a.ld_ctx + 16 * s + 8 * h2);
+                    sacc = mfma32(qf, kf[s], sacc);      // S[q][key]
+                    pacc = mfma32(gf, vf[s], pacc);      // dP[q][key]
+                }
+                // element reg <-> query q0 + (reg&3) + 8*(reg>>2) + 4*h2, key = this lane's key
+                v8 pfrag[2], dsfrag[2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2 + q0 + 8 * g + 4 * h2);
+                    f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + q0 + 8 * g + 4 * h2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int reg = 4 * g + e;
+                        const int q = q0 + 8 * g + 4 * h2 + e;
+                        float p = exp2f(sacc[reg] * sc + mbk - l4[e]);
+                        if (q >= S) p = 0.f;
+                        float pd = p, dpd = pacc[reg];
+                        if (dropping) {
+                            const uint32_t eidx = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)min(q, S - 1)) * (uint32_t)S + (uint32_t)min(key, S - 1);
+                            const bool kp = mm_keep(eidx, a.drop);
+                            pd = kp ? p * a.drop.keep_scale : 0.f;
+                            dpd = kp ? dpd * a.drop.keep_scale : 0.f;
+                        }
+                        const float ds = p * (dpd - d4[e]) * a.scale;
+                        pfrag[reg >> 3][reg & 7] = from_f<T>(pd);
+                        dsfrag[reg >> 3][reg & 7] = from_f<T>(ds);
+                        // dS row image for dQ: row = t2*32 + (q - q0), column = key
+                        const int drow = t2 * 32 + 8 * g + 4 * h2 + e;
+                        *reinterpret_cast<T*>(dSimg + ds_off(drow, key >> 3, SPC) + (key & 7) * 2) = from_f<T>(ds);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        v8 gt = tr_frag_acc_order<T>(dOtr, q0 + 16 * s2, dt * 32, lane);   // dO^T[d][q]
+                        dv[dt] = mfma32(gt, pfrag[s2], dv[dt]);
+                        v8 qtf = tr_frag_acc_order<T>(Qtr, q0 + 16 * s2, dt * 32, lane);   // Q^T[d][q]
+                        dk[dt] = mfma32(qtf, dsfrag[s2], dk[dt]);
+                    }
+            }
+        }
+        __syncthreads();
+        {   // dQ tile (query tile pair*2 + (w>>1), d tile w&1) = dS[q][:] . K[:, d]
+            const int qi = w >> 1, dt = w & 1;
+            const int qt = pair * 2 + qi;
+            if (qt < NQT) {
+                f32x16 dq = f32x16{};
+#pragma unroll
+                for (int ks = 0; ks < SP / 16; ++ks) {
+                    v8 dsf = lds_read8<T>(dSimg, ds_off(qi * 32 + r, 2 * ks + h2, SPC));
+                    v8 ktf = tr_frag_natural<T>(Ktr, ks * 16, dt * 32, lane);
+                    dq = mfma32(dsf, ktf, dq);
+                }
+                // dq[reg] = dQ(query qt*32 + (reg&3) + 8*(reg>>2) + 4*h2, d = dt*32 + r)
+                T* dqp = (T*)a.dqkv + row0 * a.ld_qkv + head * HD + dt * 32 + r;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int q = qt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+                    if (q < S) dqp[(size_t)q * a.ld_qkv] = from_f<T>(dq[reg]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (has_keys && key < S) {
+        // dk[dt][reg] = dK(key, d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h2)
+        T* dkp = (T*)a.dqkv + (row0 + key) * a.ld_qkv + a.hidden + head * HD;
+        T* dvp = dkp + a.hidden;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4 o1, o2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o1[e] = from_f<T>(dk[dt][4 * g + e]); o2[e] = from_f<T>(dv[dt][4 * g + e]); }
+                *reinterpret_cast<v4*>(dkp + dt * 32 + 8 * g + 4 * h2) = o1;
+                *reinterpret_cast<v4*>(dvp + dt * 32 + 8 * g + 4 * h2) = o2;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+template <typename T, int NKT>
+static void launch_fwd_t(const AttnArgs& a, hipStream_t s) {
+    const int lds = 2 * NKT * 32 * 128 + NKT * 32 * 4;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+    hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), dim3(a.heads, a.posts), dim3(256), lds, s, a);
+}
+template <typename T>
+static hipError_t launch_fwd_d(const AttnArgs& a, hipStream_t s) {
+    if (a.S <= 32) launch_fwd_t<T, 1>(a, s);
+    else if (a.S <= 64) launch_fwd_t<T, 2>(a, s);
+    else if (a.S <= 128) launch_fwd_t<T, 4>(a, s);
+    else if (a.S <= 224) launch_fwd_t<T, 7>(a, s);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s) {
+    if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1) return hipErrorInvalidValue;
+    return dtype == DT_BF16 ? launch_fwd_d<bf16_t>(a, s) : launch_fwd_d<f16_t>(a, s);
+}
+template <typename T, int NKT>
+static void launch_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
+    const int lds = 3 * NKT * 32 * 128 + 64 * NKT * 32 * 2 + 2 * NKT * 32 * 4;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+    hipLaunchKernelGGL((attn_bwd_kernel<T, NKT>), dim3(a.heads, a.posts), dim3(256), lds, s, a);
+}
+template <typename T>
+static hipError_t launch_bwd_d(const AttnBwdArgs& a, hipStream_t s) {
+    if (a.S <= 32) launch_bwd_t<T, 1>(a, s);
+    else if (a.S <= 64) launch_bwd_t<T, 2>(a, s);
+    else if (a.S <= 128) launch_bwd_t<T, 4>(a, s);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t s) {
+    if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1) return hipErrorInvalidValue;
+    return dtype == DT_BF16 ? launch_bwd_d<bf16_t>(a, s) : launch_bwd_d<f16_t>(a, s);
+}
+
+}  // namespace mmhip

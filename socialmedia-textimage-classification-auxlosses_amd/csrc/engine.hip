@@ -1,0 +1,766 @@
+// mmhip engine: owns the flat parameter layout, the workspace carve-up and the launch sequence of one
+// forward / backward of the late-fusion model (reference models/mm_late.py:148-193 + the HF dual encoder it calls).
+// Everything is enqueued on the caller's stream from this single C++ call path: no per-op host round trip.
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cmath>
+#include "mmhip_common.h"
+#include "mmhip_kernels.h"
+#include "../../include/mmhip.h"
+
+using namespace mmhip;
+
+namespace {
+
+struct LayerOff {   // element offsets into a flat fp32 buffer
+    size_t qkv_w, qkv_b, ao_w, ao_b, ln1_w, ln1_b, fc1_w, fc1_b, fc2_w, fc2_b, ln2_w, ln2_b, begin, end;
+};
+struct LayerW16 {   // 16-bit GEMM operand copies (byte offsets into the workspace)
+    size_t qkv, ao, fc1, fc2, qkvT, aoT, fc1T, fc2T;
+};
+struct TextAct {    // saved activations of one text layer (byte offsets into the workspace)
+    size_t qkv, ctx, pre1, a1, u, h, pre2, out, mean1, rstd1, mean2, rstd2, lse;
+};
+struct Stream16 { size_t off; };
+
+#define CHECK_HIP(expr)                       \
+    do {                                      \
+        hipError_t _e = (expr);               \
+        if (_e != hipSuccess) return (int)_e; \
+    } while (0)
+
+}  // namespace
+
+struct mmhip_engine {
+    mmhip_config cfg;
+    std::vector<mmhip_param_info> params;
+    size_t n_frozen = 0, n_train = 0;
+    // offsets (elements) ---------------------------------------------------------------
+    std::vector<LayerOff> vit, txt;
+    size_t v_cls, v_pos, v_patch_w, v_patch_b, v_ln_w, v_ln_b, v_pool_w, v_pool_b;          // frozen
+    size_t t_word, t_pos, t_type, t_eln_w, t_eln_b, t_pool_w, t_pool_b;                     // train
+    size_t logit_scale, vproj_w, tproj_w;
+    size_t fq_w, fq_b, fk_w, fk_b, fv_w, fv_b, fus_w, fus_b, cls_w, cls_b, tim_w, tim_b;
+    size_t heads_begin, heads_end, emb_begin, emb_end;
+    // bound buffers --------------------------------------------------------------------
+    float* frozen = nullptr; float* train = nullptr; float* grad = nullptr;
+    char* ws = nullptr; size_t ws_bytes = 0, ws_need = 0;
+    // workspace offsets (bytes) --------------------------------------------------------
+    std::vector<LayerW16> vit_w16, txt_w16;
+    size_t patch_w16;
+    std::vector<TextAct> tact;
+    size_t ids_all, mask_all, pos_ids, maskbias, x0, xhat_emb, rstd_emb;
+    size_t v_patches, v_pe, v_x, v_ln, v_qkv, v_ctx, v_h, v_out;                             // ViT ping-pong
+    size_t g_dx, g_dx2, g_dpre, g_ddrop, g_dqkv, g_dctx, g_du;                               // backward temporaries
+    // heads (fp32) ----------------------------------------------------------------------
+    size_t h_vpool, h_tpool, h_txt_e, h_img_e, h_txt_n, h_img_n, h_txt_inv, h_img_inv, h_logits;
+    size_t h_q, h_qk, h_prob, h_xbar, h_z, h_feats, h_featd, h_out_cls, h_out_tim;
+    size_t h_d_out_cls, h_d_logits, h_d_out_tim, h_dfeats, h_dpre, h_dz, h_dxcls, h_dxbar, h_dqk, h_dq, h_dtxt_e, h_dimg_e,
+        h_dtpool, h_dprepool, h_loss;
+    // state of the last forward --------------------------------------------------------
+    int B = 0, T = 0, Bt = 0; bool itm = false, train_mode = false, fwd_done = false, bwd_begun = false;
+    uint64_t seed = 0;
+    const float *bd_out_cls = nullptr, *bd_logits = nullptr, *bd_out_tim = nullptr, *bd_feats = nullptr;
+    // GEMM timing ----------------------------------------------------------------------
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; double flops; };
+    std::vector<Ev> evs; size_t ev_used = 0;
+
+    template <typename U> U* wsp(size_t off) const { return reinterpret_cast<U*>(ws + off); }
+    int dt() const { return cfg.dtype; }
+    size_t esz() const { return 2; }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ layout
+struct Builder {
+    mmhip_engine& e;
+    size_t off[2] = {0, 0};
+    size_t add(const std::string& name, int buffer, int group, std::initializer_list<int64_t> dims) {
+        mmhip_param_info p;
+        memset(&p, 0, sizeof(p));
+        strncpy(p.name, name.c_str(), sizeof(p.name) - 1);
+        p.ndim = (int)dims.size();
+        size_t n = 1;
+        int i = 0;
+        for (auto d : dims) { p.dims[i++] = d; n *= (size_t)d; }
+        p.buffer = buffer;
+        p.group = group;
+        p.offset = off[buffer];
+        p.numel = n;
+        e.params.push_back(p);
+        off[buffer] += (n + 3) & ~(size_t)3;      // keep every tensor 16-byte aligned
+        return (size_t)p.offset;
+    }
+};
+
+void add_text_layer(Builder& b, const mmhip_config& c, int l, LayerOff& o) {
+    const int H = c.hidden, I = c.inter;
+    const std::string p = "dual_encoder.text_model.encoder.layer." + std::to_string(l) + ".";
+    const int g = MMHIP_G_ALWAYS;
+    o.begin = b.off[1];
+    o.qkv_w = b.add(p + "attention.self.query.weight", 1, g, {H, H});
+    b.add(p + "attention.self.key.weight", 1, g, {H, H});
+    b.add(p + "attention.self.value.weight", 1, g, {H, H});
+    o.qkv_b = b.add(p + "attention.self.query.bias", 1, g, {H});
+    b.add(p + "attention.self.key.bias", 1, g, {H});
+    b.add(p + "attention.self.value.bias", 1, g, {H});
+    o.ao_w = b.add(p + "attention.output.dense.weight", 1, g, {H, H});
+    o.ao_b = b.add(p + "attention.output.dense.bias", 1, g, {H});
+    o.ln1_w = b.add(p + "attention.output.LayerNorm.weight", 1, g, {H});
+    o.ln1_b = b.add(p + "attention.output.LayerNorm.bias", 1, g, {H});
+    o.fc1_w = b.add(p + "intermediate.dense.weight", 1, g, {I, H});
+    o.fc1_b = b.add(p + "intermediate.dense.bias", 1, g, {I});
+    o.fc2_w = b.add(p + "output.dense.weight", 1, g, {H, I});
+    o.fc2_b = b.add(p + "output.dense.bias", 1, g, {H});
+    o.ln2_w = b.add(p + "output.LayerNorm.weight", 1, g, {H});
+    o.ln2_b = b.add(p + "output.LayerNorm.bias", 1, g, {H});
+    o.end = b.off[1];
+}
+void add_vit_layer(Builder& b, const mmhip_config& c, int l, LayerOff& o) {
+    const int H = c.hidden, I = c.inter;
+    const std::string p = "dual_encoder.vision_model.encoder.layer." + std::to_string(l) + ".";
+    const int g = MMHIP_G_FROZEN;
+    o.begin = b.off[0];
+    o.qkv_w = b.add(p + "attention.attention.query.weight", 0, g, {H, H});
+    b.add(p + "attention.attention.key.weight", 0, g, {H, H});
+    b.add(p + "attention.attention.value.weight", 0, g, {H, H});
+    o.qkv_b = b.add(p + "attention.attention.query.bias", 0, g, {H});
+    b.add(p + "attention.attention.key.bias", 0, g, {H});
+    b.add(p + "attention.attention.value.bias", 0, g, {H});
+    o.ao_w = b.add(p + "attention.output.dense.weight", 0, g, {H, H});
+    o.ao_b = b.add(p + "attention.output.dense.bias", 0, g, {H});
+    o.fc1_w = b.add(p + "intermediate.dense.weight", 0, g, {I, H});
+    o.fc1_b = b.add(p + "intermediate.dense.bias", 0, g, {I});
+    o.fc2_w = b.add(p + "output.dense.weight", 0, g, {H, I});
+    o.fc2_b = b.add(p + "output.dense.bias", 0, g, {H});
+    o.ln1_w = b.add(p + "layernorm_before.weight", 0, g, {H});
+    o.ln1_b = b.add(p + "layernorm_before.bias", 0, g, {H});
+    o.ln2_w = b.add(p + "layernorm_after.weight", 0, g, {H});
+    o.ln2_b = b.add(p + "layernorm_after.bias", 0, g, {H});
+    o.end = b.off[0];
+}
+
+void build_layout(mmhip_engine& e) {
+    const mmhip_config& c = e.cfg;
+    const int H = c.hidden, C = c.num_labels, E = c.proj_dim, P = (c.image / c.patch) * (c.image / c.patch) + 1;
+    Builder b{e};
+    // ---- frozen: vision tower (every dual_encoder parameter with 'vision' in its name, mm_late.py:67-69)
+    const std::string vm = "dual_encoder.vision_model.";
+    e.v_cls = b.add(vm + "embeddings.cls_token", 0, MMHIP_G_FROZEN, {1, 1, H});
+    e.v_pos = b.add(vm + "embeddings.position_embeddings", 0, MMHIP_G_FROZEN, {1, P, H});
+    e.v_patch_w = b.add(vm + "embeddings.patch_embeddings.projection.weight", 0, MMHIP_G_FROZEN, {H, 3, c.patch, c.patch});
+    e.v_patch_b = b.add(vm + "embeddings.patch_embeddings.projection.bias", 0, MMHIP_G_FROZEN, {H});
+    e.vit.resize(c.layers_img);
+    for (int l = 0; l < c.layers_img; ++l) add_vit_layer(b, c, l, e.vit[l]);
+    e.v_ln_w = b.add(vm + "layernorm.weight", 0, MMHIP_G_FROZEN, {H});
+    e.v_ln_b = b.add(vm + "layernorm.bias", 0, MMHIP_G_FROZEN, {H});
+    e.v_pool_w = b.add(vm + "pooler.dense.weight", 0, MMHIP_G_FROZEN, {H, H});
+    e.v_pool_b = b.add(vm + "pooler.dense.bias", 0, MMHIP_G_FROZEN, {H});
+    // ---- trainable, ordered [never | ITC | ITM | fusion-attention | always: heads, layers last->first, embeddings]
+    for (const char* n : {"aspectattention", "linear_iadds", "linear_gmu_t", "linear_gmu_v"}) {
+        const int out = !strcmp(n, "aspectattention") ? 1 : (!strcmp(n, "linear_iadds") ? 2 : 2 * H);
+        b.add(std::string(n) + ".weight", 1, MMHIP_G_NEVER, {out, H});
+        b.add(std::string(n) + ".bias", 1, MMHIP_G_NEVER, {out});
+    }
+    e.heads_begin = b.off[1];
+    e.logit_scale = b.add("dual_encoder.logit_scale", 1, MMHIP_G_ITC, {});
+    e.vproj_w = b.add("dual_encoder.visual_projection.weight", 1, MMHIP_G_ITC, {E, H});
+    e.tproj_w = b.add("dual_encoder.text_projection.weight", 1, MMHIP_G_ITC, {E, H});
+    e.t_pool_w = b.add("dual_encoder.text_model.pooler.dense.weight", 1, MMHIP_G_ITC, {H, H});
+    e.t_pool_b = b.add("dual_encoder.text_model.pooler.dense.bias", 1, MMHIP_G_ITC, {H});
+    e.tim_w = b.add("linear_tim.weight", 1, MMHIP_G_ITM, {2, H});
+    e.tim_b = b.add("linear_tim.bias", 1, MMHIP_G_ITM, {2});
+    e.fq_w = b.add("fc_Q.weight", 1, MMHIP_G_FUSION_ATT, {H, H});
+    e.fq_b = b.add("fc_Q.bias", 1, MMHIP_G_FUSION_ATT, {H});
+    e.fk_w = b.add("fc_K.weight", 1, MMHIP_G_FUSION_ATT, {H, H});
+    e.fk_b = b.add("fc_K.bias", 1, MMHIP_G_FUSION_ATT, {H});
+    e.fv_w = b.add("fc_V.weight", 1, MMHIP_G_FUSION_ATT, {H, H});
+    e.fv_b = b.add("fc_V.bias", 1, MMHIP_G_FUSION_ATT, {H});
+    e.fus_w = b.add("linear_fusion.weight", 1, MMHIP_G_ALWAYS, {H, 2 * H});
+    e.fus_b = b.add("linear_fusion.bias", 1, MMHIP_G_ALWAYS, {H});
+    e.cls_w = b.add("linear_cls.weight", 1, MMHIP_G_ALWAYS, {C, H});
+    e.cls_b = b.add("linear_cls.bias", 1, MMHIP_G_ALWAYS, {C});
+    e.heads_end = b.off[1];
+    e.txt.resize(c.layers_txt);
+    for (int l = c.layers_txt - 1; l >= 0; --l) add_text_layer(b, c, l, e.txt[l]);
+    const std::string tm = "dual_encoder.text_model.embeddings.";
+    e.emb_begin = b.off[1];
+    e.t_eln_w = b.add(tm + "LayerNorm.weight", 1, MMHIP_G_ALWAYS, {H});
+    e.t_eln_b = b.add(tm + "LayerNorm.bias", 1, MMHIP_G_ALWAYS, {H});
+    e.t_type = b.add(tm + "token_type_embeddings.weight", 1, MMHIP_G_ALWAYS, {c.type_vocab, H});
+    e.t_pos = b.add(tm + "position_embeddings.weight", 1, MMHIP_G_ALWAYS, {c.max_pos, H});
+    e.t_word = b.add(tm + "word_embeddings.weight", 1, MMHIP_G_ALWAYS, {c.vocab, H});
+    e.emb_end = b.off[1];
+    e.n_frozen = b.off[0];
+    e.n_train = b.off[1];
+}
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; }
+};
+
+void build_workspace(mmhip_engine& e) {
+    const mmhip_config& c = e.cfg;
+    const size_t H = c.hidden, I = c.inter, E = c.proj_dim, C = c.num_labels;
+    const size_t Bm = c.max_posts, Tm = c.max_text_len, P = (c.image / c.patch) * (c.image / c.patch) + 1;
+    const size_t Mt = 2 * Bm * Tm, Mv = Bm * P, Bt = 2 * Bm;
+    Carver w;
+    auto w16 = [&](std::vector<LayerW16>& v, int n, bool transposed) {
+        v.resize(n);
+        for (auto& L : v) {
+            L.qkv = w.take(3 * H * H * 2); L.ao = w.take(H * H * 2); L.fc1 = w.take(I * H * 2); L.fc2 = w.take(H * I * 2);
+            if (transposed) { L.qkvT = w.take(3 * H * H * 2); L.aoT = w.take(H * H * 2); L.fc1T = w.take(I * H * 2); L.fc2T = w.take(H * I * 2); }
+        }
+    };
+    w16(e.vit_w16, c.layers_img, false);
+    w16(e.txt_w16, c.layers_txt, true);
+    e.patch_w16 = w.take(H * 3 * c.patch * c.patch * 2);
+    e.ids_all = w.take(Bt * Tm * 8); e.mask_all = w.take(Bt * Tm * 8); e.pos_ids = w.take(Bt * Tm * 4); e.maskbias = w.take(Bt * Tm * 4);
+    e.x0 = w.take(Mt * H * 2); e.xhat_emb = w.take(Mt * H * 2); e.rstd_emb = w.take(Mt * 4);
+    e.tact.resize(c.layers_txt);
+    for (auto& a : e.tact) {
+        a.qkv = w.take(Mt * 3 * H * 2); a.ctx = w.take(Mt * H * 2); a.pre1 = w.take(Mt * H * 2); a.a1 = w.take(Mt * H * 2);
+        a.u = w.take(Mt * I * 2); a.h = w.take(Mt * I * 2); a.pre2 = w.take(Mt * H * 2); a.out = w.take(Mt * H * 2);
+        a.mean1 = w.take(Mt * 4); a.rstd1 = w.take(Mt * 4); a.mean2 = w.take(Mt * 4); a.rstd2 = w.take(Mt * 4);
+        a.lse = w.take(Bt * c.heads * Tm * 4);
+    }
+    e.v_patches = w.take(Bm * (P - 1) * 3 * c.patch * c.patch * 2); e.v_pe = w.take(Bm * (P - 1) * H * 2);
+    e.v_x = w.take(Mv * H * 2); e.v_ln = w.take(Mv * H * 2); e.v_qkv = w.take(Mv * 3 * H * 2); e.v_ctx = w.take(Mv * H * 2);
+    e.v_h = w.take(Mv * I * 2); e.v_out = w.take(Mv * H * 2);
+    e.g_dx = w.take(Mt * H * 2); e.g_dx2 = w.take(Mt * H * 2); e.g_dpre = w.take(Mt * H * 2); e.g_ddrop = w.take(Mt * H * 2);
+    e.g_dqkv = w.take(Mt * 3 * H * 2); e.g_dctx = w.take(Mt * H * 2); e.g_du = w.take(Mt * I * 2);
+    auto f = [&](size_t n) { return w.take(n * 4); };
+    e.h_vpool = f(Bm * H); e.h_tpool = f(Bm * H); e.h_txt_e = f(Bm * E); e.h_img_e = f(Bm * E); e.h_txt_n = f(Bm * E); e.h_img_n = f(Bm * E);
+    e.h_txt_inv = f(Bm); e.h_img_inv = f(Bm); e.h_logits = f(Bm * Bm);
+    e.h_q = f(Bt * H); e.h_qk = f(Bt * H); e.h_prob = f(Bt * P); e.h_xbar = f(Bt * H); e.h_z = f(Bt * 2 * H); e.h_feats = f(Bt * H);
+    e.h_featd = f(Bm * H); e.h_out_cls = f(Bm * C); e.h_out_tim = f(Bm * 2);
+    e.h_d_out_cls = f(Bm * C); e.h_d_logits = f(Bm * Bm); e.h_d_out_tim = f(Bm * 2); e.h_dfeats = f(Bt * H); e.h_dpre = f(Bt * H);
+    e.h_dz = f(Bt * 2 * H); e.h_dxcls = f(Bt * H); e.h_dxbar = f(Bt * H); e.h_dqk = f(Bt * H); e.h_dq = f(Bt * H);
+    e.h_dtxt_e = f(Bm * E); e.h_dimg_e = f(Bm * E); e.h_dtpool = f(Bm * H); e.h_dprepool = f(Bm * H); e.h_loss = f(8);
+    e.ws_need = w.off;
+}
+
+DropCfg make_drop(float p, uint64_t seed, uint32_t stream, bool on) {
+    DropCfg d;
+    d.seed = seed;
+    d.stream = stream;
+    uint32_t t = on ? (uint32_t)lrintf(p * 65536.0f) : 0u;
+    if (t > 65535u) t = 65535u;
+    d.thresh16 = t;
+    d.keep_scale = 1.0f / (1.0f - (float)t / 65536.0f);
+    return d;
+}
+enum { STREAM_EMBED = 1, STREAM_HEAD = 2 };
+inline uint32_t stream_attn(int l) { return 16 + 4 * l; }
+inline uint32_t stream_attn_out(int l) { return 16 + 4 * l + 1; }
+inline uint32_t stream_ffn_out(int l) { return 16 + 4 * l + 2; }
+
+// ------------------------------------------------------------------------------------------------ GEMM helper
+struct G {
+    GemmNTArgs a;
+    G(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K) {
+        memset(&a, 0, sizeof(a));
+        a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    }
+    G& bias(const float* b) { a.bias = b; a.flags |= GEMM_BIAS; return *this; }
+    G& gelu() { a.flags |= GEMM_GELU; return *this; }
+    G& aux(void* p, int ld) { a.aux = p; a.ldaux = ld; a.flags |= GEMM_AUX_PRE; return *this; }
+    G& residual(const void* p, int ld) { a.residual = p; a.ldres = ld; a.flags |= GEMM_RESIDUAL; return *this; }
+    G& mul_gelu_grad(const void* p, int ld) { a.mul_in = p; a.ldmul = ld; a.flags |= GEMM_MUL_GELU_GRAD; return *this; }
+    G& dropout(const DropCfg& d) { a.drop = d; if (d.thresh16) a.flags |= GEMM_DROPOUT; return *this; }
+};
+int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
+    if (e.timing) {
+        if (e.ev_used == e.evs.size()) {
+            mmhip_engine::Ev ev;
+            CHECK_HIP(hipEventCreate(&ev.a));
+            CHECK_HIP(hipEventCreate(&ev.b));
+            e.evs.push_back(ev);
+        }
+        auto& ev = e.evs[e.ev_used++];
+        ev.flops = 2.0 * g.a.M * (double)g.a.N * g.a.K;
+        CHECK_HIP(hipEventRecord(ev.a, s));
+        CHECK_HIP(launch_gemm_nt(g.a, e.dt(), s));
+        CHECK_HIP(hipEventRecord(ev.b, s));
+        return 0;
+    }
+    CHECK_HIP(launch_gemm_nt(g.a, e.dt(), s));
+    return 0;
+}
+SmallGemmArgs small(const void* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, int act = ACT_NONE, int acc = 0) {
+    SmallGemmArgs a;
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.act = act; a.accumulate = acc;
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+int refresh_layer(mmhip_engine& e, const float* base, const LayerOff& o, const LayerW16& w, bool transposed, hipStream_t s) {
+    const int H = e.cfg.hidden, I = e.cfg.inter, dt = e.dt();
+    CHECK_HIP(launch_cast(base + o.qkv_w, e.ws + w.qkv, (size_t)3 * H * H, dt, s));
+    CHECK_HIP(launch_cast(base + o.ao_w, e.ws + w.ao, (size_t)H * H, dt, s));
+    CHECK_HIP(launch_cast(base + o.fc1_w, e.ws + w.fc1, (size_t)I * H, dt, s));
+    CHECK_HIP(launch_cast(base + o.fc2_w, e.ws + w.fc2, (size_t)H * I, dt, s));
+    if (transposed) {
+        CHECK_HIP(launch_cast_transpose(base + o.qkv_w, e.ws + w.qkvT, 3 * H, H, dt, s));
+        CHECK_HIP(launch_cast_transpose(base + o.ao_w, e.ws + w.aoT, H, H, dt, s));
+        CHECK_HIP(launch_cast_transpose(base + o.fc1_w, e.ws + w.fc1T, I, H, dt, s));
+        CHECK_HIP(launch_cast_transpose(base + o.fc2_w, e.ws + w.fc2T, H, I, dt, s));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ forward pieces
+int vit_forward(mmhip_engine& e, const float* pixels, hipStream_t s) {
+    const mmhip_config& c = e.cfg;
+    const int H = c.hidden, I = c.inter, B = e.B, np = c.image / c.patch, P = np * np + 1, Kp = 3 * c.patch * c.patch, dt = e.dt();
+    const int Mv = B * P;
+    const float* F = e.frozen;
+    CHECK_HIP(launch_patchify(pixels, e.ws + e.v_patches, B, c.image, c.patch, dt, s));
+    {
+        G g(e.ws + e.v_patches, Kp, e.ws + e.patch_w16, Kp, e.ws + e.v_pe, H, B * (P - 1), H, Kp);
+        g.bias(F + e.v_patch_b);
+        if (int r = run_gemm(e, g, s)) return r;
+    }
+    CHECK_HIP(launch_vit_assemble(e.ws + e.v_pe, F + e.v_cls, F + e.v_pos, e.ws + e.v_x, B, P, H, dt, s));
+    char* x = e.ws + e.v_x;
+    for (int l = 0; l < c.layers_img; ++l) {
+        const LayerOff& o = e.vit[l];
+        const LayerW16& w = e.vit_w16[l];
+        LNArgs ln{x, e.ws + e.v_ln, F + o.ln1_w, F + o.ln1_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+        CHECK_HIP(launch_layernorm_fwd(ln, dt, s));
+        { G g(e.ws + e.v_ln, H, e.ws + w.qkv, H, e.ws + e.v_qkv, 3 * H, Mv, 3 * H, H); g.bias(F + o.qkv_b); if (int r = run_gemm(e, g, s)) return r; }
+        AttnArgs at;
+        memset(&at, 0, sizeof(at));
+        at.qkv = e.ws + e.v_qkv; at.ctx = e.ws + e.v_ctx; at.posts = B; at.S = P; at.heads = c.heads; at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
+        at.scale = 1.0f / sqrtf((float)(H / c.heads));
+        CHECK_HIP(launch_attn_fwd(at, dt, s));
+        { G g(e.ws + e.v_ctx, H, e.ws + w.ao, H, x, H, Mv, H, H); g.bias(F + o.ao_b).residual(x, H); if (int r = run_gemm(e, g, s)) return r; }
+        LNArgs ln2{x, e.ws + e.v_ln, F + o.ln2_w, F + o.ln2_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+        CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
+        { G g(e.ws + e.v_ln, H, e.ws + w.fc1, H, e.ws + e.v_h, I, Mv, I, H); g.bias(F + o.fc1_b).gelu(); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_h, I, e.ws + w.fc2, I, x, H, Mv, H, I); g.bias(F + o.fc2_b).residual(x, H); if (int r = run_gemm(e, g, s)) return r; }
+    }
+    LNArgs lnf{x, e.ws + e.v_out, F + e.v_ln_w, F + e.v_ln_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+    CHECK_HIP(launch_layernorm_fwd(lnf, dt, s));
+    // pooler on the CLS rows (row stride P*H): tanh(dense(x[:,0]))
+    SmallGemmArgs sp = small(e.ws + e.v_out, P * H, F + e.v_pool_w, H, F + e.v_pool_b, e.wsp<float>(e.h_vpool), H, B, H, H, ACT_TANH);
+    CHECK_HIP(launch_small_nt(sp, dt, s));
+    return 0;
+}
+
+int text_forward(mmhip_engine& e, hipStream_t s) {
+    const mmhip_config& c = e.cfg;
+    const int H = c.hidden, I = c.inter, T = e.T, Bt = e.Bt, Mt = Bt * T, dt = e.dt();
+    const float* W = e.train;
+    const bool tr = e.train_mode;
+    EmbedArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.ids = e.wsp<int64_t>(e.ids_all); ea.mask = e.wsp<int64_t>(e.mask_all);
+    ea.word = W + e.t_word; ea.pos = W + e.t_pos; ea.type = W + e.t_type; ea.gamma = W + e.t_eln_w; ea.beta = W + e.t_eln_b;
+    ea.x = e.ws + e.x0; ea.xhat = e.ws + e.xhat_emb; ea.rstd = e.wsp<float>(e.rstd_emb); ea.pos_ids = e.wsp<int>(e.pos_ids);
+    ea.maskbias = e.wsp<float>(e.maskbias);
+    ea.posts = Bt; ea.T = T; ea.H = H; ea.xlmr = c.txt_kind == MMHIP_TXT_XLMR; ea.pad_id = c.pad_id; ea.eps = c.ln_eps_txt;
+    ea.drop = make_drop(c.p_hidden, e.seed, STREAM_EMBED, tr);
+    CHECK_HIP(launch_embed_fwd(ea, dt, s));
+    const char* x = e.ws + e.x0;
+    for (int l = 0; l < c.layers_txt; ++l) {
+        const LayerOff& o = e.txt[l];
+        const LayerW16& w = e.txt_w16[l];
+        const TextAct& a = e.tact[l];
+        { G g(x, H, e.ws + w.qkv, H, e.ws + a.qkv, 3 * H, Mt, 3 * H, H); g.bias(W + o.qkv_b); if (int r = run_gemm(e, g, s)) return r; }
+        AttnArgs at;
+        memset(&at, 0, sizeof(at));
+        at.qkv = e.ws + a.qkv; at.maskbias = e.wsp<float>(e.maskbias); at.ctx = e.ws + a.ctx; at.lse = e.wsp<float>(a.lse);
+        at.posts = Bt; at.S = T; at.heads = c.heads; at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
+        at.scale = 1.0f / sqrtf((float)(H / c.heads));
+        at.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
+        CHECK_HIP(launch_attn_fwd(at, dt, s));
+        { G g(e.ws + a.ctx, H, e.ws + w.ao, H, e.ws + a.pre1, H, Mt, H, H);
+          g.bias(W + o.ao_b).dropout(make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr)).residual(x, H);
+          if (int r = run_gemm(e, g, s)) return r; }
+        LNArgs ln1{e.ws + a.pre1, e.ws + a.a1, W + o.ln1_w, W + o.ln1_b, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), Mt, H, H, H, c.ln_eps_txt};
+        CHECK_HIP(launch_layernorm_fwd(ln1, dt, s));
+        { G g(e.ws + a.a1, H, e.ws + w.fc1, H, e.ws + a.h, I, Mt, I, H); g.bias(W + o.fc1_b).aux(e.ws + a.u, I).gelu(); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + a.h, I, e.ws + w.fc2, I, e.ws + a.pre2, H, Mt, H, I);
+          g.bias(W + o.fc2_b).dropout(make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr)).residual(e.ws + a.a1, H);
+          if (int r = run_gemm(e, g, s)) return r; }
+        LNArgs ln2{e.ws + a.pre2, e.ws + a.out, W + o.ln2_w, W + o.ln2_b, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), Mt, H, H, H, c.ln_eps_txt};
+        CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
+        x = e.ws + a.out;
+    }
+    return 0;
+}
+
+const char* text_last(const mmhip_engine& e) { return e.cfg.layers_txt ? e.ws + e.tact[e.cfg.layers_txt - 1].out : e.ws + e.x0; }
+
+int heads_forward(mmhip_engine& e, float* out_cls, float* logits, float* out_tim, float* feats_out, hipStream_t s) {
+    const mmhip_config& c = e.cfg;
+    const int H = c.hidden, E = c.proj_dim, C = c.num_labels, T = e.T, B = e.B, Bt = e.Bt, dt = e.dt();
+    const int P = (c.image / c.patch) * (c.image / c.patch) + 1;
+    const float* W = e.train;
+    const char* xt = text_last(e);
+    // text pooler (first B posts) and ITC similarity -- HF dual encoder :261-274
+    CHECK_HIP(launch_small_nt(small(xt, T * H, W + e.t_pool_w, H, W + e.t_pool_b, e.wsp<float>(e.h_tpool), H, B, H, H, ACT_TANH), dt, s));
+    CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_tpool), H, W + e.tproj_w, H, nullptr, e.wsp<float>(e.h_txt_e), E, B, E, H), DT_F32, s));
+    CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_vpool), H, W + e.vproj_w, H, nullptr, e.wsp<float>(e.h_img_e), E, B, E, H), DT_F32, s));
+    ItcArgs it{e.wsp<float>(e.h_txt_e), e.wsp<float>(e.h_img_e), W + e.logit_scale, e.wsp<float>(e.h_txt_n), e.wsp<float>(e.h_img_n),
+               e.wsp<float>(e.h_txt_inv), e.wsp<float>(e.h_img_inv), e.wsp<float>(e.h_logits), B, E};
+    CHECK_HIP(launch_itc_fwd(it, s));
+    // z = [x_t[:,0] | fused image feature]
+    float* z = e.wsp<float>(e.h_z);
+    CHECK_HIP(launch_gather_rows_f32(xt, (size_t)T * H, z, 2 * H, Bt, H, dt, s));
+    if (c.fusion == MMHIP_FUSION_ATTENTION) {
+        CHECK_HIP(launch_small_nt(small(xt, T * H, W + e.fq_w, H, W + e.fq_b, e.wsp<float>(e.h_q), H, Bt, H, H), dt, s));
+        CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_q), H, W + e.fk_w, H, nullptr, e.wsp<float>(e.h_qk), H, Bt, H, H), s));
+        FusionAttnArgs fa{e.wsp<float>(e.h_qk), e.ws + e.v_out, e.wsp<float>(e.h_prob), e.wsp<float>(e.h_xbar), Bt, B, P, H, 1.0f / sqrtf((float)H)};
+        CHECK_HIP(launch_fusion_attn_fwd(fa, dt, s));
+        CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_xbar), H, W + e.fv_w, H, W + e.fv_b, z + H, 2 * H, Bt, H, H), DT_F32, s));
+    } else {
+        // concat: image CLS row of post bt % B -- two strided copies (original rows, ITM rows)
+        CHECK_HIP(launch_gather_rows_f32(e.ws + e.v_out, (size_t)P * H, z + H, 2 * H, B, H, dt, s));
+        if (Bt > B) CHECK_HIP(launch_gather_rows_f32(e.ws + e.v_out, (size_t)P * H, z + (size_t)B * 2 * H + H, 2 * H, B, H, dt, s));
+    }
+    float* feats = e.wsp<float>(e.h_feats);
+    CHECK_HIP(launch_small_nt(small(z, 2 * H, W + e.fus_w, 2 * H, W + e.fus_b, feats, H, Bt, H, 2 * H, ACT_RELU), DT_F32, s));
+    CHECK_HIP(launch_elementwise(EW_DROPOUT, feats, nullptr, e.wsp<float>(e.h_featd), (size_t)B * H, 0.f,
+                                 make_drop(c.p_head, e.seed, STREAM_HEAD, e.train_mode), s));
+    CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_featd), H, W + e.cls_w, H, W + e.cls_b, e.wsp<float>(e.h_out_cls), C, B, C, H), DT_F32, s));
+    if (e.itm) CHECK_HIP(launch_small_nt(small(feats + (size_t)B * H, H, W + e.tim_w, H, W + e.tim_b, e.wsp<float>(e.h_out_tim), 2, B, 2, H), DT_F32, s));
+    if (out_cls) CHECK_HIP(hipMemcpyAsync(out_cls, e.ws + e.h_out_cls, (size_t)B * C * 4, hipMemcpyDeviceToDevice, s));
+    if (logits) CHECK_HIP(hipMemcpyAsync(logits, e.ws + e.h_logits, (size_t)B * B * 4, hipMemcpyDeviceToDevice, s));
+    if (out_tim && e.itm) CHECK_HIP(hipMemcpyAsync(out_tim, e.ws + e.h_out_tim, (size_t)B * 2 * 4, hipMemcpyDeviceToDevice, s));
+    if (feats_out) CHECK_HIP(hipMemcpyAsync(feats_out, feats, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ backward pieces
+int heads_backward(mmhip_engine& e, hipStream_t s) {
+    const mmhip_config& c = e.cfg;
+    const int H = c.hidden, E = c.proj_dim, C = c.num_labels, T = e.T, B = e.B, Bt = e.Bt, dt = e.dt();
+    const int P = (c.image / c.patch) * (c.image / c.patch) + 1;
+    const float* W = e.train;
+    float* Gd = e.grad;
+    const float* d_out_cls = e.bd_out_cls ? e.bd_out_cls : e.wsp<float>(e.h_d_out_cls);
+    const float* d_logits = e.bd_logits;
+    const float* d_out_tim = e.bd_out_tim;
+    float* dfeats = e.wsp<float>(e.h_dfeats);
+    float* feats = e.wsp<float>(e.h_feats);
+    float* z = e.wsp<float>(e.h_z);
+    float* dxcls = e.wsp<float>(e.h_dxcls);
+    const DropCfg nodrop = make_drop(0.f, 0, 0, false);
+    // classifier: out_cls = linear_cls(dropout(feats[:B]))
+    CHECK_HIP(launch_small_nn(small(d_out_cls, C, W + e.cls_w, H, nullptr, dfeats, H, B, H, C), s));
+    CHECK_HIP(launch_elementwise(EW_DROPOUT, dfeats, nullptr, dfeats, (size_t)B * H, 0.f, make_drop(c.p_head, e.seed, STREAM_HEAD, e.train_mode), s));
+    if (e.bd_feats) CHECK_HIP(launch_elementwise(EW_ADD, dfeats, e.bd_feats, dfeats, (size_t)B * H, 1.f, nodrop, s));
+    CHECK_HIP(launch_small_tn(small(d_out_cls, C, e.wsp<float>(e.h_featd), H, nullptr, Gd + e.cls_w, H, B, H, 0, 0, 1), DT_F32, C, s));
+    CHECK_HIP(launch_bias_grad_f32(d_out_cls, B, C, C, Gd + e.cls_b, 1, s));
+    if (e.itm) {
+        if (d_out_tim) {
+            CHECK_HIP(launch_small_nn(small(d_out_tim, 2, W + e.tim_w, H, nullptr, dfeats + (size_t)B * H, H, B, H, 2), s));
+            CHECK_HIP(launch_small_tn(small(d_out_tim, 2, feats + (size_t)B * H, H, nullptr, Gd + e.tim_w, H, B, H, 0, 0, 1), DT_F32, 2, s));
+            CHECK_HIP(launch_bias_grad_f32(d_out_tim, B, 2, 2, Gd + e.tim_b, 1, s));
+        } else {
+            CHECK_HIP(hipMemsetAsync(dfeats + (size_t)B * H, 0, (size_t)B * H * 4, s));
+        }
+    }
+    // feats = relu(linear_fusion(z))
+    float* dpre = e.wsp<float>(e.h_dpre);
+    CHECK_HIP(launch_elementwise(EW_RELU_BWD, dfeats, feats, dpre, (size_t)Bt * H, 0.f, nodrop, s));
+    CHECK_HIP(launch_small_tn(small(dpre, H, z, 2 * H, nullptr, Gd + e.fus_w, 2 * H, Bt, 2 * H, 0, 0, 1), DT_F32, H, s));
+    CHECK_HIP(launch_bias_grad_f32(dpre, Bt, H, H, Gd + e.fus_b, 1, s));
+    float* dz = e.wsp<float>(e.h_dz);
+    CHECK_HIP(launch_small_nn(small(dpre, H, W + e.fus_w, 2 * H, nullptr, dz, 2 * H, Bt, 2 * H, H), s));
+    // d x_t[:,0] starts as dz[:, :H]
+    CHECK_HIP(hipMemcpy2DAsync(dxcls, (size_t)H * 4, dz, (size_t)2 * H * 4, (size_t)H * 4, Bt, hipMemcpyDeviceToDevice, s));
+    if (c.fusion == MMHIP_FUSION_ATTENTION) {
+        const float* dctx = dz + H;      // ld 2H
+        float* q = e.wsp<float>(e.h_q);
+        CHECK_HIP(launch_small_tn(small(dctx, 2 * H, e.wsp<float>(e.h_xbar), H, nullptr, Gd + e.fv_w, H, Bt, H, 0, 0, 1), DT_F32, H, s));
+        CHECK_HIP(launch_bias_grad_f32(dctx, Bt, H, 2 * H, Gd + e.fv_b, 1, s));
+        CHECK_HIP(launch_small_nn(small(dctx, 2 * H, W + e.fv_w, H, nullptr, e.wsp<float>(e.h_dxbar), H, Bt, H, H), s));
+        FusionAttnBwdArgs fb{e.wsp<float>(e.h_dxbar), e.wsp<float>(e.h_prob), e.ws + e.v_out, e.wsp<float>(e.h_dqk), Bt, B, P, H, 1.0f / sqrtf((float)H)};
+        CHECK_HIP(launch_fusion_attn_bwd(fb, dt, s));
+        // qk = q . W_K  ->  dW_K[o][i] = sum q[:,o] dqk[:,i];  dq = dqk . W_K^T ;  fc_K.bias gets an exactly-zero gradient
+        CHECK_HIP(launch_small_tn(small(q, H, e.wsp<float>(e.h_dqk), H, nullptr, Gd + e.fk_w, H, Bt, H, 0, 0, 1), DT_F32, H, s));
+        CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_dqk), H, W + e.fk_w, H, nullptr, e.wsp<float>(e.h_dq), H, Bt, H, H), DT_F32, s));
+        CHECK_HIP(launch_small_tn(small(e.wsp<float>(e.h_dq), H, z, 2 * H, nullptr, Gd + e.fq_w, H, Bt, H, 0, 0, 1), DT_F32, H, s));
+        CHECK_HIP(launch_bias_grad_f32(e.wsp<float>(e.h_dq), Bt, H, H, Gd + e.fq_b, 1, s));
+        CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_dq), H, W + e.fq_w, H, nullptr, dxcls, H, Bt, H, H, ACT_NONE, 1), s));
+    }
+    if (d_logits) {
+        ItcBwdArgs ib{d_logits, e.wsp<float>(e.h_logits), e.wsp<float>(e.h_txt_n), e.wsp<float>(e.h_img_n), e.wsp<float>(e.h_txt_inv),
+                      e.wsp<float>(e.h_img_inv), W + e.logit_scale, e.wsp<float>(e.h_dtxt_e), e.wsp<float>(e.h_dimg_e), Gd + e.logit_scale, B, E};
+        CHECK_HIP(launch_itc_bwd(ib, s));
+        CHECK_HIP(launch_small_tn(small(e.wsp<float>(e.h_dtxt_e), E, e.wsp<float>(e.h_tpool), H, nullptr, Gd + e.tproj_w, H, B, H, 0, 0, 1), DT_F32, E, s));
+        CHECK_HIP(launch_small_tn(small(e.wsp<float>(e.h_dimg_e), E, e.wsp<float>(e.h_vpool), H, nullptr, Gd + e.vproj_w, H, B, H, 0, 0, 1), DT_F32, E, s));
+        CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_dtxt_e), E, W + e.tproj_w, H, nullptr, e.wsp<float>(e.h_dtpool), H, B, H, E), s));
+        CHECK_HIP(launch_elementwise(EW_TANH_BWD, e.wsp<float>(e.h_dtpool), e.wsp<float>(e.h_tpool), e.wsp<float>(e.h_dprepool), (size_t)B * H, 0.f, nodrop, s));
+        CHECK_HIP(launch_small_tn(small(e.wsp<float>(e.h_dprepool), H, z, 2 * H, nullptr, Gd + e.t_pool_w, H, B, H, 0, 0, 1), DT_F32, H, s));
+        CHECK_HIP(launch_bias_grad_f32(e.wsp<float>(e.h_dprepool), B, H, H, Gd + e.t_pool_b, 1, s));
+        CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_dprepool), H, W + e.t_pool_w, H, nullptr, dxcls, H, B, H, H, ACT_NONE, 1), s));
+    }
+    // gradient of the last hidden state: CLS rows only
+    CHECK_HIP(launch_scatter_cls_rows(dxcls, e.ws + e.g_dx, Bt, T, H, dt, s));
+    return 0;
+}
+
+// one text layer; on entry g_dx holds the gradient of the layer's output, on exit of its input
+int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
+    const mmhip_config& c = e.cfg;
+    const int H = c.hidden, I = c.inter, T = e.T, Bt = e.Bt, Mt = Bt * T, dt = e.dt();
+    const float* W = e.train;
+    float* Gd = e.grad;
+    const LayerOff& o = e.txt[l];
+    const LayerW16& w = e.txt_w16[l];
+    const TextAct& a = e.tact[l];
+    const char* x_in = l ? e.ws + e.tact[l - 1].out : e.ws + e.x0;
+    const bool tr = e.train_mode;
+    char *dx = e.ws + e.g_dx, *dpre = e.ws + e.g_dpre, *ddrop = e.ws + e.g_ddrop, *du = e.ws + e.g_du, *dx2 = e.ws + e.g_dx2;
+    // ---- x' = LN2(pre2), pre2 = drop(fc2(h)) + a1
+    LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mt, H};
+    CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
+    const DropCfg d_ffn = make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr);
+    const char* df = dpre;
+    if (d_ffn.thresh16) { CHECK_HIP(launch_dropout16(dpre, ddrop, (size_t)Mt * H, d_ffn, dt, s)); df = ddrop; }
+    // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre
+    { G g(df, H, e.ws + w.fc2T, H, du, I, Mt, I, H); g.mul_gelu_grad(e.ws + a.u, I); if (int r = run_gemm(e, g, s)) return r; }
+    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mt, H, I); g.residual(dpre, H); if (int r = run_gemm(e, g, s)) return r; }
+    CHECK_HIP(launch_colsum(df, Mt, H, H, Gd + o.fc2_b, dt, s));
+    CHECK_HIP(launch_colsum(du, Mt, I, I, Gd + o.fc1_b, dt, s));
+    GemmTNProblem pr[4];
+    memset(pr, 0, sizeof(pr));
+    pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mt, H, I, H, I, I, 0};          // dW2[H,I] = df^T h
+    pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mt, I, H, I, H, H, 0};         // dW1[I,H] = du^T a1
+    CHECK_HIP(launch_gemm_tn(pr, 2, 0, dt, 0, s));
+    // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1; reuse dpre for d_pre1 afterwards)
+    LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mt, H};
+    CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
+    const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
+    const char* dout = dpre;
+    if (d_ao.thresh16) { CHECK_HIP(launch_dropout16(dpre, ddrop, (size_t)Mt * H, d_ao, dt, s)); dout = ddrop; }
+    char* dctx = e.ws + e.g_dctx;
+    { G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H); if (int r = run_gemm(e, g, s)) return r; }
+    CHECK_HIP(launch_colsum(dout, Mt, H, H, Gd + o.ao_b, dt, s));
+    AttnBwdArgs ab;
+    memset(&ab, 0, sizeof(ab));
+    ab.qkv = e.ws + a.qkv; ab.maskbias = e.wsp<float>(e.maskbias); ab.ctx = e.ws + a.ctx; ab.dctx = dctx; ab.lse = e.wsp<float>(a.lse);
+    ab.dqkv = e.ws + e.g_dqkv; ab.posts = Bt; ab.S = T; ab.heads = c.heads; ab.ld_qkv = 3 * H; ab.ld_ctx = H; ab.hidden = H;
+    ab.scale = 1.0f / sqrtf((float)(H / c.heads));
+    ab.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
+    CHECK_HIP(launch_attn_bwd(ab, dt, s));
+    { G g(e.ws + e.g_dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.residual(dpre, H); if (int r = run_gemm(e, g, s)) return r; }
+    CHECK_HIP(launch_colsum(e.ws + e.g_dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, s));
+    pr[0] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mt, H, H, H, H, H, 0};              // dWo = dout^T ctx
+    pr[1] = GemmTNProblem{e.ws + e.g_dqkv, x_in, Gd + o.qkv_w, Mt, 3 * H, H, 3 * H, H, H, 0};  // dWqkv = dqkv^T x_in
+    CHECK_HIP(launch_gemm_tn(pr, 2, 0, dt, 0, s));
+    return 0;
+}
+
+int embed_backward(mmhip_engine& e, hipStream_t s) {
+    const mmhip_config& c = e.cfg;
+    const float* W = e.train;
+    float* Gd = e.grad;
+    EmbedBwdArgs b;
+    memset(&b, 0, sizeof(b));
+    b.dx = e.ws + e.g_dx; b.xhat = e.ws + e.xhat_emb; b.rstd = e.wsp<float>(e.rstd_emb); b.gamma = W + e.t_eln_w;
+    b.ids = e.wsp<int64_t>(e.ids_all); b.pos_ids = e.wsp<int>(e.pos_ids);
+    b.dword = Gd + e.t_word; b.dpos = Gd + e.t_pos; b.dtype = Gd + e.t_type; b.dgamma = Gd + e.t_eln_w; b.dbeta = Gd + e.t_eln_b;
+    b.posts = e.Bt; b.T = e.T; b.H = c.hidden; b.pad_id = c.pad_id;
+    b.pos_pad_id = c.txt_kind == MMHIP_TXT_XLMR ? c.pad_id : -1;     // nn.Embedding(padding_idx=...) rows get no gradient
+    b.drop = make_drop(c.p_hidden, e.seed, STREAM_EMBED, e.train_mode);
+    CHECK_HIP(launch_embed_bwd(b, e.dt(), s));
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* mmhip_version(void) { return "mmhip 0.1 (gfx950)"; }
+
+int mmhip_create(const mmhip_config* cfg, mmhip_handle* out) {
+    if (!cfg || !out) return MMHIP_E_INVALID;
+    const mmhip_config& c = *cfg;
+    if (c.hidden <= 0 || c.hidden % 64 || c.hidden > 1024 || c.heads * 64 != c.hidden || c.inter % 128 || c.hidden % 128) return MMHIP_E_INVALID;
+    if (c.image % c.patch || c.patch % 8 || (3 * c.patch * c.patch) % 64) return MMHIP_E_INVALID;
+    if ((c.image / c.patch) * (c.image / c.patch) + 1 > 224) return MMHIP_E_INVALID;
+    if (c.max_text_len > 128 || c.max_text_len < 1 || c.max_posts < 1 || c.max_posts > 1024) return MMHIP_E_INVALID;
+    if (c.dtype != MMHIP_BF16 && c.dtype != MMHIP_F16) return MMHIP_E_INVALID;
+    if (c.num_labels < 1 || c.num_labels > 64 || c.proj_dim < 1 || c.proj_dim > 1024) return MMHIP_E_INVALID;
+    if (c.txt_kind == MMHIP_TXT_XLMR && c.max_pos < c.max_text_len + c.pad_id + 1) return MMHIP_E_INVALID;
+    if (c.txt_kind == MMHIP_TXT_BERT && c.max_pos < c.max_text_len) return MMHIP_E_INVALID;
+    mmhip_engine* e = new (std::nothrow) mmhip_engine();
+    if (!e) return MMHIP_E_INVALID;
+    e->cfg = c;
+    build_layout(*e);
+    build_workspace(*e);
+    *out = e;
+    return 0;
+}
+void mmhip_destroy(mmhip_handle h) {
+    if (!h) return;
+    for (auto& ev : h->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    delete h;
+}
+int mmhip_param_count(mmhip_handle h) { return h ? (int)h->params.size() : MMHIP_E_INVALID; }
+int mmhip_param_info_at(mmhip_handle h, int i, mmhip_param_info* out) {
+    if (!h || !out || i < 0 || i >= (int)h->params.size()) return MMHIP_E_INVALID;
+    *out = h->params[i];
+    return 0;
+}
+uint64_t mmhip_buffer_numel(mmhip_handle h, int buffer) { return !h ? 0 : (buffer == 0 ? h->n_frozen : h->n_train); }
+uint64_t mmhip_workspace_bytes(mmhip_handle h) { return h ? h->ws_need : 0; }
+int mmhip_bind(mmhip_handle h, float* frozen, float* train, float* train_grad, void* workspace, uint64_t workspace_bytes) {
+    if (!h || !frozen || !train || !workspace) return MMHIP_E_INVALID;
+    if (workspace_bytes < h->ws_need) return MMHIP_E_CAPACITY;
+    if (((uintptr_t)frozen | (uintptr_t)train | (uintptr_t)train_grad | (uintptr_t)workspace) & 255) return MMHIP_E_INVALID;
+    h->frozen = frozen; h->train = train; h->grad = train_grad; h->ws = (char*)workspace; h->ws_bytes = workspace_bytes;
+    h->fwd_done = false;
+    return 0;
+}
+int mmhip_refresh_weights(mmhip_handle h, int which, void* stream) {
+    if (!h || !h->ws) return MMHIP_E_STATE;
+    hipStream_t s = (hipStream_t)stream;
+    mmhip_engine& e = *h;
+    if (which & 1) {
+        for (int l = 0; l < e.cfg.layers_img; ++l)
+            if (int r = refresh_layer(e, e.frozen, e.vit[l], e.vit_w16[l], false, s)) return r;
+        CHECK_HIP(launch_cast(e.frozen + e.v_patch_w, e.ws + e.patch_w16, (size_t)e.cfg.hidden * 3 * e.cfg.patch * e.cfg.patch, e.dt(), s));
+    }
+    if (which & 2)
+        for (int l = 0; l < e.cfg.layers_txt; ++l)
+            if (int r = refresh_layer(e, e.train, e.txt[l], e.txt_w16[l], true, s)) return r;
+    return 0;
+}
+
+int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
+                  const int64_t* tim_mask, int B, int T, int train, uint64_t seed, float* out_cls, float* logits_per_text,
+                  float* out_tim, float* mm_features, void* stream) {
+    if (!h || !h->ws) return MMHIP_E_STATE;
+    if (!ids || !mask || !pixels || B < 1 || T < 1) return MMHIP_E_INVALID;
+    if ((tim_ids == nullptr) != (tim_mask == nullptr)) return MMHIP_E_INVALID;
+    mmhip_engine& e = *h;
+    if (B > e.cfg.max_posts || T > e.cfg.max_text_len) return MMHIP_E_CAPACITY;
+    hipStream_t s = (hipStream_t)stream;
+    e.B = B; e.T = T; e.itm = tim_ids != nullptr; e.Bt = e.itm ? 2 * B : B; e.train_mode = train != 0; e.seed = seed;
+    e.fwd_done = false; e.bwd_begun = false;
+    const size_t nb = (size_t)B * T * 8;
+    CHECK_HIP(hipMemcpyAsync(e.ws + e.ids_all, ids, nb, hipMemcpyDeviceToDevice, s));
+    CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all, mask, nb, hipMemcpyDeviceToDevice, s));
+    if (e.itm) {
+        CHECK_HIP(hipMemcpyAsync(e.ws + e.ids_all + nb, tim_ids, nb, hipMemcpyDeviceToDevice, s));
+        CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all + nb, tim_mask, nb, hipMemcpyDeviceToDevice, s));
+    }
+    if (int r = vit_forward(e, pixels, s)) return r;
+    if (int r = text_forward(e, s)) return r;
+    if (int r = heads_forward(e, out_cls, logits_per_text, out_tim, mm_features, s)) return r;
+    e.fwd_done = true;
+    return 0;
+}
+
+int mmhip_loss(mmhip_handle h, const int64_t* onehot, const float* class_w, const int64_t* lbl_tim, float w_cls, float w_itc,
+               float w_itm, float* loss, int* n_correct, void* stream) {
+    if (!h || !h->fwd_done) return MMHIP_E_STATE;
+    if (!onehot) return MMHIP_E_INVALID;
+    mmhip_engine& e = *h;
+    if (w_itm != 0.f && (!e.itm || !lbl_tim)) return MMHIP_E_INVALID;
+    LossArgs a;
+    memset(&a, 0, sizeof(a));
+    a.out_cls = e.wsp<float>(e.h_out_cls); a.onehot = onehot; a.class_w = class_w;
+    a.logits_per_text = w_itc != 0.f ? e.wsp<float>(e.h_logits) : nullptr;
+    a.out_tim = w_itm != 0.f ? e.wsp<float>(e.h_out_tim) : nullptr; a.lbl_tim = lbl_tim;
+    a.w_cls = w_cls; a.w_itc = w_itc; a.w_itm = w_itm;
+    a.loss = e.wsp<float>(e.h_loss);
+    a.d_out_cls = e.wsp<float>(e.h_d_out_cls);
+    a.d_logits = w_itc != 0.f ? e.wsp<float>(e.h_d_logits) : nullptr;
+    a.d_out_tim = w_itm != 0.f ? e.wsp<float>(e.h_d_out_tim) : nullptr;
+    a.n_correct = n_correct;
+    a.B = e.B; a.C = e.cfg.num_labels;
+    hipStream_t s = (hipStream_t)stream;
+    CHECK_HIP(launch_loss(a, s));
+    if (loss) CHECK_HIP(hipMemcpyAsync(loss, a.loss, 16, hipMemcpyDeviceToDevice, s));
+    e.bd_out_cls = a.d_out_cls; e.bd_logits = a.d_logits; e.bd_out_tim = a.d_out_tim; e.bd_feats = nullptr;
+    return 0;
+}
+
+int mmhip_num_backward_stages(mmhip_handle h) { return h ? h->cfg.layers_txt + 2 : MMHIP_E_INVALID; }
+
+int mmhip_stage_grad_range(mmhip_handle h, int stage, uint64_t* begin, uint64_t* end) {
+    if (!h || !begin || !end || stage < 0 || stage > h->cfg.layers_txt + 1) return MMHIP_E_INVALID;
+    const mmhip_engine& e = *h;
+    if (stage == 0) { *begin = e.heads_begin; *end = e.heads_end; }
+    else if (stage <= e.cfg.layers_txt) { const LayerOff& o = e.txt[e.cfg.layers_txt - stage]; *begin = o.begin; *end = o.end; }
+    else { *begin = e.emb_begin; *end = e.emb_end; }
+    return 0;
+}
+
+int mmhip_backward_begin(mmhip_handle h, const float* d_out_cls, const float* d_logits, const float* d_out_tim, const float* d_feats, void* stream) {
+    (void)stream;
+    if (!h || !h->fwd_done || !h->grad) return MMHIP_E_STATE;
+    mmhip_engine& e = *h;
+    if (d_out_cls || d_logits || d_out_tim || d_feats) {
+        if (!d_out_cls) return MMHIP_E_INVALID;
+        e.bd_out_cls = d_out_cls; e.bd_logits = d_logits; e.bd_out_tim = d_out_tim; e.bd_feats = d_feats;
+    } else if (!e.bd_out_cls) {
+        return MMHIP_E_STATE;      // no mmhip_loss before, and no explicit gradients
+    }
+    e.bwd_begun = true;
+    return 0;
+}
+int mmhip_backward_stage(mmhip_handle h, int stage, void* stream) {
+    if (!h || !h->bwd_begun) return MMHIP_E_STATE;
+    mmhip_engine& e = *h;
+    hipStream_t s = (hipStream_t)stream;
+    const int L = e.cfg.layers_txt;
+    if (stage == 0) return heads_backward(e, s);
+    if (stage >= 1 && stage <= L) return text_layer_backward(e, L - stage, s);
+    if (stage == L + 1) return embed_backward(e, s);
+    return MMHIP_E_INVALID;
+}
+int mmhip_backward(mmhip_handle h, const float* d_out_cls, const float* d_logits, const float* d_out_tim, const float* d_feats, void* stream) {
+    if (int r = mmhip_backward_begin(h, d_out_cls, d_logits, d_out_tim, d_feats, stream)) return r;
+    const int n = mmhip_num_backward_stages(h);
+    for (int st = 0; st < n; ++st)
+        if (int r = mmhip_backward_stage(h, st, stream)) return r;
+    return 0;
+}
+
+int mmhip_adamw(float* p, float* g, float* m, float* v, uint64_t n, float lr, float beta1, float beta2, float eps,
+                float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+    if (!p || !g || !m || !v || step < 1) return MMHIP_E_INVALID;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MMHIP_E_INVALID;
+    AdamWArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)beta1, step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+    a.zero_grad = zero_grad; a.grad_scale = grad_scale;
+    CHECK_HIP(launch_adamw(a, (hipStream_t)stream));
+    return 0;
+}
+
+int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_t* launches, double* flops) {
+    if (!h) return MMHIP_E_INVALID;
+    mmhip_engine& e = *h;
+    if (ms || launches || flops) {
+        double tms = 0, tf = 0;
+        for (size_t i = 0; i < e.ev_used; ++i) {
+            CHECK_HIP(hipEventSynchronize(e.evs[i].b));
+            float t = 0;
+            CHECK_HIP(hipEventElapsedTime(&t, e.evs[i].a, e.evs[i].b));
+            tms += t; tf += e.evs[i].flops;
+        }
+        if (ms) *ms = tms;
+        if (launches) *launches = e.ev_used;
+        if (flops) *flops = tf;
+    }
+    if (reset) e.ev_used = 0;
+    e.timing = enable != 0;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+// Shared device helpers for the mmhip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmhip {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define MM_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define MM_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---------------------------------------------------------------- 16-bit activation types
+template <typename T> struct Vec;
+template <> struct Vec<bf16_t> { typedef bf16x8 v8; typedef bf16x4 v4; };
+template <> struct Vec<f16_t> { typedef f16x8 v8; typedef f16x4 v4; };
+
+template <typename T> __device__ __forceinline__ float to_f(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x) { return (T)x; }
+
+// D(16x16) += A(16x32) * B(32x16); lane l: A[l&15][8(l>>4)+j], B[8(l>>4)+j][l&15]; D: col=l&15,row=4(l>>4)+reg
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// D(32x32) += A(32x16) * B(16x32); lane l: A[l&31][8(l>>5)+j], B[8(l>>5)+j][l&31]; D: col=l&31,row=(reg&3)+8(reg>>2)+4(l>>5)
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// 16-byte LDS read of 8 elements
+template <typename T> __device__ __forceinline__ typename Vec<T>::v8 lds_read8(const char* lds, int byte_off) {
+    return *reinterpret_cast<const typename Vec<T>::v8*>(lds + byte_off);
+}
+// transposed LDS read (ds_read_b64_tr_b16): per 16-lane group a 4-row x 16-column block; lane 4q+p gives the
+// address of row q, columns 4p..4p+3; lane i receives column i, rows 0..3 in elements 0..3.
+__device__ __forceinline__ s16x4 lds_read_tr4(const char* lds, int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + byte_off));
+}
+template <typename T> __device__ __forceinline__ typename Vec<T>::v8 join_tr(s16x4 lo, s16x4 hi) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(typename Vec<T>::v8, r);
+}
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// Bit-identical to oracle/mm_oracle.py:rng_u32 (the oracle replays the very same masks).
+__device__ __host__ __forceinline__ uint32_t mm_rng_u32(uint32_t idx, uint32_t stream, uint64_t seed) {
+    uint32_t x = idx ^ (uint32_t)seed;
+    x *= 0x9E3779B1u;
+    x ^= x >> 15;
+    x += stream * 0x85EBCA77u + (uint32_t)(seed >> 32);
+    x ^= x >> 13;
+    x *= 0xC2B2AE3Du;
+    x ^= x >> 16;
+    return x;
+}
+struct DropCfg {
+    uint64_t seed;
+    uint32_t stream;
+    uint32_t thresh16;   // drop when the element's 16 random bits < thresh16 (0 => dropout off)
+    float keep_scale;    // 1 / (1 - thresh16/65536)
+};
+// element e uses 16 bits of the hash of (e >> 1): low half for even e, high half for odd e
+__device__ __forceinline__ bool mm_keep(uint32_t e, const DropCfg& d) {
+    uint32_t h = mm_rng_u32(e >> 1, d.stream, d.seed);
+    uint32_t r = (e & 1u) ? (h >> 16) : (h & 0xFFFFu);
+    return r >= d.thresh16;
+}
+// keep flags for two consecutive elements e (even) and e+1 with one hash
+__device__ __forceinline__ void mm_keep2(uint32_t e_even, const DropCfg& d, bool& k0, bool& k1) {
+    uint32_t h = mm_rng_u32(e_even >> 1, d.stream, d.seed);
+    k0 = (h & 0xFFFFu) >= d.thresh16;
+    k1 = (h >> 16) >= d.thresh16;
+}
+
+// ---------------------------------------------------------------- math
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, i.e. fp32 round-off level)
+__device__ __forceinline__ float mm_erf(float x) {
+    float ax = fabsf(x);
+    float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    float y = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    float r = 1.0f - y * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float mm_gelu(float x) { return 0.5f * x * (1.0f + mm_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float mm_gelu_grad(float x) {
+    float cdf = 0.5f * (1.0f + mm_erf(x * 0.70710678118654752f));
+    float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks b and b+8 share an XCD (observed round-robin dispatch),
+// so give each XCD a contiguous chunk of logical tile ids (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+}  // namespace mmhip

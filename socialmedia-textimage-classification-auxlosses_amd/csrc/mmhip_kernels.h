@@ -1,0 +1,169 @@
+// Internal launcher interface between the kernels (*.hip) and the engine / C ABI (engine.hip, capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mmhip_common.h"
+
+namespace mmhip {
+
+enum { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2 };
+enum { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };
+
+// ---------------------------------------------------------------- GEMM
+enum {
+    GEMM_BIAS = 1,            // + bias[n] (fp32)
+    GEMM_GELU = 2,            // exact-erf GELU
+    GEMM_RESIDUAL = 4,        // + residual[m][n] (16-bit), applied last
+    GEMM_DROPOUT = 8,         // hash dropout on element index m*N + n, before the residual
+    GEMM_OUT_F32 = 16,        // C is fp32
+    GEMM_AUX_PRE = 32,        // aux[m][n] = value after bias, before the activation (16-bit)
+    GEMM_MUL_GELU_GRAD = 64,  // value *= gelu'(mul_in[m][n])
+    GEMM_TANH = 128,
+};
+struct GemmNTArgs {
+    const void* A; const void* B; void* C; void* aux; const float* bias; const void* residual; const void* mul_in;
+    int M, N, K, lda, ldb, ldc, ldaux, ldres, ldmul;
+    int flags;
+    int force_slow;
+    DropCfg drop;
+};
+static constexpr int GEMM_TN_MAX_GROUP = 8;
+struct GemmTNProblem {
+    const void* A; const void* B; float* C;
+    int M, Nn, Nc, lda, ldb, ldc, tile_start;
+};
+struct GemmTNGroup {
+    GemmTNProblem p[GEMM_TN_MAX_GROUP];
+    int count, accumulate;
+};
+struct SmallGemmArgs {
+    const void* A; const float* W; const float* bias; float* out;
+    int M, N, K, lda, ldw, ldo, act, accumulate;
+};
+hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s);
+hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s);
+hipError_t launch_small_nt(const SmallGemmArgs& a, int a_dtype, hipStream_t s);   // out[M,N] = act(A[M,K] W[N,K]^T + b)
+hipError_t launch_small_nn(const SmallGemmArgs& a, hipStream_t s);                // out[M,N] = A[M,K] W[K,N]
+hipError_t launch_small_tn(const SmallGemmArgs& a, int b_dtype, int n_rows, hipStream_t s);  // out[n_rows,N] = A[M,n_rows]^T B[M,N]
+
+// ---------------------------------------------------------------- attention
+struct AttnArgs {
+    const void* qkv;      // [rows, ld_qkv] packed q | k | v, head h at columns h*64
+    const float* maskbias;  // [posts, S] additive key bias (0 or -inf) or null
+    void* ctx;            // [rows, ld_ctx]
+    float* lse;           // [posts, heads, S] (natural-log units of the scaled scores) or null
+    int posts, S, heads, ld_qkv, ld_ctx, hidden;
+    float scale;
+    DropCfg drop;
+};
+struct AttnBwdArgs {
+    const void* qkv; const float* maskbias; const void* ctx; const void* dctx; const float* lse;
+    void* dqkv;           // [rows, ld_qkv]
+    int posts, S, heads, ld_qkv, ld_ctx, hidden;
+    float scale;
+    DropCfg drop;
+};
+hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s);
+hipError_t launch_attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t s);
+
+// ---------------------------------------------------------------- row ops (LayerNorm, embeddings, elementwise)
+struct LNArgs {
+    const void* x; void* y; const float* gamma; const float* beta; float* mean; float* rstd;
+    int rows, width, ldx, ldy; float eps;
+};
+struct LNBwdArgs {
+    const void* dy; const void* x; const float* gamma; const float* mean; const float* rstd;
+    void* dx;             // 16-bit
+    const void* dres;     // optional 16-bit tensor added to dx (gradient arriving through the residual branch)
+    float* dgamma; float* dbeta;   // fp32, atomically accumulated
+    int rows, width;
+};
+hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s);
+hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s);
+
+struct EmbedArgs {
+    const int64_t* ids; const int64_t* mask;
+    const float* word; const float* pos; const float* type; const float* gamma; const float* beta;
+    void* x;              // [rows, H] 16-bit output (after LN and dropout)
+    void* xhat;           // [rows, H] 16-bit normalised value before gamma/beta (saved for backward) or null
+    float* rstd;          // [rows]
+    int* pos_ids;         // [rows] (written)
+    float* maskbias;      // [rows] additive key bias (written)
+    int posts, T, H, xlmr, pad_id; float eps;
+    DropCfg drop;
+};
+struct EmbedBwdArgs {
+    const void* dx; const void* xhat; const float* rstd; const float* gamma;
+    const int64_t* ids; const int* pos_ids;
+    float* dword; float* dpos; float* dtype; float* dgamma; float* dbeta;
+    int posts, T, H, pad_id, pos_pad_id;
+    DropCfg drop;
+};
+hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s);
+hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s);
+
+hipError_t launch_patchify(const float* pixels, void* out, int B, int img, int patch, int dtype, hipStream_t s);
+hipError_t launch_vit_assemble(const void* patches, const float* cls, const float* pos, void* x, int B, int P, int H, int dtype, hipStream_t s);
+hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s);   // out[c] += sum_r x[r][c]
+hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s);
+hipError_t launch_cast_transpose(const float* src, void* dst, int rows, int cols, int dtype, hipStream_t s);   // dst[c][r] = src[r][c]
+hipError_t launch_gather_rows_f32(const void* src, size_t src_stride, float* out, int ldo, int rows, int H, int dtype, hipStream_t s);
+hipError_t launch_dropout16(const void* src, void* dst, size_t n, const DropCfg& d, int dtype, hipStream_t s);
+hipError_t launch_scatter_cls_rows(const float* d, void* dx, int posts, int T, int H, int dtype, hipStream_t s);
+
+// ---------------------------------------------------------------- heads
+struct FusionAttnArgs {
+    const float* qk;      // [Bt, H]  W_K^T q   (fp32)
+    const void* xv;       // [B*P, H] 16-bit image tokens
+    float* prob;          // [Bt, P]  softmax weights (saved)
+    float* xbar;          // [Bt, H]  sum_j p_j x_v[j]
+    int Bt, B, P, H; float scale;
+};
+struct FusionAttnBwdArgs {
+    const float* dxbar; const float* prob; const void* xv; float* dqk; int Bt, B, P, H; float scale;
+};
+hipError_t launch_fusion_attn_fwd(const FusionAttnArgs& a, int dtype, hipStream_t s);
+hipError_t launch_fusion_attn_bwd(const FusionAttnBwdArgs& a, int dtype, hipStream_t s);
+
+struct ItcArgs {
+    const float* txt_e; const float* img_e;   // [B, E] raw projections
+    const float* logit_scale;                 // scalar parameter
+    float* txt_n; float* img_n; float* txt_inv; float* img_inv;   // normalised rows and 1/norm (saved)
+    float* logits;                            // [B, B] logits_per_text
+    int B, E;
+};
+struct ItcBwdArgs {
+    const float* dlogits; const float* logits; const float* txt_n; const float* img_n; const float* txt_inv; const float* img_inv;
+    const float* logit_scale;
+    float* dtxt_e; float* dimg_e; float* dlogit_scale;   // dlogit_scale accumulated
+    int B, E;
+};
+hipError_t launch_itc_fwd(const ItcArgs& a, hipStream_t s);
+hipError_t launch_itc_bwd(const ItcBwdArgs& a, hipStream_t s);
+
+struct LossArgs {
+    const float* out_cls; const int64_t* onehot; const float* class_w;   // [B,C], [B,C], [C] or null
+    const float* logits_per_text;                                        // [B,B] or null
+    const float* out_tim; const int64_t* lbl_tim;                        // [B,2], [B] or null
+    float w_cls, w_itc, w_itm;
+    float* loss;            // [4]: total, cls, itc, itm
+    float* d_out_cls; float* d_logits; float* d_out_tim;                 // gradients of the total loss (may be null)
+    int* n_correct;         // argmax(out_cls) == argmax(onehot) count (may be null)
+    int B, C;
+};
+hipError_t launch_loss(const LossArgs& a, hipStream_t s);
+
+hipError_t launch_elementwise(int op, const float* a, const float* b, float* out, size_t n, float alpha, const DropCfg& drop, hipStream_t s);
+enum { EW_TANH_BWD = 0, EW_RELU_BWD = 1, EW_DROPOUT = 2, EW_ADD = 3, EW_COPY = 4 };
+hipError_t launch_bias_grad_f32(const float* d, int rows, int cols, int ld, float* out, int accumulate, hipStream_t s);
+
+// ---------------------------------------------------------------- optimizer
+struct AdamWArgs {
+    float* p; float* g; float* m; float* v; size_t n;
+    float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt;
+    int zero_grad;
+    float grad_scale;     // gradients are multiplied by this before use (1/world for DP averaging)
+};
+hipError_t launch_adamw(const AdamWArgs& a, hipStream_t s);
+
+}  // namespace mmhip

@@ -1,0 +1,537 @@
+// Bandwidth-bound row kernels: LayerNorm fwd/bwd, text-embedding gather + LN (+ its backward scatter), ViT patchify /
+// token assembly, column sums (bias gradients), fp32 -> 16-bit casts (plain and transposed).
+// One wave per row, 8-byte (4 x 16-bit) or 16-byte (4 x fp32) accesses per lane, fp32 arithmetic.
+#include "mmhip_common.h"
+#include "mmhip_kernels.h"
+
+namespace mmhip {
+
+static constexpr int MAXC = 4;   // 4-element chunks per lane: width <= 64*4*4 = 1024
+
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* v) {
+    typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = to_f<T>(x[e]);
+}
+template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
+    f32x4 x = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = x[e];
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float* v) {
+    typename Vec<T>::v4 x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = from_f<T>(v[e]);
+    *reinterpret_cast<typename Vec<T>::v4*>(p) = x;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm forward
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int nch = a.width >> 2;
+    const T* x = (const T*)a.x + (size_t)row * a.ldx;
+    float v[MAXC][4];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+        const int c = lane + 64 * t;
+        if (c < nch) {
+            load4<T>(x + c * 4, v[t]);
+            s += v[t][0] + v[t][1] + v[t][2] + v[t][3];
+        }
+    }
+    const float mean = wave_sum(s) / a.width;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t)
+        if (lane + 64 * t < nch)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float d = v[t][e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / a.width + a.eps);
+    T* y = (T*)a.y + (size_t)row * a.ldy;
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+        const int c = lane + 64 * t;
+        if (c < nch) {
+            float g[4], b[4], o[4];
+            load4<float>(a.gamma + c * 4, g);
+            load4<float>(a.beta + c * 4, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[t][e] - mean) * rstd * g[e] + b[e];
+            store4<T>(y + c * 4, o);
+        }
+    }
+    if (lane == 0 && a.mean) { a.mean[row] = mean; a.rstd[row] = rstd; }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) (+ dres), g = dy * gamma; dgamma += dy * xhat, dbeta += dy.
+// A block walks ROWS_PER_BLOCK rows (wave-strided), keeps the column partials in registers, reduces the 4 waves
+// through LDS and issues one atomic per column per block.
+static constexpr int LN_ROWS_PER_BLOCK = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
+    __shared__ float red[2][4][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nch = a.width >> 2;
+    float dg[MAXC][4], db[MAXC][4], gam[MAXC][4];
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dg[t][e] = 0.f; db[t][e] = 0.f; gam[t][e] = 0.f; }
+        if (lane + 64 * t < nch) load4<float>(a.gamma + (lane + 64 * t) * 4, gam[t]);
+    }
+    const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK;
+    for (int rr = w; rr < LN_ROWS_PER_BLOCK; rr += 4) {
+        const int row = r0 + rr;
+        if (row >= a.rows) break;
+        const T* x = (const T*)a.x + (size_t)row * a.width;
+        const T* dy = (const T*)a.dy + (size_t)row * a.width;
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        float xh[MAXC][4], g[MAXC][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            if (c < nch) {
+                float xv[4], dv[4];
+                load4<T>(x + c * 4, xv);
+                load4<T>(dy + c * 4, dv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[t][e] = (xv[e] - mean) * rstd;
+                    g[t][e] = dv[e] * gam[t][e];
+                    s1 += g[t][e];
+                    s2 += g[t][e] * xh[t][e];
+                    dg[t][e] += dv[e] * xh[t][e];
+                    db[t][e] += dv[e];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / a.width, c2 = wave_sum(s2) / a.width;
+        T* dx = (T*)a.dx + (size_t)row * a.width;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            if (c < nch) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (g[t][e] - c1 - xh[t][e] * c2);
+                if (a.dres) {
+                    float r[4];
+                    load4<T>((const T*)a.dres + (size_t)row * a.width + c * 4, r);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += r[e];
+                }
+                store4<T>(dx + c * 4, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t)
+        if (lane + 64 * t < nch)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[0][w][(lane + 64 * t) * 4 + e] = dg[t][e]; red[1][w][(lane + 64 * t) * 4 + e] = db[t][e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.width; c += 256) {
+        atomicAdd(a.dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(a.dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ text embeddings
+// position ids: XLM-R  cumsum(ids != pad) * (ids != pad) + pad  (HF xlm_roberta :142-155); BERT arange(T).
+__global__ __launch_bounds__(64) void pos_ids_kernel(const int64_t* ids, const int64_t* mask, int* pos_ids, float* maskbias, int T, int xlmr, int pad_id) {
+    const int post = blockIdx.x, lane = threadIdx.x;
+    int running = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const bool in = t < T;
+        const bool nz = in && ids[(size_t)post * T + t] != pad_id;
+        const unsigned long long bal = __ballot(nz);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull)) + (nz ? 1 : 0);
+        if (in) {
+            pos_ids[(size_t)post * T + t] = xlmr ? (nz ? running + pre + pad_id : pad_id) : t;
+            maskbias[(size_t)post * T + t] = mask[(size_t)post * T + t] ? 0.f : -INFINITY;
+        }
+        running += __popcll(bal);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.posts * a.T) return;
+    const int nch = a.H >> 2;
+    const int64_t id = a.ids[row];
+    const int pid = a.pos_ids[row];
+    const float* wr = a.word + (size_t)id * a.H;
+    const float* pr = a.pos + (size_t)pid * a.H;
+    float v[MAXC][4];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+        const int c = lane + 64 * t;
+        if (c < nch) {
+            float x1[4], x2[4], x3[4];
+            load4<float>(wr + c * 4, x1);
+            load4<float>(pr + c * 4, x2);
+            load4<float>(a.type + c * 4, x3);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[t][e] = x1[e] + x3[e] + x2[e]; s += v[t][e]; }
+        }
+    }
+    const float mean = wave_sum(s) / a.H;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t)
+        if (lane + 64 * t < nch)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float d = v[t][e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / a.H + a.eps);
+    T* y = (T*)a.x + (size_t)row * a.H;
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+        const int c = lane + 64 * t;
+        if (c < nch) {
+            float g[4], b[4], o[4], xh[4];
+            load4<float>(a.gamma + c * 4, g);
+            load4<float>(a.beta + c * 4, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xh[e] = (v[t][e] - mean) * rstd; o[e] = xh[e] * g[e] + b[e]; }
+            if (a.xhat) store4<T>((T*)a.xhat + (size_t)row * a.H + c * 4, xh);
+            if (a.drop.thresh16) {
+                const uint32_t e0 = (uint32_t)row * (uint32_t)a.H + (uint32_t)c * 4u;
+                bool k0, k1, k2, k3;
+                mm_keep2(e0, a.drop, k0, k1);
+                mm_keep2(e0 + 2, a.drop, k2, k3);
+                o[0] = k0 ? o[0] * a.drop.keep_scale : 0.f;
+                o[1] = k1 ? o[1] * a.drop.keep_scale : 0.f;
+                o[2] = k2 ? o[2] * a.drop.keep_scale : 0.f;
+                o[3] = k3 ? o[3] * a.drop.keep_scale : 0.f;
+            }
+            store4<T>(y + c * 4, o);
+        }
+    }
+    if (lane == 0 && a.rstd) a.rstd[row] = rstd;
+}
+
+// backward: dropout -> LN backward (from saved xhat, rstd) -> scatter-add into word / position / type tables.
+// Rows of nn.Embedding(padding_idx=...) get no gradient (word row pad_id; XLM-R position row pad_id).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
+    __shared__ float red[3][4][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nch = a.H >> 2, rows = a.posts * a.T;
+    float dg[MAXC][4], db[MAXC][4], dt[MAXC][4], gam[MAXC][4];
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dg[t][e] = 0.f; db[t][e] = 0.f; dt[t][e] = 0.f; gam[t][e] = 0.f; }
+        if (lane + 64 * t < nch) load4<float>(a.gamma + (lane + 64 * t) * 4, gam[t]);
+    }
+    const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK;
+    for (int rr = w; rr < LN_ROWS_PER_BLOCK; rr += 4) {
+        const int row = r0 + rr;
+        if (row >= rows) break;
+        const float rstd = a.rstd[row];
+        float xh[MAXC][4], g[MAXC][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            if (c < nch) {
+                float dv[4];
+                load4<T>((const T*)a.dx + (size_t)row * a.H + c * 4, dv);
+                load4<T>((const T*)a.xhat + (size_t)row * a.H + c * 4, xh[t]);
+                if (a.drop.thresh16) {
+                    const uint32_t e0 = (uint32_t)row * (uint32_t)a.H + (uint32_t)c * 4u;
+                    bool k0, k1, k2, k3;
+                    mm_keep2(e0, a.drop, k0, k1);
+                    mm_keep2(e0 + 2, a.drop, k2, k3);
+                    dv[0] = k0 ? dv[0] * a.drop.keep_scale : 0.f;
+                    dv[1] = k1 ? dv[1] * a.drop.keep_scale : 0.f;
+                    dv[2] = k2 ? dv[2] * a.drop.keep_scale : 0.f;
+                    dv[3] = k3 ? dv[3] * a.drop.keep_scale : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    g[t][e] = dv[e] * gam[t][e];
+                    s1 += g[t][e];
+                    s2 += g[t][e] * xh[t][e];
+                    dg[t][e] += dv[e] * xh[t][e];
+                    db[t][e] += dv[e];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / a.H, c2 = wave_sum(s2) / a.H;
+        const int64_t id = a.ids[row];
+        const int pid = a.pos_ids[row];
+        float* wrow = (id != a.pad_id) ? a.dword + (size_t)id * a.H : nullptr;
+        float* prow = (pid != a.pos_pad_id) ? a.dpos + (size_t)pid * a.H : nullptr;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o = rstd * (g[t][e] - c1 - xh[t][e] * c2);
+                    dt[t][e] += o;
+                    if (wrow) atomicAdd(wrow + c * 4 + e, o);
+                    if (prow) atomicAdd(prow + c * 4 + e, o);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t)
+        if (lane + 64 * t < nch)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (lane + 64 * t) * 4 + e;
+                red[0][w][c] = dg[t][e]; red[1][w][c] = db[t][e]; red[2][w][c] = dt[t][e];
+            }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.H; c += 256) {
+        atomicAdd(a.dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(a.dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        atomicAdd(a.dtype + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ViT input
+// pixels [B,3,img,img] fp32 NCHW -> patches [B*np*np, 3*ps*ps] 16-bit, column = c*ps*ps + i*ps + j
+// (the flattening of the conv weight [H,3,ps,ps], HF vit :60,69).  8 consecutive j per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ px, T* __restrict__ out, int B, int img, int ps) {
+    const int np = img / ps, K = 3 * ps * ps, kc = K / 8;
+    const size_t total = (size_t)B * np * np * kc;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int ch = idx % kc;
+        const size_t prow = idx / kc;
+        const int col = ch * 8, c = col / (ps * ps), i = (col / ps) % ps, j = col % ps;
+        const int b = prow / (np * np), py = (prow / np) % np, pxi = prow % np;
+        const float* src = px + (((size_t)b * 3 + c) * img + (py * ps + i)) * img + pxi * ps + j;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+        typename Vec<T>::v8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = from_f<T>(v0[e]); o[4 + e] = from_f<T>(v1[e]); }
+        *reinterpret_cast<typename Vec<T>::v8*>(out + prow * K + col) = o;
+    }
+}
+// x[b*P] = cls + pos[0]; x[b*P + 1 + p] = patches[b*(P-1) + p] + pos[1 + p]      (HF vit :146-157)
+template <typename T>
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const T* __restrict__ patches, const float* __restrict__ cls, const float* __restrict__ pos, T* __restrict__ x, int B, int P, int H) {
+    const int hc = H / 4;
+    const size_t total = (size_t)B * P * hc;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (idx % hc) * 4;
+        const size_t row = idx / hc;
+        const int b = row / P, p = row % P;
+        float v[4], q[4];
+        if (p == 0) load4<float>(cls + c, v);
+        else load4<T>(patches + ((size_t)b * (P - 1) + (p - 1)) * H + c, v);
+        load4<float>(pos + (size_t)p * H + c, q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += q[e];
+        store4<T>(x + row * H + c, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// out[c] += sum_r x[r][c]   (bias gradients).  grid (ceil(cols/256), row chunks); lanes own 4 columns each.
+static constexpr int COLSUM_ROWS = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int cols, int ld, float* __restrict__ out) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        const int r1 = min(rows, (int)(blockIdx.y + 1) * COLSUM_ROWS);
+        for (int r = blockIdx.y * COLSUM_ROWS + w; r < r1; r += 4) {
+            float v[4];
+            load4<T>(x + (size_t)r * ld + c, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[w][lane * 4 + e] = s[e];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < cols) atomicAdd(out + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------ casts
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float v[4];
+        load4<float>(src + i * 4, v);
+        store4<T>(dst + i * 4, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = from_f<T>(src[n4 * 4 + threadIdx.x]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(size_t)(r0 + r) * cols + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (r0 + r < rows && c0 + c < cols) dst[(size_t)(c0 + c) * rows + r0 + r] = from_f<T>(tile[r][c]);
+    }
+}
+// dx[post*T + t][:] = (t == 0) ? d[post][:] : 0        (gradient of the last hidden state: only CLS rows are read)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restrict__ d, T* __restrict__ dx, int posts, int Tn, int H) {
+    const int hc = H / 4;
+    const size_t total = (size_t)posts * Tn * hc;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (idx % hc) * 4;
+        const size_t row = idx / hc;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row % Tn == 0) load4<float>(d + (row / Tn) * H + c, v);
+        store4<T>(dx + row * H + c, v);
+    }
+}
+
+// dst = dropout(src) on the linear element index (backward of a GEMM-epilogue dropout: same mask, same scale)
+template <typename T>
+__global__ __launch_bounds__(256) void dropout16_kernel(const T* __restrict__ src, T* __restrict__ dst, size_t n, DropCfg d) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float v[4];
+        load4<T>(src + i * 4, v);
+        bool k0, k1, k2, k3;
+        mm_keep2((uint32_t)(i * 4), d, k0, k1);
+        mm_keep2((uint32_t)(i * 4 + 2), d, k2, k3);
+        v[0] = k0 ? v[0] * d.keep_scale : 0.f;
+        v[1] = k1 ? v[1] * d.keep_scale : 0.f;
+        v[2] = k2 ? v[2] * d.keep_scale : 0.f;
+        v[3] = k3 ? v[3] * d.keep_scale : 0.f;
+        store4<T>(dst + i * 4, v);
+    }
+}
+// out[r][0..H) (fp32, row stride ldo) = src[r * src_stride .. +H) (16-bit): CLS-row gather
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const T* __restrict__ src, size_t src_stride, float* __restrict__ out, int ldo, int rows, int H) {
+    const int hc = H / 4;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rows * hc; idx += gridDim.x * 256) {
+        const int r = idx / hc, c = (idx % hc) * 4;
+        float v[4];
+        load4<T>(src + (size_t)r * src_stride + c, v);
+        *reinterpret_cast<f32x4*>(out + (size_t)r * ldo + c) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+#define DISPATCH_T(dtype, KERNEL, grid, block, stream, ...)                                        \
+    do {                                                                                           \
+        if ((dtype) == DT_BF16) hipLaunchKernelGGL((KERNEL<bf16_t>), grid, block, 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<f16_t>), grid, block, 0, stream, __VA_ARGS__);             \
+    } while (0)
+
+static inline int cap_grid(size_t work_items) {
+    size_t g = (work_items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s) {
+    if (a.rows <= 0) return hipSuccess;
+    if (a.width % 4 || a.width > 1024 || a.ldx % 4 || a.ldy % 4) return hipErrorInvalidValue;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ln_fwd_kernel<f16_t>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s) {
+    if (a.rows <= 0) return hipSuccess;
+    if (a.width % 4 || a.width > 1024) return hipErrorInvalidValue;
+    const int grid = (a.rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s) {
+    if (a.posts <= 0) return hipSuccess;
+    if (a.H % 4 || a.H > 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pos_ids_kernel, dim3(a.posts), dim3(64), 0, s, a.ids, a.mask, a.pos_ids, a.maskbias, a.T, a.xlmr, a.pad_id);
+    const int grid = (a.posts * a.T + 3) / 4;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(embed_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s) {
+    if (a.posts <= 0) return hipSuccess;
+    const int grid = (a.posts * a.T + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(embed_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_patchify(const float* pixels, void* out, int B, int img, int patch, int dtype, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (patch % 8 || img % patch) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * (img / patch) * (img / patch) * (3 * patch * patch / 8);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(cap_grid(total)), dim3(256), 0, s, pixels, (bf16_t*)out, B, img, patch);
+    else hipLaunchKernelGGL(patchify_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, pixels, (f16_t*)out, B, img, patch);
+    return hipGetLastError();
+}
+hipError_t launch_vit_assemble(const void* patches, const float* cls, const float* pos, void* x, int B, int P, int H, int dtype, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const size_t total = (size_t)B * P * (H / 4);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(vit_assemble_kernel<bf16_t>, dim3(cap_grid(total)), dim3(256), 0, s, (const bf16_t*)patches, cls, pos, (bf16_t*)x, B, P, H);
+    else hipLaunchKernelGGL(vit_assemble_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, (const f16_t*)patches, cls, pos, (f16_t*)x, B, P, H);
+    return hipGetLastError();
+}
+hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    if (cols % 4 || ld % 4) return hipErrorInvalidValue;
+    dim3 grid((cols + 255) / 256, (rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, cols, ld, out);
+    else hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, rows, cols, ld, out);
+    return hipGetLastError();
+}
+hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s) {
+    if (!n) return hipSuccess;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(cap_grid(n / 4 + 1)), dim3(256), 0, s, src, (bf16_t*)dst, n);
+    else hipLaunchKernelGGL(cast_kernel<f16_t>, dim3(cap_grid(n / 4 + 1)), dim3(256), 0, s, src, (f16_t*)dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_cast_transpose(const float* src, void* dst, int rows, int cols, int dtype, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, rows, cols);
+    else hipLaunchKernelGGL(cast_transpose_kernel<f16_t>, grid, dim3(256), 0, s, src, (f16_t*)dst, rows, cols);
+    return hipGetLastError();
+}
+hipError_t launch_dropout16(const void* src, void* dst, size_t n, const DropCfg& d, int dtype, hipStream_t s) {
+    if (!n) return hipSuccess;
+    if (n % 4) return hipErrorInvalidValue;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(dropout16_kernel<bf16_t>, dim3(cap_grid(n / 4)), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n, d);
+    else hipLaunchKernelGGL(dropout16_kernel<f16_t>, dim3(cap_grid(n / 4)), dim3(256), 0, s, (const f16_t*)src, (f16_t*)dst, n, d);
+    return hipGetLastError();
+}
+hipError_t launch_gather_rows_f32(const void* src, size_t src_stride, float* out, int ldo, int rows, int H, int dtype, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (H % 4 || ldo % 4) return hipErrorInvalidValue;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(gather_rows_f32_kernel<bf16_t>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const bf16_t*)src, src_stride, out, ldo, rows, H);
+    else hipLaunchKernelGGL(gather_rows_f32_kernel<f16_t>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const f16_t*)src, src_stride, out, ldo, rows, H);
+    return hipGetLastError();
+}
+hipError_t launch_scatter_cls_rows(const float* d, void* dx, int posts, int T, int H, int dtype, hipStream_t s) {
+    if (posts <= 0) return hipSuccess;
+    const size_t total = (size_t)posts * T * (H / 4);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(scatter_cls_kernel<bf16_t>, dim3(cap_grid(total)), dim3(256), 0, s, d, (bf16_t*)dx, posts, T, H);
+    else hipLaunchKernelGGL(scatter_cls_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, d, (f16_t*)dx, posts, T, H);
+    return hipGetLastError();
+}
+
+}  // namespace mmhip
