@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Benchmark of the late-fusion fine-tuning step (BASELINE.json metric: posts/sec, Bernice + ViT-B/16, attention fusion,
+bs = 64 per GPU, bf16) on N MI355X of one node.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--aux] [--dtype bf16|f16] [--batch 64] [--no-cpu-baseline]
+
+A step = one full training step on one synthetic batch already resident in HBM: ViT forward (frozen), text forward,
+heads, fused loss, backward, gradient exchange (N > 1), fused AdamW, 16-bit weight refresh.  N > 1 is launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (one rank per GPU, RCCL); weak scaling:
+every rank has its own 64 posts.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs per post, BASELINE.md 2 (2*MAC; forward 58.173, backward text 44.695 + heads 0.930; ViT frozen)
+GF_PER_POST = {"plain": 103.798, "aux": 171.528}
+PEAK_TFLOPS = 2500.0        # bf16 / f16 dense MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """the CPU oracle (plain PyTorch fp32 restatement of the reference path) timed on this box's host cores:
+    forward+backward of the same model on a bounded sample (B=8 posts of the same synthetic shape)."""
+    import torch
+    from oracle import mm_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.OracleConfig(num_labels=2)
+    P = {k: v.requires_grad_(O.trainable(k)) for k, v in O.make_params(cfg, 0).items()}
+    B = 8
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, B, 128, 1234, False)
+    drop = O.Dropout("torch")
+
+    def step():
+        for p in P.values():
+            p.grad = None
+        out_cls, lpt, _, _, _ = O.mm_forward(P, ids, mask, pixels, cfg, None, drop)
+        O.mix_loss(out_cls, onehot, None, lpt, None, None, False, False).backward()
+
+    step()
+    t0, n = time.time(), 0
+    while n < 1 or (time.time() - t0 < seconds_budget * 0.6 and n < 4):
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 3), "unit": "posts/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+bwd steps of B={B} posts (T=128, 224x224), fp32 torch CPU oracle, optimizer excluded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--aux", action="store_true", help="BASELINE config 3: ITC + ITM auxiliary losses")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--txt_model_name", default="bernice")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import types
+    import numpy as np
+    import torch
+    import smtc_amd  # noqa: F401
+    from smtc_amd import _lib, dist as mmdist
+    from smtc_amd.mm_late import MMLate_Model
+    from smtc_amd.synthetic import synthetic_batch
+
+    mmdist.init_from_env()
+    world, rank = mmdist.world_size(), mmdist.rank()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}")
+    torch.cuda.set_device(dev)
+
+    B, T, C = args.batch, 128, (3 if args.aux else 2)
+    cfg = types.SimpleNamespace(batch_size=B, num_labels=C, use_clip_loss=args.aux, beta_itc=0.1 if args.aux else None,
+                                use_tim_loss=args.aux, beta_itm=0.1 if args.aux else None, max_length=T, dropout=0.05)
+    trainer = MMLate_Model(cfg, args.txt_model_name, "vit", "attention", dtype=args.dtype, seed=0)
+    a = trainer.model.arch
+    ids, mask, pixels, onehot = synthetic_batch(a["vocab"], C, B, T, 1234 + rank, a["txt_kind"], a["pad_id"], False, a["image"], dev)
+    np.random.seed(30 + rank)
+    lr, wd = 1e-5, 0.00025
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    step_no = 0
+    for _ in range(args.warmup):
+        step_no += 1
+        trainer.train_step(ids, mask, pixels, onehot, None, lr, wd, step_no)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_no += 1
+        loss, _ = trainer.train_step(ids, mask, pixels, onehot, None, lr, wd, step_no)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_step = elapsed / args.steps * 1e3
+    posts_s = world * B * args.steps / elapsed
+    final_loss = float(loss[0].item())
+
+    # ---- extra: forward+backward only (no optimizer / refresh), same batch
+    lib, m = _lib.lib(), trainer.model
+    sync()
+    t1 = time.perf_counter()
+    nfb = max(3, args.steps // 4)
+    for _ in range(nfb):
+        tim = trainer.prepare_itm_inputs(ids, mask) if args.aux else (None, None, None)
+        m._engine_forward(ids, mask, pixels, tim[0], tim[1])
+        lo = torch.empty(4, device=dev)
+        w_cls, w_itc, w_itm = trainer.loss_weights()
+        _lib.check(lib.mmhip_loss(m._handle, _lib.ptr(onehot), None, _lib.ptr(tim[2]), w_cls, w_itc, w_itm, _lib.ptr(lo), None, _lib.stream_ptr()))
+        _lib.check(lib.mmhip_backward(m._handle, None, None, None, None, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    fb_ms = (time.perf_counter() - t1) / nfb * 1e3
+    m._flat_grad.zero_()
+
+    # ---- roofline of the dominant kernel (MFMA NT GEMM): HIP events around every launch, on the launch stream
+    import ctypes as Ct
+    _lib.check(lib.mmhip_gemm_timing(m._handle, 1, 1, None, None, None))
+    for _ in range(2):
+        step_no += 1
+        trainer.train_step(ids, mask, pixels, onehot, None, lr, wd, step_no)
+    gms, gl, gf = Ct.c_double(), Ct.c_uint64(), Ct.c_double()
+    _lib.check(lib.mmhip_gemm_timing(m._handle, 0, 1, Ct.byref(gms), Ct.byref(gl), Ct.byref(gf)))
+    achieved = gf.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (128x128x64 MFMA 16x16x32, LDS-DMA staged)", "achieved": round(achieved, 1),
+                "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": int(gl.value // 2), "avg_launch_us": round(gms.value * 1e3 / max(1, gl.value), 2),
+                "gemm_ms_per_step": round(gms.value / 2, 3)}
+    mode = "aux" if args.aux else "plain"
+    out = {
+        "metric": "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion, bs=64",
+        "value": round(posts_s, 1), "unit": "posts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": ("BASELINE config 3: Bernice+ViT-B/16, attention fusion, ITC+ITM, bs=64/GPU" if args.aux else
+                                "BASELINE config 2: Bernice+ViT-B/16, attention fusion, no aux loss, bs=64/GPU"),
+                   "step": "full train step: fwd + loss + bwd + grad exchange + AdamW + weight refresh",
+                   "posts_per_gpu": B, "text_tokens": T, "image": a["image"], "vocab": a["vocab"], "parallelism": f"dp{world}",
+                   "weights": "random-init at true shapes"},
+        "fwd_bwd_ms": round(fb_ms, 3), "fwd_bwd_posts_per_s": round(world * B / (fb_ms * 1e-3), 1),
+        "model_tflops": round(posts_s * GF_PER_POST[mode] / 1e3, 1),
+        "model_frac_of_peak": round(posts_s / world * GF_PER_POST[mode] / 1e3 / PEAK_TFLOPS, 4),
+        "final_loss": round(final_loss, 5), "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""Data parallelism for the late-fusion step: one process per GPU (torchrun), torch.distributed backend "nccl" (= RCCL
+over xGMI on ROCm); "gloo" on CPU for the tests.  The reference has no distributed layer: semantics are
+"the reference run per rank on its own B posts (ITC / ITM stay rank-local), gradients averaged".
+
+Exchange plan:
+  * dense all-reduce (sum; AdamW multiplies by 1/world) of each backward stage's parameter range, launched right after
+    the stage is enqueued, so RCCL overlaps with the remaining backward stages (heads -> layer L-1 ... 0 -> embeddings);
+  * the word-embedding gradient (vocab x H, 768 MB for Bernice) is row-sparse: ranks exchange (row id, row) for the rows
+    they touched (<= B*T of them) with one all_gather, then add the other ranks' rows locally -- exact, 25 MB per rank
+    instead of 768 MB.
+"""
+import os
+
+import torch
+import torch.distributed as td
+
+
+def world_size():
+    return td.get_world_size() if td.is_available() and td.is_initialized() else 1
+
+
+def rank():
+    return td.get_rank() if td.is_available() and td.is_initialized() else 0
+
+
+def init_from_env(backend=None):
+    """torchrun / torch.distributed.run environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT)."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or (td.is_available() and td.is_initialized()):
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    td.init_process_group(backend=backend)
+
+
+def allreduce_range(flat_grad, begin, end, async_op=True):
+    """sum-all-reduce flat_grad[begin:end] in place; returns the Work handle (or None)"""
+    if end <= begin:
+        return None
+    return td.all_reduce(flat_grad[begin:end], op=td.ReduceOp.SUM, async_op=async_op)
+
+
+def sparse_rows_exchange(table_grad, ids):
+    """table_grad [V, H] holds this rank's gradient rows (non-zero only for rows in `ids`); afterwards it holds the sum
+    over ranks.  Fixed-size payload (no host sync): rows are sent once per distinct id (first occurrence in sorted order),
+    the other slots carry zeros."""
+    W = world_size()
+    if W == 1:
+        return
+    ids = ids.reshape(-1).to(table_grad.device)
+    sorted_ids, _ = torch.sort(ids)
+    first = torch.ones_like(sorted_ids, dtype=torch.bool)
+    first[1:] = sorted_ids[1:] != sorted_ids[:-1]
+    payload = table_grad.index_select(0, sorted_ids) * first.unsqueeze(1).to(table_grad.dtype)
+    ids_all = [torch.empty_like(sorted_ids) for _ in range(W)]
+    pay_all = [torch.empty_like(payload) for _ in range(W)]
+    td.all_gather(ids_all, sorted_ids)
+    td.all_gather(pay_all, payload)
+    me = rank()
+    for r in range(W):
+        if r != me:
+            table_grad.index_add_(0, ids_all[r], pay_all[r])
+
+
+def exchange_stage(model, stage, n_stage, use_itc, use_itm):
+    """called right after backward stage `stage` was enqueued; returns async Work handles to wait on before AdamW"""
+    works = []
+    b, e = model._stage_ranges[stage]
+    if stage < n_stage - 1:
+        w = allreduce_range(model._flat_grad, b, e)
+        if w is not None:
+            works.append(w)
+        return works
+    # embeddings: [LayerNorm, type, position] dense; word table sparse
+    word = next(i for i in model._train_params if i["name"].endswith("word_embeddings.weight"))
+    w = allreduce_range(model._flat_grad, b, word["offset"])
+    if w is not None:
+        works.append(w)
+    V, H = word["shape"]
+    table = model._flat_grad[word["offset"]: word["offset"] + V * H].view(V, H)
+    sparse_rows_exchange(table, model._last["ids_all"])
+    return works

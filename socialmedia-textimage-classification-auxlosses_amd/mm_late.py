@@ -1,0 +1,522 @@
+"""Drop-in for the reference's late-fusion model and trainer (models/mm_late.py), backed by libmmhip.so.
+
+  MM_Model        same constructor / forward signature / state_dict keys as reference models/mm_late.py:50-193;
+                  forward + backward run the hand-written HIP kernels through the C ABI (include/mmhip.h).
+  MMLate_Model    same role as reference models/mm_late.py:298-739 (ITM sampling :389-414, train :416-532, eval :534-638),
+                  with a fused step (loss + backward + AdamW on flat buffers) and one-process-per-GPU data parallelism.
+
+There is no CPU / eager fallback: without the built library (or without a GPU) construction raises.
+"""
+import ctypes as C
+import json
+import logging
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import dist as mmdist
+from .config import MODEL_DIR_DICT, TEXT_ARCH, IMAGE_ARCH, metric_names
+from .utils import agg_metrics_val
+
+logger = logging.getLogger(__name__)
+
+
+class Scaled_Dot_Product_Attention(nn.Module):
+    """reference models/mm_late.py:195-210 (kept for API parity; MM_Model's attention fusion runs inside the engine)."""
+
+    def forward(self, Q, K, V, scale=None):
+        attention = torch.matmul(Q, K.permute(0, 2, 1))
+        scores = attention
+        if scale:
+            attention = attention * scale
+        attention = torch.softmax(attention, dim=-1)
+        return torch.matmul(attention, V), scores
+
+
+class _Node(nn.Module):
+    """name-space node so that parameters carry the reference checkpoint's dotted keys"""
+
+
+def default_arch(txt_model_name, img_model_name):
+    if txt_model_name not in TEXT_ARCH:
+        raise ValueError(f"text model {txt_model_name!r}: late-fusion path supports {sorted(TEXT_ARCH)}")
+    if img_model_name not in IMAGE_ARCH:
+        raise ValueError(f"image model {img_model_name!r}: late-fusion HIP path supports {sorted(IMAGE_ARCH)} (ViT-B/16)")
+    a = dict(hidden=768, heads=12, inter=3072, layers_txt=12, layers_img=12, proj_dim=512, p_hidden=0.1, p_attn=0.1)
+    a.update(TEXT_ARCH[txt_model_name])
+    a.update(IMAGE_ARCH[img_model_name])
+    return a
+
+
+def _read_hf_dir(path):
+    """(config dict, state dict) of a local HuggingFace model directory, or (None, None)"""
+    cfg_file = os.path.join(path, "config.json")
+    if not os.path.isfile(cfg_file):
+        return None, None
+    with open(cfg_file) as f:
+        cfg = json.load(f)
+    sd = None
+    if os.path.isfile(os.path.join(path, "model.safetensors")):
+        from safetensors.torch import load_file
+        sd = load_file(os.path.join(path, "model.safetensors"))
+    elif os.path.isfile(os.path.join(path, "pytorch_model.bin")):
+        sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+    return cfg, sd
+
+
+def _vit_key_to_ref(k):
+    """transformers >= 5 ViT names -> 4.25.1 checkpoint names"""
+    if k.startswith("layers."):
+        k = "encoder.layer." + k[len("layers."):]
+        k = k.replace("attention.q_proj", "attention.attention.query").replace("attention.k_proj", "attention.attention.key")
+        k = k.replace("attention.v_proj", "attention.attention.value").replace("attention.o_proj", "attention.output.dense")
+        k = k.replace("mlp.fc1", "intermediate.dense").replace("mlp.fc2", "output.dense")
+    return k
+
+
+class _MMFunction(torch.autograd.Function):
+    """autograd edge around the engine so that a reference-style caller's loss.backward() (mm_late.py:489) works."""
+
+    @staticmethod
+    def forward(ctx, model, ids, mask, pixels, tim_ids, tim_mask, *params):
+        outs = model._engine_forward(ids, mask, pixels, tim_ids, tim_mask)
+        ctx.model, ctx.token, ctx.has_tim = model, model._fwd_token, tim_ids is not None
+        ctx.set_materialize_grads(False)
+        out_cls, lpt, out_tim, feats = outs
+        return (out_cls, lpt, out_tim, feats) if ctx.has_tim else (out_cls, lpt, feats)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        model = ctx.model
+        if ctx.token != model._fwd_token:
+            raise RuntimeError("MM_Model: backward() after another forward(); the engine keeps one set of activations")
+        if ctx.has_tim:
+            d_cls, d_lpt, d_tim, d_feats = douts
+        else:
+            (d_cls, d_lpt, d_feats), d_tim = douts, None
+        grads = model._engine_backward_autograd(d_cls, d_lpt, d_tim, d_feats)
+        return (None,) * 6 + tuple(grads)
+
+
+class MM_Model(nn.Module):
+    """reference models/mm_late.py:50-193.
+
+    MM_Model(num_labels, txt_model_name, img_model_name, dropout, fusion_name='concat'); keyword-only extras are
+    additive: `arch` overrides (layer counts, vocab ... for tests), `dtype` ('bf16' | 'f16'), `max_posts` /
+    `max_text_len` (capacity the workspace is sized for), `device`, `seed`.
+    Weights: loaded from the local directories of config.MODEL_DIR_DICT when they exist (HF layout), else random
+    init at the architecture's true shapes (no network in this environment).
+    """
+
+    def __init__(self, num_labels, txt_model_name, img_model_name, dropout, fusion_name="concat", *, arch=None,
+                 dtype="bf16", max_posts=64, max_text_len=128, device=None, seed=0):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise _lib.MMHipError("MM_Model needs an MI355X (gfx950) GPU: the HIP path has no CPU fallback")
+        if fusion_name not in ("concat", "attention"):
+            raise NotImplementedError(f"fusion {fusion_name!r}: the HIP late-fusion path implements 'attention' and 'concat' "
+                                      "(reference models/mm_late.py:92-113)")
+        self.num_labels, self.fusion_name = num_labels, fusion_name
+        self.txt_model_name, self.img_model_name = txt_model_name, img_model_name
+        self.device_ = torch.device(device if device is not None else f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}")
+        a = default_arch(txt_model_name, img_model_name)
+        txt_cfg, txt_sd = _read_hf_dir(MODEL_DIR_DICT.get(txt_model_name, ""))
+        img_cfg, img_sd = _read_hf_dir(MODEL_DIR_DICT.get(img_model_name, ""))
+        if txt_cfg:
+            a.update(vocab=txt_cfg["vocab_size"], max_pos=txt_cfg["max_position_embeddings"], type_vocab=txt_cfg.get("type_vocab_size", 1),
+                     layers_txt=txt_cfg["num_hidden_layers"], ln_eps_txt=txt_cfg.get("layer_norm_eps", 1e-12),
+                     pad_id=txt_cfg.get("pad_token_id", a["pad_id"]), p_hidden=txt_cfg.get("hidden_dropout_prob", 0.1),
+                     p_attn=txt_cfg.get("attention_probs_dropout_prob", 0.1))
+        if img_cfg:
+            a.update(layers_img=img_cfg["num_hidden_layers"], image=img_cfg.get("image_size", 224), patch=img_cfg.get("patch_size", 16),
+                     ln_eps_img=img_cfg.get("layer_norm_eps", 1e-12))
+        a.update(arch or {})
+        self.arch = a
+        self.dtype_name = dtype
+        self._cfg_kw = dict(hidden=a["hidden"], heads=a["heads"], inter=a["inter"], layers_txt=a["layers_txt"], layers_img=a["layers_img"],
+                            vocab=a["vocab"], max_pos=a["max_pos"], type_vocab=a["type_vocab"],
+                            txt_kind=_lib.TXT_XLMR if a["txt_kind"] == "xlmr" else _lib.TXT_BERT, pad_id=a["pad_id"],
+                            ln_eps_txt=a["ln_eps_txt"], ln_eps_img=a["ln_eps_img"], image=a["image"], patch=a["patch"],
+                            proj_dim=a["proj_dim"], num_labels=num_labels,
+                            fusion=_lib.FUSION_ATTENTION if fusion_name == "attention" else _lib.FUSION_CONCAT,
+                            p_hidden=a["p_hidden"], p_attn=a["p_attn"], p_head=float(dropout),
+                            dtype={"bf16": _lib.BF16, "f16": _lib.F16}[dtype])
+        self._handle = None
+        self._capacity = (0, 0)
+        self._fwd_token = 0
+        self._seed_base = int(seed) if seed is not None else int(torch.initial_seed())
+        self._calls = 0
+        self._ws = None
+        self._last = {}
+        self._create_engine(max_posts, max_text_len, first=True)
+        self._init_weights()
+        if txt_sd is not None:
+            self._load_tower(txt_sd, "dual_encoder.text_model.", lambda k: k)
+        if img_sd is not None:
+            self._load_tower(img_sd, "dual_encoder.vision_model.", _vit_key_to_ref)
+        self._refresh_weights(3)
+
+    # ------------------------------------------------------------------ engine / buffers
+    def _create_engine(self, max_posts, max_text_len, first=False):
+        lib = _lib.lib()
+        cfg = _lib.Config(max_posts=int(max_posts), max_text_len=int(max_text_len), **self._cfg_kw)
+        h = C.c_void_p()
+        _lib.check(lib.mmhip_create(C.byref(cfg), C.byref(h)), "create")
+        if self._handle is not None:
+            lib.mmhip_destroy(self._handle)
+        self._handle = h
+        self._capacity = (int(max_posts), int(max_text_len))
+        dev = self.device_
+        if first:
+            n_frozen, n_train = lib.mmhip_buffer_numel(h, 0), lib.mmhip_buffer_numel(h, 1)
+            self._flat_frozen = torch.zeros(n_frozen, dtype=torch.float32, device=dev)
+            self._flat_train = torch.zeros(n_train, dtype=torch.float32, device=dev)
+            self._flat_grad = torch.zeros(n_train, dtype=torch.float32, device=dev)
+            self._infos = []
+            pi = _lib.ParamInfo()
+            for i in range(lib.mmhip_param_count(h)):
+                _lib.check(lib.mmhip_param_info_at(h, i, C.byref(pi)), "param_info")
+                self._infos.append(dict(name=pi.name.decode(), shape=tuple(pi.dims[: pi.ndim]), buffer=pi.buffer, group=pi.group,
+                                        offset=int(pi.offset), numel=int(pi.numel)))
+            self._register_parameters()
+        self._ws = None
+        torch.cuda.empty_cache()
+        self._ws = torch.empty(lib.mmhip_workspace_bytes(h), dtype=torch.uint8, device=dev)
+        _lib.check(lib.mmhip_bind(h, _lib.ptr(self._flat_frozen), _lib.ptr(self._flat_train), _lib.ptr(self._flat_grad),
+                                  _lib.ptr(self._ws), self._ws.numel()), "bind")
+        self._stage_ranges = []
+        b, e = C.c_uint64(), C.c_uint64()
+        for st in range(lib.mmhip_num_backward_stages(h)):
+            _lib.check(lib.mmhip_stage_grad_range(h, st, C.byref(b), C.byref(e)), "stage_grad_range")
+            self._stage_ranges.append((int(b.value), int(e.value)))
+        self._weights_version = None
+
+    def _register_parameters(self):
+        """nn.Parameters are views into the flat fp32 buffers, registered under the reference checkpoint's keys."""
+        self._train_params = []
+        for inf in self._infos:
+            flat = self._flat_frozen if inf["buffer"] == 0 else self._flat_train
+            view = flat[inf["offset"]: inf["offset"] + inf["numel"]].view(inf["shape"])
+            p = nn.Parameter(view, requires_grad=inf["buffer"] == 1)     # 'vision' parameters frozen, mm_late.py:67-69
+            node = self
+            parts = inf["name"].split(".")
+            for part in parts[:-1]:
+                if part not in node._modules:
+                    node.add_module(part, _Node())
+                node = node._modules[part]
+            node.register_parameter(parts[-1], p)
+            inf["param"] = p
+            if inf["buffer"] == 1:
+                self._train_params.append(inf)
+        # transformers 4.25.1 checkpoints carry this buffer
+        emb = self._modules["dual_encoder"]._modules["text_model"]._modules["embeddings"]
+        emb.register_buffer("position_ids", torch.arange(self.arch["max_pos"], device=self.device_).unsqueeze(0))
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().mmhip_destroy(self._handle)
+        except Exception:
+            pass
+
+    def _init_weights(self):
+        """HF initializer_range 0.02 for the towers, nn.Linear defaults for the heads (reference: from_pretrained + nn.Linear)."""
+        g = torch.Generator(device=self.device_).manual_seed(self._seed_base)
+        with torch.no_grad():
+            for inf in self._infos:
+                n, p = inf["name"], inf["param"]
+                if n.startswith("dual_encoder."):
+                    if n.endswith("logit_scale"):
+                        p.fill_(2.6592)
+                    elif "LayerNorm.weight" in n or ("layernorm" in n and n.endswith("weight")):
+                        p.fill_(1.0)
+                    elif n.endswith(".bias"):
+                        p.zero_()
+                    else:
+                        p.normal_(0.0, 0.02, generator=g)
+                else:
+                    fan_in = p.shape[1] if p.dim() == 2 else self.arch["hidden"] * (2 if n.startswith("linear_fusion") else 1)
+                    bound = 1.0 / math.sqrt(fan_in)
+                    p.uniform_(-bound, bound, generator=g)
+            pad = self.arch["pad_id"]
+            self._modules["dual_encoder"]._modules["text_model"]._modules["embeddings"]._modules["word_embeddings"].weight[pad].zero_()
+
+    def _load_tower(self, sd, prefix, keymap):
+        own = {inf["name"]: inf["param"] for inf in self._infos}
+        with torch.no_grad():
+            for k, v in sd.items():
+                for strip in ("vit.", "bert.", "roberta.", ""):
+                    if k.startswith(strip):
+                        name = prefix + keymap(k[len(strip):])
+                        if name in own and tuple(own[name].shape) == tuple(v.shape):
+                            own[name].copy_(v.to(own[name].device, torch.float32))
+                            break
+
+    def _refresh_weights(self, which):
+        _lib.check(_lib.lib().mmhip_refresh_weights(self._handle, which, _lib.stream_ptr()), "refresh_weights")
+        self._weights_version = (self._flat_train._version, self._flat_frozen._version)
+
+    def _ensure(self, B, T):
+        cap_b, cap_t = self._capacity
+        if B > cap_b or T > cap_t:
+            self._create_engine(max(B, cap_b), max(T, cap_t))
+            self._refresh_weights(3)
+        elif self._weights_version != (self._flat_train._version, self._flat_frozen._version):
+            # parameters were modified in place (optimizer.step / load_state_dict): re-derive the 16-bit GEMM operands
+            self._refresh_weights(3 if self._weights_version is None or self._weights_version[1] != self._flat_frozen._version else 2)
+
+    # ------------------------------------------------------------------ engine calls
+    def _engine_forward(self, ids, mask, pixels, tim_ids=None, tim_mask=None, seed=None):
+        dev = self.device_
+        ids = ids.to(dev, torch.int64).contiguous()
+        mask = mask.to(dev, torch.int64).contiguous()
+        pixels = pixels.to(dev, torch.float32).contiguous()
+        if ids.dim() != 2 or pixels.dim() != 4 or pixels.shape[0] != ids.shape[0]:
+            raise ValueError(f"MM_Model.forward: ids {tuple(ids.shape)} / pixel_values {tuple(pixels.shape)}")
+        B, T = ids.shape
+        if tuple(pixels.shape[1:]) != (3, self.arch["image"], self.arch["image"]):
+            raise ValueError(f"pixel_values must be [B,3,{self.arch['image']},{self.arch['image']}], got {tuple(pixels.shape)}")
+        if tim_ids is not None:
+            tim_ids = tim_ids.to(dev, torch.int64).contiguous()
+            tim_mask = tim_mask.to(dev, torch.int64).contiguous()
+        self._ensure(B, T)
+        if seed is None:
+            self._calls += 1
+            seed = (self._seed_base * 0x9E3779B97F4A7C15 + self._calls) & 0xFFFFFFFFFFFFFFFF
+        out_cls = torch.empty(B, self.num_labels, device=dev)
+        lpt = torch.empty(B, B, device=dev)
+        out_tim = torch.empty(B, 2, device=dev) if tim_ids is not None else None
+        feats = torch.empty(B, self.arch["hidden"], device=dev)
+        _lib.check(_lib.lib().mmhip_forward(self._handle, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(pixels), _lib.ptr(tim_ids), _lib.ptr(tim_mask),
+                                            B, T, int(self.training), seed, _lib.ptr(out_cls), _lib.ptr(lpt), _lib.ptr(out_tim),
+                                            _lib.ptr(feats), _lib.stream_ptr()), "forward")
+        self._fwd_token += 1
+        self._last = dict(B=B, T=T, itm=tim_ids is not None, seed=seed, ids_all=ids if tim_ids is None else torch.cat([ids, tim_ids]))
+        return out_cls, lpt, out_tim, feats
+
+    def active_groups(self, use_itc, use_itm):
+        g = {_lib.G_ALWAYS}
+        if self.fusion_name == "attention":
+            g.add(_lib.G_FUSION_ATT)
+        if use_itc:
+            g.add(_lib.G_ITC)
+        if use_itm:
+            g.add(_lib.G_ITM)
+        return g
+
+    def active_ranges(self, use_itc, use_itm):
+        """merged [begin, end) element ranges of the trainable flat buffer that receive gradients"""
+        groups = self.active_groups(use_itc, use_itm)
+        spans = sorted((i["offset"], i["offset"] + ((i["numel"] + 3) & ~3)) for i in self._train_params if i["group"] in groups)
+        out = []
+        for b, e in spans:
+            if out and out[-1][1] == b:
+                out[-1][1] = e
+            else:
+                out.append([b, e])
+        return [tuple(x) for x in out]
+
+    def _engine_backward_autograd(self, d_cls, d_lpt, d_tim, d_feats):
+        B = self._last["B"]
+        dev = self.device_
+        self._flat_grad.zero_()
+        f = lambda t: None if t is None else t.to(dev, torch.float32).contiguous()
+        d_cls = f(d_cls) if d_cls is not None else torch.zeros(B, self.num_labels, device=dev)
+        d_lpt, d_tim, d_feats = f(d_lpt), f(d_tim), f(d_feats)
+        _lib.check(_lib.lib().mmhip_backward(self._handle, _lib.ptr(d_cls), _lib.ptr(d_lpt), _lib.ptr(d_tim), _lib.ptr(d_feats),
+                                             _lib.stream_ptr()), "backward")
+        groups = self.active_groups(d_lpt is not None, d_tim is not None)
+        out = []
+        for inf in self._train_params:
+            if inf["group"] in groups:
+                out.append(self._flat_grad[inf["offset"]: inf["offset"] + inf["numel"]].view(inf["shape"]).clone())
+            else:
+                out.append(None)
+        return out
+
+    # ------------------------------------------------------------------ reference interface
+    def forward(self, ids, mask, pixel_values, tim_inputs=None, iadds_task=False):
+        """-> (out_cls, logits_per_text, out_tim | None, out_iadds = None, mm_features)   (mm_late.py:148-193)"""
+        if iadds_task:
+            raise NotImplementedError("iadds head is deprecated in the reference (models/config.py:65,68)")
+        tim_ids, tim_mask = tim_inputs if tim_inputs is not None else (None, None)
+        if torch.is_grad_enabled() and any(i["param"].requires_grad for i in self._train_params):
+            params = [i["param"] for i in self._train_params]
+            outs = _MMFunction.apply(self, ids, mask, pixel_values, tim_ids, tim_mask, *params)
+            if tim_ids is not None:
+                out_cls, lpt, out_tim, feats = outs
+            else:
+                (out_cls, lpt, feats), out_tim = outs, None
+        else:
+            out_cls, lpt, out_tim, feats = self._engine_forward(ids, mask, pixel_values, tim_ids, tim_mask)
+        return out_cls, lpt, out_tim, None, feats
+
+
+# =====================================================================================================================
+class MMLate_Model(object):
+    """reference models/mm_late.py:298-739 (late-fusion branch).  `train()`/`eval()` keep the reference's semantics
+    (loss mixing :473-487, ITM sampling :389-414 with the same numpy RNG call order, metrics CSVs every even epoch);
+    the step itself is fused: engine loss + backward + AdamW over flat buffers, gradients all-reduced per backward stage
+    when torch.distributed is initialised (one process per GPU, RCCL)."""
+
+    def __init__(self, config, txt_model_name, img_model_name, fusion_name, multilabel=False, **model_kw):
+        if multilabel:
+            raise NotImplementedError("multilabel BCE branch: no task enables it in the reference (models/config.py:10)")
+        self.batch_size, self.num_labels = config.batch_size, config.num_labels
+        self.multilabel = multilabel
+        self.use_clip_loss, self.beta_itc = config.use_clip_loss, config.beta_itc
+        self.use_tim_loss, self.beta_itm = config.use_tim_loss, config.beta_itm
+        self.txt_model_name, self.img_model_name = txt_model_name, img_model_name
+        self.max_length = config.max_length
+        model_kw.setdefault("max_posts", config.batch_size)
+        model_kw.setdefault("max_text_len", config.max_length)
+        self.model = MM_Model(self.num_labels, txt_model_name, img_model_name, config.dropout, fusion_name=fusion_name, **model_kw)
+        self.device = self.model.device_
+        self._opt = None
+        self.world = mmdist.world_size()
+
+    # ---- checkpoints (reference :343-345, :529-531): plain state_dict with the reference's keys
+    def load_saved_model(self, model_path):
+        self.model.load_state_dict(torch.load(model_path, map_location=self.device))
+
+    def save_model(self, model_path):
+        torch.save(self.model.state_dict(), model_path)
+
+    # ---- ITM negative sampling, reference :389-414 (same numpy RNG stream: one choice([True, False]) per row and one
+    # choice(list(others)) per swapped row; sources are read from the original ids, so swaps do not chain)
+    def prepare_itm_inputs(self, ids, mask):
+        B = ids.shape[0]
+        src, labels = list(range(B)), []
+        if B > 1:
+            for idx in range(B):
+                if np.random.choice([True, False]):
+                    labels.append(0)
+                    src[idx] = int(np.random.choice(list(set(range(B)) - {idx})))
+                else:
+                    labels.append(1)
+        else:
+            labels.append(1)
+        sel = torch.tensor(src, dtype=torch.int64, device=ids.device)
+        lbl = torch.tensor(labels, dtype=torch.long, device=self.device)
+        return ids.index_select(0, sel).to(self.device), mask.index_select(0, sel).to(self.device), lbl
+
+    def loss_weights(self):
+        """reference :473-487 -> (w_cls, w_itc, w_itm)"""
+        bi = self.beta_itc if self.use_clip_loss else 0.0
+        bm = self.beta_itm if self.use_tim_loss else 0.0
+        return 1.0 - (bi + bm), bi, bm
+
+    # ---- one fused training step on device tensors; returns (loss[4] device tensor, n_correct device tensor)
+    def train_step(self, ids, mask, pixel_values, onehot, class_weight, lr, weight_decay, step, tim=None):
+        m, lib = self.model, _lib.lib()
+        s = _lib.stream_ptr()
+        if self.use_tim_loss and tim is None:
+            tim = self.prepare_itm_inputs(ids, mask)
+        tim_ids, tim_mask, lbl_tim = tim if tim is not None else (None, None, None)
+        m.train()
+        m._engine_forward(ids, mask, pixel_values, tim_ids, tim_mask)
+        w_cls, w_itc, w_itm = self.loss_weights()
+        onehot = onehot.to(self.device, torch.int64).contiguous()
+        cw = None if class_weight is None else class_weight.to(self.device, torch.float32).contiguous()
+        loss = torch.empty(4, device=self.device)
+        ncorr = torch.empty(1, dtype=torch.int32, device=self.device)
+        _lib.check(lib.mmhip_loss(m._handle, _lib.ptr(onehot), _lib.ptr(cw), _lib.ptr(lbl_tim), w_cls, w_itc, w_itm, _lib.ptr(loss),
+                                  _lib.ptr(ncorr), s), "loss")
+        _lib.check(lib.mmhip_backward_begin(m._handle, None, None, None, None, s), "backward_begin")
+        works = []
+        n_stage = len(m._stage_ranges)
+        for st in range(n_stage):
+            _lib.check(lib.mmhip_backward_stage(m._handle, st, s), "backward_stage")
+            if self.world > 1:
+                works += mmdist.exchange_stage(m, st, n_stage, self.use_clip_loss, self.use_tim_loss)
+        for w in works:
+            w.wait()
+        self._adamw(lr, weight_decay, step)
+        m._refresh_weights(2)
+        return loss, ncorr
+
+    def _adamw(self, lr, weight_decay, step):
+        m, lib = self.model, _lib.lib()
+        if self._opt is None:
+            self._opt = (torch.zeros_like(m._flat_train), torch.zeros_like(m._flat_train))
+        em, ev = self._opt
+        for b, e in m.active_ranges(self.use_clip_loss, self.use_tim_loss):
+            off = b * 4
+            _lib.check(lib.mmhip_adamw(C.c_void_p(m._flat_train.data_ptr() + off), C.c_void_p(m._flat_grad.data_ptr() + off),
+                                       C.c_void_p(em.data_ptr() + off), C.c_void_p(ev.data_ptr() + off), e - b, lr, 0.9, 0.999, 1e-8,
+                                       weight_decay, step, 1.0 / self.world, 1, _lib.stream_ptr()), "adamw")
+
+    @staticmethod
+    def _unpack(batch):
+        """reference :438-447: [B,1,T] -> [B,T], [B,1,3,H,W] -> [B,3,H,W] (with the B == 1 guard)"""
+        ids, mask, px = batch["input_ids"], batch["attention_mask"], batch["pixel_values"]
+        if ids.dim() == 3:
+            ids, mask = ids.squeeze(1), mask.squeeze(1)
+        if px.dim() == 5:
+            px = px.squeeze(1)
+        return ids, mask, px
+
+    def train(self, dataloader, val_dataloader, epochs, loss_fn=None, lr=1e-5, weight_decay=0.00025, tim_loss_fn=None,
+              iadds_loss_fn=None, te_dataloader=None, model_path=None, val_filename=None, te_filename=None, class_weight=None,
+              log_every=50):
+        """reference :416-532.  `loss_fn` is accepted for signature parity; the class weights it would carry are passed
+        as `class_weight` (nn.CrossEntropyLoss(weight=w), run_mm_late.py:85)."""
+        import pandas as pd
+        if class_weight is None and loss_fn is not None and getattr(loss_fn, "weight", None) is not None:
+            class_weight = loss_fn.weight
+        res_val, res_te, step = [], [], 0
+        for epoch in range(epochs):
+            if mmdist.rank() == 0:
+                print("Epoch:", epoch + 1)
+            for it, batch in enumerate(dataloader):
+                ids, mask, px = self._unpack(batch)
+                step += 1
+                loss, ncorr = self.train_step(ids.to(self.device), mask.to(self.device), px, batch["labels"], class_weight, lr, weight_decay, step)
+                if log_every and it % log_every == 0 and mmdist.rank() == 0:     # the reference syncs every step (:496-498)
+                    n = ids.shape[0]
+                    print(f"Got {int(ncorr.item())} / {n} with accuracy {float(ncorr.item()) / n * 100:.2f} loss {loss[0].item():.4f}")
+            for loader, store, fname, tag in ((val_dataloader, res_val, val_filename, "val"), (te_dataloader, res_te, te_filename, "test")):
+                if loader is None:
+                    continue
+                r = self.eval(loader, class_weight=class_weight)
+                r["epoch"] = epoch
+                store.append(r)
+                if fname is not None and (epoch % 2 == 0 or epoch == epochs - 1) and mmdist.rank() == 0:
+                    pd.DataFrame(agg_metrics_val(store, metric_names, self.num_labels)).to_csv(fname, index=False)
+                    logger.info("%s saved!", fname)
+        if model_path is not None and mmdist.rank() == 0:
+            self.save_model(model_path)
+            logger.info("%s saved", model_path)
+
+    def eval(self, dataloader, loss_fn=None, tim_loss_fn=None, iadds_loss_fn=None, class_weight=None):
+        """reference :534-638: forward without dropout, same loss mix (ITM inputs re-sampled, :565-568), argmax."""
+        m, lib = self.model, _lib.lib()
+        if class_weight is None and loss_fn is not None and getattr(loss_fn, "weight", None) is not None:
+            class_weight = loss_fn.weight
+        m.eval()
+        ids_all, preds, labels, losses = [], [], [], []
+        w_cls, w_itc, w_itm = self.loss_weights()
+        cw = None if class_weight is None else class_weight.to(self.device, torch.float32).contiguous()
+        with torch.no_grad():
+            for batch in dataloader:
+                ids, mask, px = self._unpack(batch)
+                ids, mask = ids.to(self.device), mask.to(self.device)
+                tim = self.prepare_itm_inputs(ids, mask) if self.use_tim_loss else None
+                tim_ids, tim_mask, lbl_tim = tim if tim is not None else (None, None, None)
+                out_cls, _, _, _ = m._engine_forward(ids, mask, px, tim_ids, tim_mask)
+                onehot = batch["labels"].to(self.device, torch.int64).contiguous()
+                loss = torch.empty(4, device=self.device)
+                _lib.check(lib.mmhip_loss(m._handle, _lib.ptr(onehot), _lib.ptr(cw), _lib.ptr(lbl_tim), w_cls, w_itc, w_itm,
+                                          _lib.ptr(loss), None, _lib.stream_ptr()), "loss")
+                losses.append(loss[0:1].clone())
+                preds.append(out_cls.argmax(dim=1))
+                labels.append(onehot.argmax(dim=1))
+                if "data_id" in batch:
+                    ids_all.append(batch["data_id"])
+        return {"data_id": torch.cat(ids_all).cpu().numpy() if ids_all else np.zeros(0, dtype=np.int64),
+                "loss": float(torch.cat(losses).mean().item()) if losses else float("nan"),
+                "predictions": torch.cat(preds).cpu().numpy(), "labels": torch.cat(labels).cpu().numpy()}
