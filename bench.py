@@ -28,7 +28,8 @@ def cpu_baseline(seconds_budget=25.0):
     forward+backward of the same model on a bounded sample (B=8 posts of the same synthetic shape)."""
     import torch
     from oracle import mm_oracle as O
-    cores = os.cpu_count() or 1
+    # the box's CPU share, not the host's core count (a GPU box exposes 256 logical CPUs but grants about 16)
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     cfg = O.OracleConfig(num_labels=2)
     P = {k: v.requires_grad_(O.trainable(k)) for k, v in O.make_params(cfg, 0).items()}

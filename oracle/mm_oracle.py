@@ -373,7 +373,7 @@ def mm_forward(P: Dict[str, Tensor], ids: Tensor, mask: Tensor, pixels: Tensor, 
 # --------------------------------------------------------------------------------------
 def clip_loss(sim: Tensor) -> Tensor:
     """reference models/utils.py:225-231."""
-    tgt = torch.arange(len(sim))
+    tgt = torch.arange(len(sim), device=sim.device)
     return (F.cross_entropy(sim, tgt) + F.cross_entropy(sim.t(), tgt)) / 2.0
 
 
@@ -381,12 +381,12 @@ def cls_loss(out: Tensor, onehot: Tensor, weight: Optional[Tensor]) -> Tensor:
     """nn.CrossEntropyLoss(weight=w)(out, float one-hot): -(1/B) sum_b sum_c w_c y_bc logsoftmax(out)_bc
     (models/run_mm_late.py:85 with models/mm_late.py:471; SURVEY §8c known answer (1))."""
     lsm = torch.log_softmax(out, dim=1)
-    w = torch.ones(out.shape[1]) if weight is None else weight
-    return -(onehot.to(out.dtype) * lsm * w).sum() / out.shape[0]
+    w = torch.ones(out.shape[1], device=out.device) if weight is None else weight.to(out.device)
+    return -(onehot.to(out.device, out.dtype) * lsm * w).sum() / out.shape[0]
 
 
 def itm_loss(out_tim: Tensor, lbl: Tensor) -> Tensor:
-    return F.cross_entropy(out_tim, lbl)
+    return F.cross_entropy(out_tim, lbl.to(out_tim.device))
 
 
 def mix_loss(out_cls, onehot, weight, logits_per_text, out_tim, lbl_tim,
