@@ -100,7 +100,8 @@ int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, 
     if (p_drop > 0.f) { a.drop = drop_of(p_drop, seed, stream_id); a.flags |= GEMM_DROPOUT; }
     if (residual) { a.residual = residual; a.ldres = ldres; a.flags |= GEMM_RESIDUAL; }
     if (out_f32) a.flags |= GEMM_OUT_F32;
-    a.force_slow = force_slow;
+    a.force_slow = force_slow & 1;
+    a.tile = force_slow >> 4;      // bits 4.. select the tile variant (test / tuning hook)
     CHECK_HIP(launch_gemm_nt(a, dtype, (hipStream_t)stream));
     return 0;
 }

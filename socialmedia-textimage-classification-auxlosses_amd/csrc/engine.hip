@@ -52,7 +52,7 @@ struct mmhip_engine {
     std::vector<TextAct> tact;
     size_t ids_all, mask_all, pos_ids, maskbias, x0, xhat_emb, rstd_emb;
     size_t v_patches, v_pe, v_x, v_ln, v_qkv, v_ctx, v_h, v_out;                             // ViT ping-pong
-    size_t g_dx, g_dx2, g_dpre, g_ddrop, g_dqkv, g_dctx, g_du;                               // backward temporaries
+    size_t g_dx, g_dx2, g_dpre, g_ddrop, g_dpre1, g_ddrop1, g_dqkv, g_dctx, g_du;                               // backward temporaries
     // heads (fp32) ----------------------------------------------------------------------
     size_t h_vpool, h_tpool, h_txt_e, h_img_e, h_txt_n, h_img_n, h_txt_inv, h_img_inv, h_logits;
     size_t h_q, h_qk, h_prob, h_xbar, h_z, h_feats, h_featd, h_out_cls, h_out_tim;
@@ -231,7 +231,7 @@ void build_workspace(mmhip_engine& e) {
     e.v_patches = w.take(Bm * (P - 1) * 3 * c.patch * c.patch * 2); e.v_pe = w.take(Bm * (P - 1) * H * 2);
     e.v_x = w.take(Mv * H * 2); e.v_ln = w.take(Mv * H * 2); e.v_qkv = w.take(Mv * 3 * H * 2); e.v_ctx = w.take(Mv * H * 2);
     e.v_h = w.take(Mv * I * 2); e.v_out = w.take(Mv * H * 2);
-    e.g_dx = w.take(Mt * H * 2); e.g_dx2 = w.take(Mt * H * 2); e.g_dpre = w.take(Mt * H * 2); e.g_ddrop = w.take(Mt * H * 2);
+    e.g_dx = w.take(Mt * H * 2); e.g_dx2 = w.take(Mt * H * 2); e.g_dpre = w.take(Mt * H * 2); e.g_ddrop = w.take(Mt * H * 2); e.g_dpre1 = w.take(Mt * H * 2); e.g_ddrop1 = w.take(Mt * H * 2);
     e.g_dqkv = w.take(Mt * 3 * H * 2); e.g_dctx = w.take(Mt * H * 2); e.g_du = w.take(Mt * I * 2);
     auto f = [&](size_t n) { return w.take(n * 4); };
     e.h_vpool = f(Bm * H); e.h_tpool = f(Bm * H); e.h_txt_e = f(Bm * E); e.h_img_e = f(Bm * E); e.h_txt_n = f(Bm * E); e.h_img_n = f(Bm * E);
@@ -293,6 +293,7 @@ int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
 }
 SmallGemmArgs small(const void* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, int act = ACT_NONE, int acc = 0) {
     SmallGemmArgs a;
+    memset(&a, 0, sizeof(a));
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.act = act; a.accumulate = acc;
     return a;
 }
@@ -519,44 +520,43 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     const TextAct& a = e.tact[l];
     const char* x_in = l ? e.ws + e.tact[l - 1].out : e.ws + e.x0;
     const bool tr = e.train_mode;
-    char *dx = e.ws + e.g_dx, *dpre = e.ws + e.g_dpre, *ddrop = e.ws + e.g_ddrop, *du = e.ws + e.g_du, *dx2 = e.ws + e.g_dx2;
+    char *dx = e.ws + e.g_dx, *dpre2 = e.ws + e.g_dpre, *ddrop2 = e.ws + e.g_ddrop, *dpre1 = e.ws + e.g_dpre1, *ddrop1 = e.ws + e.g_ddrop1;
+    char *du = e.ws + e.g_du, *dx2 = e.ws + e.g_dx2, *dctx = e.ws + e.g_dctx, *dqkv = e.ws + e.g_dqkv;
     // ---- x' = LN2(pre2), pre2 = drop(fc2(h)) + a1
-    LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mt, H};
+    LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mt, H};
     CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
     const DropCfg d_ffn = make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr);
-    const char* df = dpre;
-    if (d_ffn.thresh16) { CHECK_HIP(launch_dropout16(dpre, ddrop, (size_t)Mt * H, d_ffn, dt, s)); df = ddrop; }
-    // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre
+    const char* df = dpre2;
+    if (d_ffn.thresh16) { CHECK_HIP(launch_dropout16(dpre2, ddrop2, (size_t)Mt * H, d_ffn, dt, s)); df = ddrop2; }
+    // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
     { G g(df, H, e.ws + w.fc2T, H, du, I, Mt, I, H); g.mul_gelu_grad(e.ws + a.u, I); if (int r = run_gemm(e, g, s)) return r; }
-    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mt, H, I); g.residual(dpre, H); if (int r = run_gemm(e, g, s)) return r; }
+    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mt, H, I); g.residual(dpre2, H); if (int r = run_gemm(e, g, s)) return r; }
     CHECK_HIP(launch_colsum(df, Mt, H, H, Gd + o.fc2_b, dt, s));
     CHECK_HIP(launch_colsum(du, Mt, I, I, Gd + o.fc1_b, dt, s));
-    GemmTNProblem pr[4];
-    memset(pr, 0, sizeof(pr));
-    pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mt, H, I, H, I, I, 0};          // dW2[H,I] = df^T h
-    pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mt, I, H, I, H, H, 0};         // dW1[I,H] = du^T a1
-    CHECK_HIP(launch_gemm_tn(pr, 2, 0, dt, 0, s));
-    // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1; reuse dpre for d_pre1 afterwards)
-    LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mt, H};
+    // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
+    LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mt, H};
     CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
-    const char* dout = dpre;
-    if (d_ao.thresh16) { CHECK_HIP(launch_dropout16(dpre, ddrop, (size_t)Mt * H, d_ao, dt, s)); dout = ddrop; }
-    char* dctx = e.ws + e.g_dctx;
+    const char* dout = dpre1;
+    if (d_ao.thresh16) { CHECK_HIP(launch_dropout16(dpre1, ddrop1, (size_t)Mt * H, d_ao, dt, s)); dout = ddrop1; }
     { G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H); if (int r = run_gemm(e, g, s)) return r; }
     CHECK_HIP(launch_colsum(dout, Mt, H, H, Gd + o.ao_b, dt, s));
     AttnBwdArgs ab;
     memset(&ab, 0, sizeof(ab));
     ab.qkv = e.ws + a.qkv; ab.maskbias = e.wsp<float>(e.maskbias); ab.ctx = e.ws + a.ctx; ab.dctx = dctx; ab.lse = e.wsp<float>(a.lse);
-    ab.dqkv = e.ws + e.g_dqkv; ab.posts = Bt; ab.S = T; ab.heads = c.heads; ab.ld_qkv = 3 * H; ab.ld_ctx = H; ab.hidden = H;
+    ab.dqkv = dqkv; ab.posts = Bt; ab.S = T; ab.heads = c.heads; ab.ld_qkv = 3 * H; ab.ld_ctx = H; ab.hidden = H;
     ab.scale = 1.0f / sqrtf((float)(H / c.heads));
     ab.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
     CHECK_HIP(launch_attn_bwd(ab, dt, s));
-    { G g(e.ws + e.g_dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.residual(dpre, H); if (int r = run_gemm(e, g, s)) return r; }
-    CHECK_HIP(launch_colsum(e.ws + e.g_dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, s));
-    pr[0] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mt, H, H, H, H, H, 0};              // dWo = dout^T ctx
-    pr[1] = GemmTNProblem{e.ws + e.g_dqkv, x_in, Gd + o.qkv_w, Mt, 3 * H, H, 3 * H, H, H, 0};  // dWqkv = dqkv^T x_in
-    CHECK_HIP(launch_gemm_tn(pr, 2, 0, dt, 0, s));
+    { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.residual(dpre1, H); if (int r = run_gemm(e, g, s)) return r; }
+    CHECK_HIP(launch_colsum(dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, s));
+    // ---- all four weight gradients of the layer in one grouped launch (432 tiles of 128x128, no split-K, plain stores)
+    GemmTNProblem pr[4];
+    pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mt, H, I, H, I, I, 0};          // dW2[H,I]   = df^T h
+    pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mt, I, H, I, H, H, 0};         // dW1[I,H]   = du^T a1
+    pr[2] = GemmTNProblem{dqkv, x_in, Gd + o.qkv_w, Mt, 3 * H, H, 3 * H, H, H, 0};      // dWqkv[3H,H] = dqkv^T x_in
+    pr[3] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mt, H, H, H, H, H, 0};       // dWo[H,H]   = dout^T ctx
+    CHECK_HIP(launch_gemm_tn(pr, 4, 0, dt, 0, s));
     return 0;
 }
 

@@ -8,20 +8,39 @@
 // Operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered.
 // LDS images are XOR-swizzled on the *source* address (the LDS-DMA destination is lane-linear) and on the read.
 #include "mmhip_common.h"
+#include <cstdlib>
 #include "mmhip_kernels.h"
 
 namespace mmhip {
 
 // ------------------------------------------------------------------------------------------------ NT
-static constexpr int BM = 128, BN = 128, BK = 64;
-static constexpr int NT_LDS_BYTES = 4 * 64 * 68 * 4;   // epilogue staging (69632) >= 2 x (16K + 16K) operand buffers
+// Tile variants (BM x BN, waves WM x WN, each wave (BM/WM) x (BN/WN)):
+//   128x128, 2x2 (256 thr, 64 KB operand LDS, 2 blocks/CU)   64 FLOP per operand byte staged
+//   256x128, 4x2 (512 thr, 96 KB, 1 block/CU)                85
+//   256x256, 2x4 (512 thr, 128 KB, 1 block/CU)               128
+// At the full MFMA rate a CU consumes 2 * 9.8 TFLOP/s; the L1/TA path delivers ~64 B/clk, so 128x128 is fill-bound.
+static constexpr int BK = 64;
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
+template <int BM, int BN, int WM, int WN>
+struct NTCfg {
+    static constexpr int NW = WM * WN, NTHR = NW * 64;
+    static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    static constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;        // LDS-DMA wave-instructions per wave per stage
+    static constexpr int EP_LD = TN + 4;                            // fp32 staging row stride (floats)
+    static constexpr int EP_WAVE = 32 * EP_LD * 4;                  // 32-row chunk per wave
+    static constexpr int LDS = (2 * STAGE > NW * EP_WAVE) ? 2 * STAGE : NW * EP_WAVE;
+    static constexpr int BLOCKS_PER_CU = (LDS <= 80 * 1024) ? 2 : 1;
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, (NTCfg<BM, BN, WM, WN>::BLOCKS_PER_CU * WM * WN) / 4)
+void gemm_nt_kernel(GemmNTArgs a) {
+    using C = NTCfg<BM, BN, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WN, wn = w % WN;
     const int tilesN = a.N / BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (id / tilesN) * BM, n0 = (id % tilesN) * BN;
@@ -30,30 +49,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
 
     // ---- LDS-DMA staging: one wave instruction = 8 tile rows x 128 B; lane -> (row, 16-B slot)
     const int lrow = lane >> 3, slot = lane & 7;
-    const T* asrc[4];
-    const T* bsrc[4];
+    const T* asrc[C::AI];
+    const T* bsrc[C::BI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int row = (w * 4 + i) * 8 + lrow;
-        int chunk = slot ^ (row & 7);                       // source-side swizzle
-        int gm = min(m0 + row, a.M - 1);                    // rows past M read a valid row, never stored
+    for (int i = 0; i < C::AI; ++i) {
+        const int row = (w * C::AI + i) * 8 + lrow;
+        const int chunk = slot ^ (row & 7);                 // source-side swizzle
+        const int gm = min(m0 + row, a.M - 1);              // rows past M read a valid row, never stored
         asrc[i] = A + (size_t)gm * a.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < C::BI; ++i) {
+        const int row = (w * C::BI + i) * 8 + lrow;
+        const int chunk = slot ^ (row & 7);
         bsrc[i] = B + (size_t)(n0 + row) * a.ldb + chunk * 8;
     }
     auto stage = [&](int buf, int k0) {
-        char* base = smem + buf * 32768 + w * 4096;
+        char* base = smem + buf * C::STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds(MM_GLB(asrc[i] + k0), MM_LDS(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(MM_GLB(bsrc[i] + k0), MM_LDS(base + 16384 + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < C::AI; ++i)
+            __builtin_amdgcn_global_load_lds(MM_GLB(asrc[i] + k0), MM_LDS(base + (w * C::AI + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C::BI; ++i)
+            __builtin_amdgcn_global_load_lds(MM_GLB(bsrc[i] + k0), MM_LDS(base + C::A_BYTES + (w * C::BI + i) * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[C::FM][C::FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < C::FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets: row = base16 + (lane&15); 16-B chunk = kk*4 + (lane>>4), XOR (row&7) == (lane&7)
     const int frag_row = (lane & 15) * 128;
@@ -64,36 +89,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) stage(cur ^ 1, (t + 1) * BK);
-        const char* As = smem + cur * 32768 + wm * (64 * 128) + frag_row;
-        const char* Bs = smem + cur * 32768 + 16384 + wn * (64 * 128) + frag_row;
+        const char* As = smem + cur * C::STAGE + wm * (C::TM * 128) + frag_row;
+        const char* Bs = smem + cur * C::STAGE + C::A_BYTES + wn * (C::TN * 128) + frag_row;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int coff = ((kk * 4 + kc) ^ sw) << 4;
-            v8 af[4], bf[4];
+            v8 af[C::FM], bf[C::FN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = lds_read8<T>(As, i * (16 * 128) + coff);
+            for (int j = 0; j < C::FN; ++j) bf[j] = lds_read8<T>(Bs, j * (16 * 128) + coff);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = lds_read8<T>(Bs, j * (16 * 128) + coff);
+            for (int i = 0; i < C::FM; ++i) af[i] = lds_read8<T>(As, i * (16 * 128) + coff);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < C::FM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < C::FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
         }
         __syncthreads();
     }
 
-    // ---- epilogue: accumulators -> wave-private fp32 LDS tile -> row-contiguous 16-B global stores
-    float* ep = reinterpret_cast<float*>(smem + w * (64 * 68 * 4));
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ep[(i * 16 + (lane >> 4) * 4 + r) * 68 + j * 16 + (lane & 15)] = acc[i][j][r];
-    __syncthreads();
+    // ---- epilogue: accumulators -> wave-private fp32 LDS chunk (32 rows) -> row-contiguous 16-B global stores
+    float* ep = reinterpret_cast<float*>(smem + w * C::EP_WAVE);
     const int fl = a.flags;
-    const int c8 = (lane & 7) * 8;
-    const int n = n0 + wn * 64 + c8;
+    constexpr int LPR = C::TN / 8;                 // lanes per row
+    constexpr int RPP = 64 / LPR;                  // rows per pass
+    const int c8 = (lane % LPR) * 8;
+    const int n = n0 + wn * C::TN + c8;
     float bias8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
@@ -103,57 +123,68 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int row = p * 8 + (lane >> 3);
-        const int m = m0 + wm * 64 + row;
-        if (m >= a.M) continue;
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + row * 68 + c8), v1 = *reinterpret_cast<const f32x4*>(ep + row * 68 + c8 + 4);
-        float v[8];
+    for (int ch = 0; ch < C::TM / 32; ++ch) {
+        if (ch) __syncthreads();                   // previous chunk fully read before it is overwritten
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
-        if (fl & GEMM_AUX_PRE) {
-            v8 o;
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = from_f<T>(v[e]);
-            *reinterpret_cast<v8*>((T*)a.aux + (size_t)m * a.ldaux + n) = o;
-        }
-        if (fl & GEMM_GELU) {
+            for (int j = 0; j < C::FN; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = mm_gelu(v[e]);
-        }
-        if (fl & GEMM_TANH) {
+                for (int r = 0; r < 4; ++r) ep[(ii * 16 + (lane >> 4) * 4 + r) * C::EP_LD + j * 16 + (lane & 15)] = acc[ch * 2 + ii][j][r];
+        __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
-        }
-        if (fl & GEMM_MUL_GELU_GRAD) {
-            v8 u = *reinterpret_cast<const v8*>((const T*)a.mul_in + (size_t)m * a.ldmul + n);
+        for (int p = 0; p < 32 / RPP; ++p) {
+            const int row = p * RPP + lane / LPR;
+            const int m = m0 + wm * C::TM + ch * 32 + row;
+            if (m >= a.M) continue;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + row * C::EP_LD + c8), v1 = *reinterpret_cast<const f32x4*>(ep + row * C::EP_LD + c8 + 4);
+            float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= mm_gelu_grad(to_f<T>(u[e]));
-        }
-        if ((fl & GEMM_DROPOUT) && a.drop.thresh16) {
-            const uint32_t e0 = (uint32_t)m * (uint32_t)a.N + (uint32_t)n;
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
+            if (fl & GEMM_AUX_PRE) {
+                v8 o;
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                bool k0, k1;
-                mm_keep2(e0 + e, a.drop, k0, k1);
-                v[e] = k0 ? v[e] * a.drop.keep_scale : 0.f;
-                v[e + 1] = k1 ? v[e + 1] * a.drop.keep_scale : 0.f;
+                for (int e = 0; e < 8; ++e) o[e] = from_f<T>(v[e]);
+                *reinterpret_cast<v8*>((T*)a.aux + (size_t)m * a.ldaux + n) = o;
             }
-        }
-        if (fl & GEMM_RESIDUAL) {
-            v8 r = *reinterpret_cast<const v8*>((const T*)a.residual + (size_t)m * a.ldres + n);
+            if (fl & GEMM_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += to_f<T>(r[e]);
-        }
-        if (fl & GEMM_OUT_F32) {
-            float* c = (float*)a.C + (size_t)m * a.ldc + n;
-            *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        } else {
-            v8 o;
+                for (int e = 0; e < 8; ++e) v[e] = mm_gelu(v[e]);
+            }
+            if (fl & GEMM_TANH) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = from_f<T>(v[e]);
-            *reinterpret_cast<v8*>((T*)a.C + (size_t)m * a.ldc + n) = o;
+                for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+            }
+            if (fl & GEMM_MUL_GELU_GRAD) {
+                v8 u = *reinterpret_cast<const v8*>((const T*)a.mul_in + (size_t)m * a.ldmul + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= mm_gelu_grad(to_f<T>(u[e]));
+            }
+            if ((fl & GEMM_DROPOUT) && a.drop.thresh16) {
+                const uint32_t e0 = (uint32_t)m * (uint32_t)a.N + (uint32_t)n;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    bool k0, k1;
+                    mm_keep2(e0 + e, a.drop, k0, k1);
+                    v[e] = k0 ? v[e] * a.drop.keep_scale : 0.f;
+                    v[e + 1] = k1 ? v[e + 1] * a.drop.keep_scale : 0.f;
+                }
+            }
+            if (fl & GEMM_RESIDUAL) {
+                v8 r = *reinterpret_cast<const v8*>((const T*)a.residual + (size_t)m * a.ldres + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += to_f<T>(r[e]);
+            }
+            if (fl & GEMM_OUT_F32) {
+                float* c = (float*)a.C + (size_t)m * a.ldc + n;
+                *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+                v8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = from_f<T>(v[e]);
+                *reinterpret_cast<v8*>((T*)a.C + (size_t)m * a.ldc + n) = o;
+            }
         }
     }
 }
@@ -254,52 +285,60 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNGroup g) {
             }
 }
 
-// ------------------------------------------------------------------------------------------------ simple fallbacks
-// Small / ragged problems (heads with 2-4 outputs, B posts as the row count): plain fp32-accumulate kernels.
-// NT: out[m][n] = act(sum_k A[m][k] W[n][k] + b[n]); one wave per output column n, lanes stride over k.
+// ------------------------------------------------------------------------------------------------ small fp32 GEMM
+// Heads (B = 64..128 posts as the row count; 2-4 labels): exact fp32 on the matrix cores.
+//   out[m][n] (+)= act( sum_k A(m,k) * B(k,n) + bias[n] ),   A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn]
+// v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, bit-exact fp32): lane l holds A[l&31][k = l>>5], B[k = l>>5][l&31].
+// A workgroup owns one 32x32 output tile; its 4 waves split K in 8-wide slices (wave w takes slices w, w+4, ...),
+// each lane fetching 4 consecutive k per operand (one 16-byte load when that operand is k-contiguous), and the four
+// partial tiles are summed through LDS.  K order inside a slice is permuted identically for A and B.
 template <typename TA>
-__global__ __launch_bounds__(256) void small_nt_kernel(SmallGemmArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= a.N) return;
-    const float* W = a.W + (size_t)n * a.ldw;
-    const float bn = a.bias ? a.bias[n] : 0.f;
-    for (int m = 0; m < a.M; ++m) {
-        const TA* x = (const TA*)a.A + (size_t)m * a.lda;
-        float s = 0.f;
-        for (int k = lane; k < a.K; k += 64) s += (float)x[k] * W[k];
-        s = wave_sum(s);
-        if (lane == 0) {
-            s += bn;
-            if (a.act == ACT_TANH) s = tanhf(s);
-            else if (a.act == ACT_RELU) s = fmaxf(s, 0.f);
-            float* o = a.out + (size_t)m * a.ldo + n;
-            *o = a.accumulate ? *o + s : s;
+__global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemmArgs a) {
+    __shared__ float red[4][32][33];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int m = min(m0 + r, a.M - 1), n = min(n0 + r, a.N - 1);       // out-of-range rows/cols compute garbage, never stored
+    const TA* Ap = (const TA*)a.A + (size_t)m * a.sam;
+    const float* Bp = a.W + (size_t)n * a.sbn;
+    f32x16 acc = f32x16{};
+    for (int k0 = w * 8 + h * 4; k0 < a.K; k0 += 32) {
+        float av[4], bv[4];
+        if (a.sak == 1 && k0 + 3 < a.K && sizeof(TA) == 4 && ((((uintptr_t)(Ap + k0)) & 15) == 0)) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(Ap + k0);
+            av[0] = t[0]; av[1] = t[1]; av[2] = t[2]; av[3] = t[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = (k0 + e < a.K) ? (float)Ap[(size_t)(k0 + e) * a.sak] : 0.f;
+        }
+        if (a.sbk == 1 && k0 + 3 < a.K && ((((uintptr_t)(Bp + k0)) & 15) == 0)) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(Bp + k0);
+            bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (k0 + e < a.K) ? Bp[(size_t)(k0 + e) * a.sbk] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+    }
+    // D: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) red[w][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] = acc[reg];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int row = i >> 5, col = i & 31;
+        const int gm = m0 + row, gn = n0 + col;
+        if (gm < a.M && gn < a.N) {
+            float v = red[0][row][col] + red[1][row][col] + red[2][row][col] + red[3][row][col];
+            if (a.bias) v += a.bias[gn];
+            if (a.act == ACT_TANH) v = tanhf(v);
+            else if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+            float* o = a.out + (size_t)gm * a.ldo + gn;
+            *o = a.accumulate ? *o + v : v;
         }
     }
 }
-// NN: out[m][i] = sum_o A[m][o] W[o][i]   (thread per (m, i); W rows read coalesced)
-__global__ __launch_bounds__(256) void small_nn_kernel(SmallGemmArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
-    if (i >= a.N) return;
-    const float* x = (const float*)a.A + (size_t)m * a.lda;
-    float s = 0.f;
-    for (int o = 0; o < a.K; ++o) s += x[o] * a.W[(size_t)o * a.ldw + i];
-    float* dst = a.out + (size_t)m * a.ldo + i;
-    *dst = a.accumulate ? *dst + s : s;
-}
-// TN: out[n][c] = sum_m A[m][n] B[m][c]    (thread per (n, c); B rows read coalesced; TB = float or 16-bit)
-template <typename TB>
-__global__ __launch_bounds__(256) void small_tn_kernel(SmallGemmArgs a) {
-    const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-    if (c >= a.N) return;
-    const float* A = (const float*)a.A;
-    const TB* B = (const TB*)a.W;
-    float s = 0.f;
-    for (int m = 0; m < a.M; ++m) s += A[(size_t)m * a.lda + n] * (float)B[(size_t)m * a.ldw + c];
-    float* dst = a.out + (size_t)n * a.ldo + c;
-    *dst = a.accumulate ? *dst + s : s;
-}
+
 // generic slow NT/TN for 16-bit operands of any shape (used when the MFMA kernels' shape rules do not hold)
 template <typename T>
 __global__ __launch_bounds__(256) void slow_nt_kernel(GemmNTArgs a) {
@@ -335,25 +374,58 @@ __global__ __launch_bounds__(256) void slow_tn_kernel(GemmTNProblem P, int accum
 // ------------------------------------------------------------------------------------------------ launchers
 static bool nt_fast_ok(const GemmNTArgs& a) {
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    return a.N % BN == 0 && a.K % BK == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&
+    return a.N % 128 == 0 && a.K % BK == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&
            (!(a.flags & GEMM_RESIDUAL) || (a.ldres % 8 == 0 && al(a.residual))) &&
            (!(a.flags & GEMM_AUX_PRE) || (a.ldaux % 8 == 0 && al(a.aux))) &&
            (!(a.flags & GEMM_MUL_GELU_GRAD) || (a.ldmul % 8 == 0 && al(a.mul_in))) &&
            (!(a.flags & GEMM_BIAS) || al(a.bias)) && a.M > 0;
 }
 
+template <typename T, int BM, int BN, int WM, int WN>
+static void launch_nt_t(const GemmNTArgs& a, hipStream_t s) {
+    using C = NTCfg<BM, BN, WM, WN>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
+    const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(C::NTHR), C::LDS, s, a);
+}
+
+// tile choice: explicit (a.tile: 1 = 128x128, 2 = 256x128, 3 = 256x256) or by a wave-quantisation x intensity score
+static int choose_nt_tile(const GemmNTArgs& a) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("MMHIP_NT_TILE"); env = e ? atoi(e) : 0; }
+    int t = a.tile ? a.tile : env;
+    if (t == 3 && a.N % 256) t = 2;
+    if (t >= 1 && t <= 3) return t;
+    const double eff[4] = {0, 0.62, 0.80, 1.0};
+    const int bm[4] = {0, 128, 256, 256}, bn[4] = {0, 128, 128, 256}, slots[4] = {0, 512, 256, 256};
+    int best = 1;
+    double best_score = -1;
+    for (int c = 1; c <= 3; ++c) {
+        if (a.N % bn[c]) continue;
+        const long tiles = (long)((a.M + bm[c] - 1) / bm[c]) * (a.N / bn[c]);
+        const long waves = (tiles + slots[c] - 1) / slots[c];
+        const double useful = (double)a.M * a.N / ((double)waves * slots[c] * bm[c] * bn[c]);
+        const double score = useful * eff[c];
+        if (score > best_score) { best_score = score; best = c; }
+    }
+    return best;
+}
+
+template <typename T>
+static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
+    switch (choose_nt_tile(a)) {
+        case 3: launch_nt_t<T, 256, 256, 2, 4>(a, s); break;
+        case 2: launch_nt_t<T, 256, 128, 4, 2>(a, s); break;
+        default: launch_nt_t<T, 128, 128, 2, 2>(a, s); break;
+    }
+}
+
 hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if (nt_fast_ok(a) && !a.force_slow) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-            attr_done = true;
-        }
-        const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-        if (dtype == DT_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, dim3(grid), dim3(256), NT_LDS_BYTES, s, a);
-        else hipLaunchKernelGGL(gemm_nt_kernel<f16_t>, dim3(grid), dim3(256), NT_LDS_BYTES, s, a);
+        if (dtype == DT_BF16) launch_nt_d<bf16_t>(a, s);
+        else launch_nt_d<f16_t>(a, s);
     } else {
         dim3 grid((a.N + 255) / 256, a.M);
         if (dtype == DT_BF16) hipLaunchKernelGGL(slow_nt_kernel<bf16_t>, grid, dim3(256), 0, s, a);
@@ -399,26 +471,33 @@ hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate,
     return hipGetLastError();
 }
 
-hipError_t launch_small_nt(const SmallGemmArgs& a, int a_dtype, hipStream_t s) {
+hipError_t launch_small_gemm(const SmallGemmArgs& a, int a_dtype, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
-    dim3 grid((a.N + 3) / 4);
-    if (a_dtype == DT_F32) hipLaunchKernelGGL(small_nt_kernel<float>, grid, dim3(256), 0, s, a);
-    else if (a_dtype == DT_BF16) hipLaunchKernelGGL(small_nt_kernel<bf16_t>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(small_nt_kernel<f16_t>, grid, dim3(256), 0, s, a);
+    dim3 grid((a.N + 31) / 32, (a.M + 31) / 32);
+    if (a_dtype == DT_F32) hipLaunchKernelGGL(small_gemm_kernel<float>, grid, dim3(256), 0, s, a);
+    else if (a_dtype == DT_BF16) hipLaunchKernelGGL(small_gemm_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(small_gemm_kernel<f16_t>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_small_nn(const SmallGemmArgs& a, hipStream_t s) {
-    if (a.M <= 0 || a.N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(small_nn_kernel, dim3((a.N + 255) / 256, a.M), dim3(256), 0, s, a);
-    return hipGetLastError();
+// out[M,N] = act(A[M,K] W[N,K]^T + b)
+hipError_t launch_small_nt(const SmallGemmArgs& a0, int a_dtype, hipStream_t s) {
+    SmallGemmArgs a = a0;
+    a.sam = a.lda; a.sak = 1; a.sbk = 1; a.sbn = a.ldw;
+    return launch_small_gemm(a, a_dtype, s);
 }
-hipError_t launch_small_tn(const SmallGemmArgs& a, int b_dtype, int n_rows, hipStream_t s) {
-    if (n_rows <= 0 || a.N <= 0) return hipSuccess;
-    dim3 grid((a.N + 255) / 256, n_rows);
-    if (b_dtype == DT_F32) hipLaunchKernelGGL(small_tn_kernel<float>, grid, dim3(256), 0, s, a);
-    else if (b_dtype == DT_BF16) hipLaunchKernelGGL(small_tn_kernel<bf16_t>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(small_tn_kernel<f16_t>, grid, dim3(256), 0, s, a);
-    return hipGetLastError();
+// out[M,N] = A[M,K] W[K,N]
+hipError_t launch_small_nn(const SmallGemmArgs& a0, hipStream_t s) {
+    SmallGemmArgs a = a0;
+    a.sam = a.lda; a.sak = 1; a.sbk = a.ldw; a.sbn = 1;
+    return launch_small_gemm(a, DT_F32, s);
+}
+// out[n_rows,N] = A[M,n_rows]^T B[M,N]   (a.M = reduction length, a.W = B fp32)
+hipError_t launch_small_tn(const SmallGemmArgs& a0, int b_dtype, int n_rows, hipStream_t s) {
+    if (b_dtype != DT_F32) return hipErrorInvalidValue;
+    SmallGemmArgs a = a0;
+    a.K = a0.M; a.M = n_rows;
+    a.sam = 1; a.sak = a0.lda; a.sbk = a0.ldw; a.sbn = 1;
+    return launch_small_gemm(a, DT_F32, s);
 }
 
 }  // namespace mmhip

@@ -25,6 +25,7 @@ struct GemmNTArgs {
     int M, N, K, lda, ldb, ldc, ldaux, ldres, ldmul;
     int flags;
     int force_slow;
+    int tile;                 // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256
     DropCfg drop;
 };
 static constexpr int GEMM_TN_MAX_GROUP = 8;
@@ -39,6 +40,7 @@ struct GemmTNGroup {
 struct SmallGemmArgs {
     const void* A; const float* W; const float* bias; float* out;
     int M, N, K, lda, ldw, ldo, act, accumulate;
+    int sam, sak, sbk, sbn;   // element strides of A(m,k) and B(k,n); filled by the launch_small_* wrappers
 };
 hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s);
 hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s);

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) (+ dres), g = dy * gamma; dgamma += dy * xhat, dbeta += dy.
 // A block walks ROWS_PER_BLOCK rows (wave-strided), keeps the column partials in registers, reduces the 4 waves
 // through LDS and issues one atomic per column per block.
-static constexpr int LN_ROWS_PER_BLOCK = 64;
+static constexpr int LN_ROWS_PER_BLOCK = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
     __shared__ float red[2][4][1024];
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const T* __restrict__
 
 // ------------------------------------------------------------------------------------------------ column sums
 // out[c] += sum_r x[r][c]   (bias gradients).  grid (ceil(cols/256), row chunks); lanes own 4 columns each.
-static constexpr int COLSUM_ROWS = 256;
+static constexpr int COLSUM_ROWS = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int cols, int ld, float* __restrict__ out) {
     __shared__ float red[4][256];
