@@ -21,7 +21,10 @@ namespace mmhip {
 // At the full MFMA rate a CU consumes 2 * 9.8 TFLOP/s; the L1/TA path delivers ~64 B/clk, so 128x128 is fill-bound.
 static constexpr int BK = 64;
 
-template <int BM, int BN, int WM, int WN>
+// counted wait: at most N of this wave's vector-memory operations (LDS-DMA loads here) may still be in flight
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, int NS>
 struct NTCfg {
     static constexpr int NW = WM * WN, NTHR = NW * 64;
     static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -29,14 +32,15 @@ struct NTCfg {
     static constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;        // LDS-DMA wave-instructions per wave per stage
     static constexpr int EP_LD = TN + 4;                            // fp32 staging row stride (floats)
     static constexpr int EP_WAVE = 32 * EP_LD * 4;                  // 32-row chunk per wave
-    static constexpr int LDS = (2 * STAGE > NW * EP_WAVE) ? 2 * STAGE : NW * EP_WAVE;
+    static constexpr int LDS = (NS * STAGE > NW * EP_WAVE) ? NS * STAGE : NW * EP_WAVE;
     static constexpr int BLOCKS_PER_CU = (LDS <= 80 * 1024) ? 2 : 1;
+    static constexpr int LPS = AI + BI;                             // LDS-DMA instructions per wave per stage
 };
 
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, (NTCfg<BM, BN, WM, WN>::BLOCKS_PER_CU * WM * WN) / 4)
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64, (NTCfg<BM, BN, WM, WN, NS>::BLOCKS_PER_CU * WM * WN) / 4)
 void gemm_nt_kernel(GemmNTArgs a) {
-    using C = NTCfg<BM, BN, WM, WN>;
+    using C = NTCfg<BM, BN, WM, WN, NS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -84,13 +88,9 @@ void gemm_nt_kernel(GemmNTArgs a) {
     const int frag_row = (lane & 15) * 128;
     const int sw = lane & 7, kc = lane >> 4;
     const int nk = a.K / BK;
-    stage(0, 0);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) stage(cur ^ 1, (t + 1) * BK);
-        const char* As = smem + cur * C::STAGE + wm * (C::TM * 128) + frag_row;
-        const char* Bs = smem + cur * C::STAGE + C::A_BYTES + wn * (C::TN * 128) + frag_row;
+    auto compute = [&](int buf) {
+        const char* As = smem + buf * C::STAGE + wm * (C::TM * 128) + frag_row;
+        const char* Bs = smem + buf * C::STAGE + C::A_BYTES + wn * (C::TN * 128) + frag_row;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int coff = ((kk * 4 + kc) ^ sw) << 4;
@@ -103,6 +103,36 @@ void gemm_nt_kernel(GemmNTArgs a) {
             for (int i = 0; i < C::FM; ++i)
 #pragma unroll
                 for (int j = 0; j < C::FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+        }
+    };
+    if constexpr (NS == 2) {
+        // two buffers, one tile of prefetch; __syncthreads drains the LDS-DMA queue (vmcnt(0)) at every step
+        stage(0, 0);
+        __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nk) stage(cur ^ 1, (t + 1) * BK);
+            compute(cur);
+            __syncthreads();
+        }
+    } else {
+        // NS-deep ring, NS-1 tiles of LDS-DMA in flight across the (raw) barriers: per step one counted wait for the
+        // oldest tile, one s_barrier (everyone's share of that tile landed, everyone finished reading the buffer that
+        // is restaged next), restage, compute.
+#pragma unroll
+        for (int p = 0; p < NS - 1; ++p)
+            if (p < nk) stage(p, p * BK);
+        int buf = 0, sbuf = NS - 1;
+        for (int t = 0; t < nk; ++t) {
+            const int ahead = nk - 1 - t;                          // tiles issued after tile t
+            if (ahead >= NS - 2) wait_vmcnt<(NS - 2) * C::LPS>();
+            else if (NS > 3 && ahead == 1) wait_vmcnt<C::LPS>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (t + NS - 1 < nk) stage(sbuf, (t + NS - 1) * BK);
+            compute(buf);
+            buf = (buf + 1 == NS) ? 0 : buf + 1;
+            sbuf = (sbuf + 1 == NS) ? 0 : sbuf + 1;
         }
         __syncthreads();
     }
@@ -192,13 +222,28 @@ void gemm_nt_kernel(GemmNTArgs a) {
 // ------------------------------------------------------------------------------------------------ TN (grouped)
 // C[n][c] = sum_m A[m][n] * B[m][c].  Both operands have the reduction index as their row index, so the MFMA
 // fragments are fetched with the hardware transposing read ds_read_b64_tr_b16 from [m][n] / [m][c] LDS images
-// (256-B rows, 16-B chunk index XOR-ed with ((row&3)<<2 | (row>>2)&3): conflict-free for the tr reads).
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNGroup g) {
+// (rows of TILE*2 bytes; the low 4 bits of the 16-B chunk index are XOR-ed with ((row&3)<<2 | (row>>2)&3):
+// conflict-free for the transposing reads, and a permutation inside each 256-B group so LDS-DMA stays line-friendly).
+template <int BNN, int BNC, int WN, int WC, int NS>
+struct TNCfg {
+    static constexpr int NW = WN * WC, NTHR = NW * 64;
+    static constexpr int A_ROW = BNN * 2, B_ROW = BNC * 2;                 // bytes per reduction row
+    static constexpr int A_BYTES = 64 * A_ROW, B_BYTES = 64 * B_ROW, STAGE = A_BYTES + B_BYTES;
+    static constexpr int A_RPI = 1024 / A_ROW, B_RPI = 1024 / B_ROW;       // reduction rows per LDS-DMA wave instruction
+    static constexpr int AI = 64 / A_RPI / NW, BI = 64 / B_RPI / NW;
+    static constexpr int LPS = AI + BI;
+    static constexpr int LDS = NS * STAGE;
+    static constexpr int BLOCKS_PER_CU = (LDS <= 80 * 1024) ? 2 : 1;
+};
+
+template <typename T, int BNN, int BNC, int WN, int WC, int NS>
+__global__ __launch_bounds__(WN * WC * 64, (TNCfg<BNN, BNC, WN, WC, NS>::BLOCKS_PER_CU * WN * WC) / 4)
+void gemm_tn_kernel(GemmTNGroup g) {
+    using C = TNCfg<BNN, BNC, WN, WC, NS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wn_ = w >> 1, wc_ = w & 1;
+    const int wn_ = w / WC, wc_ = w % WC;
     int id = xcd_remap(blockIdx.x, gridDim.x);
     int pi = 0;
 #pragma unroll
@@ -206,30 +251,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNGroup g) {
         if (i < g.count && id >= g.p[i].tile_start) pi = i;
     const GemmTNProblem& P = g.p[pi];
     id -= P.tile_start;
-    const int tilesC = P.Nc / 128;
-    const int n0 = (id / tilesC) * 128, c0 = (id % tilesC) * 128;
+    const int tilesC = P.Nc / BNC;
+    const int n0 = (id / tilesC) * BNN, c0 = (id % tilesC) * BNC;
     const T* __restrict__ A = (const T*)P.A;
     const T* __restrict__ B = (const T*)P.B;
 
-    // staging: one wave instruction = 4 reduction rows x 256 B; lane -> (row, 16-B slot)
-    const int lrow = lane >> 4, slot = lane & 15;
-    const T* asrc[4];
-    const T* bsrc[4];
+    auto fsw = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
+    // staging: lane -> (row within the instruction, 16-B slot within the row); source chunk = slot ^ f(row)
+    const T* asrc[C::AI];
+    const T* bsrc[C::BI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int row = (w * 4 + i) * 4 + lrow;                              // 0..63 within the m-step
-        int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        asrc[i] = A + (size_t)row * P.lda + n0 + chunk * 8;
-        bsrc[i] = B + (size_t)row * P.ldb + c0 + chunk * 8;
+    for (int i = 0; i < C::AI; ++i) {
+        constexpr int SPR = C::A_ROW / 16;                                  // slots per row
+        const int row = (w * C::AI + i) * C::A_RPI + lane / SPR, slot = lane % SPR;
+        asrc[i] = A + (size_t)row * P.lda + n0 + (slot ^ fsw(row)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < C::BI; ++i) {
+        constexpr int SPR = C::B_ROW / 16;
+        const int row = (w * C::BI + i) * C::B_RPI + lane / SPR, slot = lane % SPR;
+        bsrc[i] = B + (size_t)row * P.ldb + c0 + (slot ^ fsw(row)) * 8;
     }
     auto stage = [&](int buf, int mstep) {
-        char* base = smem + buf * 32768 + w * 4096;
+        char* base = smem + buf * C::STAGE;
         const size_t ao = (size_t)mstep * 64 * P.lda, bo = (size_t)mstep * 64 * P.ldb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds(MM_GLB(asrc[i] + ao), MM_LDS(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(MM_GLB(bsrc[i] + bo), MM_LDS(base + 16384 + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < C::AI; ++i)
+            __builtin_amdgcn_global_load_lds(MM_GLB(asrc[i] + ao), MM_LDS(base + (w * C::AI + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C::BI; ++i)
+            __builtin_amdgcn_global_load_lds(MM_GLB(bsrc[i] + bo), MM_LDS(base + C::A_BYTES + (w * C::BI + i) * 1024), 16, 0, 0);
     };
     f32x4 acc[4][4];
 #pragma unroll
@@ -239,38 +290,59 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNGroup g) {
 
     // transposed-read addressing: lane = 16 g + 4 q + p; rows 8g+q (and +4), columns col16 + 4p..4p+3
     const int gq = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
-    const int nsteps = P.M / 64;
-    stage(0, 0);
-    __syncthreads();
-    for (int t = 0; t < nsteps; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nsteps) stage(cur ^ 1, t + 1);
-        const char* As = smem + cur * 32768;
-        const char* Bs = As + 16384;
+    auto compute = [&](int buf) {
+        const char* As = smem + buf * C::STAGE;
+        const char* Bs = As + C::A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int r0 = kk * 32 + gq * 8 + q4, r1 = r0 + 4;
-            const int f0 = ((r0 & 3) << 2) | ((r0 >> 2) & 3), f1 = ((r1 & 3) << 2) | ((r1 >> 2) & 3);
+            const int f0 = fsw(r0), f1 = fsw(r1);
             v8 af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ch = (wn_ * 64 + i * 16 + p4 * 4) >> 3, in = (p4 & 1) * 8;
-                af[i] = join_tr<T>(lds_read_tr4(As, r0 * 256 + ((ch ^ f0) << 4) + in), lds_read_tr4(As, r1 * 256 + ((ch ^ f1) << 4) + in));
+                af[i] = join_tr<T>(lds_read_tr4(As, r0 * C::A_ROW + ((ch ^ f0) << 4) + in), lds_read_tr4(As, r1 * C::A_ROW + ((ch ^ f1) << 4) + in));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ch = (wc_ * 64 + j * 16 + p4 * 4) >> 3, in = (p4 & 1) * 8;
-                bf[j] = join_tr<T>(lds_read_tr4(Bs, r0 * 256 + ((ch ^ f0) << 4) + in), lds_read_tr4(Bs, r1 * 256 + ((ch ^ f1) << 4) + in));
+                bf[j] = join_tr<T>(lds_read_tr4(Bs, r0 * C::B_ROW + ((ch ^ f0) << 4) + in), lds_read_tr4(Bs, r1 * C::B_ROW + ((ch ^ f1) << 4) + in));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
         }
+    };
+    const int nsteps = P.M / 64;
+    if constexpr (NS == 2) {
+        stage(0, 0);
         __syncthreads();
+        for (int t = 0; t < nsteps; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nsteps) stage(cur ^ 1, t + 1);
+            compute(cur);
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < NS - 1; ++p)
+            if (p < nsteps) stage(p, p);
+        int buf = 0, sbuf = NS - 1;
+        for (int t = 0; t < nsteps; ++t) {
+            const int ahead = nsteps - 1 - t;
+            if (ahead >= NS - 2) wait_vmcnt<(NS - 2) * C::LPS>();
+            else if (NS > 3 && ahead == 1) wait_vmcnt<C::LPS>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (t + NS - 1 < nsteps) stage(sbuf, t + NS - 1);
+            compute(buf);
+            buf = (buf + 1 == NS) ? 0 : buf + 1;
+            sbuf = (sbuf + 1 == NS) ? 0 : sbuf + 1;
+        }
     }
     // D[row = n][col = c]: col = lane&15, row = 4*(lane>>4) + reg
-    float* C = P.C;
+    float* Cp = P.C;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -279,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNGroup g) {
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wn_ * 64 + i * 16 + (lane >> 4) * 4 + r;
                 const int c = c0 + wc_ * 64 + j * 16 + (lane & 15);
-                float* dst = C + (size_t)n * P.ldc + c;
+                float* dst = Cp + (size_t)n * P.ldc + c;
                 if (g.accumulate) atomicAdd(dst, acc[i][j][r]);
                 else *dst = acc[i][j][r];
             }
@@ -381,22 +453,23 @@ static bool nt_fast_ok(const GemmNTArgs& a) {
            (!(a.flags & GEMM_BIAS) || al(a.bias)) && a.M > 0;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NS>
 static void launch_nt_t(const GemmNTArgs& a, hipStream_t s) {
-    using C = NTCfg<BM, BN, WM, WN>;
+    using C = NTCfg<BM, BN, WM, WN, NS>;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(C::NTHR), C::LDS, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN, NS>), dim3(grid), dim3(C::NTHR), C::LDS, s, a);
 }
 
-// tile choice: explicit (a.tile: 1 = 128x128, 2 = 256x128, 3 = 256x256) or by a wave-quantisation x intensity score
+// tile choice: explicit (a.tile: 1 = 128x128 2-stage, 2 = 256x128 2-stage, 3 = 256x256 2-stage, 4 = 128x128 4-stage ring,
+// 5 = 256x128 3-stage ring) or by a wave-quantisation x intensity score
 static int choose_nt_tile(const GemmNTArgs& a) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_NT_TILE"); env = e ? atoi(e) : 0; }
     int t = a.tile ? a.tile : env;
     if (t == 3 && a.N % 256) t = 2;
-    if (t >= 1 && t <= 3) return t;
+    if (t >= 1 && t <= 5) return t;
     const double eff[4] = {0, 0.62, 0.80, 1.0};
     const int bm[4] = {0, 128, 256, 256}, bn[4] = {0, 128, 128, 256}, slots[4] = {0, 512, 256, 256};
     int best = 1;
@@ -415,9 +488,11 @@ static int choose_nt_tile(const GemmNTArgs& a) {
 template <typename T>
 static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
     switch (choose_nt_tile(a)) {
-        case 3: launch_nt_t<T, 256, 256, 2, 4>(a, s); break;
-        case 2: launch_nt_t<T, 256, 128, 4, 2>(a, s); break;
-        default: launch_nt_t<T, 128, 128, 2, 2>(a, s); break;
+        case 5: launch_nt_t<T, 256, 128, 4, 2, 3>(a, s); break;
+        case 4: launch_nt_t<T, 128, 128, 2, 2, 4>(a, s); break;
+        case 3: launch_nt_t<T, 256, 256, 2, 4, 2>(a, s); break;
+        case 2: launch_nt_t<T, 256, 128, 4, 2, 2>(a, s); break;
+        default: launch_nt_t<T, 128, 128, 2, 2, 2>(a, s); break;
     }
 }
 
@@ -434,31 +509,46 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <typename T, int BNN, int BNC, int WN, int WC, int NS>
+static void launch_tn_t(const GemmTNGroup& g, int tiles, hipStream_t s) {
+    using C = TNCfg<BNN, BNC, WN, WC, NS>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BNN, BNC, WN, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
+    hipLaunchKernelGGL((gemm_tn_kernel<T, BNN, BNC, WN, WC, NS>), dim3(tiles), dim3(C::NTHR), C::LDS, s, g);
+}
+
+// variant: 1 = 128x128 2-stage, 2 = 128x128 4-stage ring, 3 = 256x128 3-stage ring (default); env MMHIP_TN_TILE overrides
 hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        attr_done = true;
-    }
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("MMHIP_TN_TILE"); env = e ? atoi(e) : 0; }
+    int variant = (force_slow >> 4) ? (force_slow >> 4) : (env ? env : 3);
+    force_slow &= 1;
+    const int bnn = variant == 3 ? 256 : 128;
     GemmTNGroup g;
     g.count = 0;
     g.accumulate = accumulate;
     int tiles = 0;
     auto flush = [&]() {
         if (!g.count) return;
-        if (dtype == DT_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(tiles), dim3(256), 65536, s, g);
-        else hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(tiles), dim3(256), 65536, s, g);
+        if (dtype == DT_BF16) {
+            if (variant == 3) launch_tn_t<bf16_t, 256, 128, 4, 2, 3>(g, tiles, s);
+            else if (variant == 2) launch_tn_t<bf16_t, 128, 128, 2, 2, 4>(g, tiles, s);
+            else launch_tn_t<bf16_t, 128, 128, 2, 2, 2>(g, tiles, s);
+        } else {
+            if (variant == 3) launch_tn_t<f16_t, 256, 128, 4, 2, 3>(g, tiles, s);
+            else if (variant == 2) launch_tn_t<f16_t, 128, 128, 2, 2, 4>(g, tiles, s);
+            else launch_tn_t<f16_t, 128, 128, 2, 2, 2>(g, tiles, s);
+        }
         g.count = 0;
         tiles = 0;
     };
     for (int i = 0; i < count; ++i) {
         GemmTNProblem P = probs[i];
         auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-        bool fast = !force_slow && P.M > 0 && P.M % 64 == 0 && P.Nn % 128 == 0 && P.Nc % 128 == 0 && P.lda % 8 == 0 && P.ldb % 8 == 0 && al(P.A) && al(P.B);
+        bool fast = !force_slow && P.M > 0 && P.M % 64 == 0 && P.Nn % bnn == 0 && P.Nc % 128 == 0 && P.lda % 8 == 0 && P.ldb % 8 == 0 && al(P.A) && al(P.B);
         if (fast) {
             P.tile_start = tiles;
-            tiles += (P.Nn / 128) * (P.Nc / 128);
+            tiles += (P.Nn / bnn) * (P.Nc / 128);
             g.p[g.count++] = P;
             if (g.count == GEMM_TN_MAX_GROUP) flush();
         } else if (P.M > 0) {

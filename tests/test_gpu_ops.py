@@ -61,9 +61,11 @@ def _gemm_ref(A, B, bias, act, resid, mulg, keep, scale):
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K,slow", [(256, 256, 128, 0), (200, 128, 64, 0), (1000, 768, 768, 0), (8192, 2304, 768, 0),
                                         (512, 768, 3072, 0), (96, 48, 40, 1), (64, 768, 768, 0), (1000, 768, 768, 32),
-                                        (700, 512, 256, 48), (8192, 2304, 768, 32), (2048, 3072, 768, 48)])
+                                        (700, 512, 256, 48), (8192, 2304, 768, 32), (2048, 3072, 768, 48), (1000, 768, 768, 64),
+                                        (200, 128, 64, 80), (8192, 2304, 768, 80), (2048, 3072, 768, 64), (300, 256, 128, 80)])
 def test_gemm_nt_epilogues(dt, M, N, K, slow):
-    """`slow`: bit 0 forces the generic kernel, bits 4.. pick the tile variant (16 = 128x128, 32 = 256x128, 48 = 256x256)"""
+    """`slow`: bit 0 forces the generic kernel, bits 4.. pick the tile variant (16 = 128x128, 32 = 256x128, 48 = 256x256,
+    64 = 128x128 4-stage ring, 80 = 256x128 3-stage ring)"""
     code, tdt = DT[dt]
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = (torch.randn(M, K, generator=g) * 0.5).to(tdt).to(dev())
@@ -102,7 +104,8 @@ def test_gemm_nt_epilogues(dt, M, N, K, slow):
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,Nn,Nc,slow", [(64, 128, 128, 0), (256, 256, 384, 0), (8192, 768, 768, 0), (1024, 2304, 768, 0),
-                                          (96, 40, 72, 1)])
+                                          (96, 40, 72, 1), (64, 128, 128, 16), (256, 256, 384, 16), (128, 128, 256, 32),
+                                          (8192, 768, 768, 32), (64, 256, 128, 48), (192, 512, 384, 48), (8192, 768, 3072, 48)])
 def test_gemm_tn(dt, M, Nn, Nc, slow):
     code, tdt = DT[dt]
     g = torch.Generator(device="cpu").manual_seed(M + Nn)

@@ -35,14 +35,14 @@ def main():
               ("txt dx_qkv", 8192, 768, 2304), ("vit qkv", 12608, 2304, 768), ("vit ao", 12608, 768, 768), ("vit fc1", 12608, 3072, 768),
               ("vit fc2", 12608, 768, 3072), ("itm qkv", 16384, 2304, 768), ("itm ao", 16384, 768, 768), ("itm fc2", 16384, 768, 3072),
               ("square 4096", 4096, 4096, 4096)]
-    print(f"{'shape':14s} {'M':>6} {'N':>5} {'K':>5} | " + " | ".join(f"{n:>18s}" for n in ("128x128", "256x128", "256x256", "auto")))
+    print(f"{'shape':14s} {'M':>6} {'N':>5} {'K':>5} | " + " | ".join(f"{n:>18s}" for n in ("128x128", "256x128", "256x256", "128x128 ring4", "256x128 ring3", "auto")))
     for name, M, N, K in shapes:
         A = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
         B = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
         Cm = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         bias = torch.randn(N, device=dev)
         cells = []
-        for tile in (1, 2, 3, 0):
+        for tile in (1, 2, 3, 4, 5, 0):
             if tile == 3 and N % 256:
                 cells.append(f"{'-':>18s}")
                 continue
@@ -56,9 +56,12 @@ def main():
         A = (torch.randn(M, Nn, device=dev) * 0.1).to(torch.bfloat16)
         B = (torch.randn(M, Nc, device=dev) * 0.5).to(torch.bfloat16)
         Cm = torch.empty(Nn, Nc, device=dev)
-        fn = lambda: lib.mmhip_op_gemm_tn(0, p(A), Nn, p(B), Nc, p(Cm), Nc, M, Nn, Nc, 0, 0, st())
-        us = time_it(fn)
-        print(f"{name:14s} M={M} {Nn}x{Nc}: {us:7.1f}us {2.0 * M * Nn * Nc / us / 1e6:6.0f}TF", flush=True)
+        cells = []
+        for var in (1, 2, 3):
+            fn = lambda: lib.mmhip_op_gemm_tn(0, p(A), Nn, p(B), Nc, p(Cm), Nc, M, Nn, Nc, 0, var << 4, st())
+            us = time_it(fn)
+            cells.append(f"{us:7.1f}us {2.0 * M * Nn * Nc / us / 1e6:6.0f}TF")
+        print(f"{name:14s} M={M} {Nn}x{Nc}: " + " | ".join(cells) + "   (128x128 2-stage | 128x128 ring4 | 256x128 ring3)", flush=True)
 
 
 if __name__ == "__main__":
