@@ -45,9 +45,16 @@ void gemm_nt_kernel(GemmNTArgs a) {
     typedef typename Vec<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
-    const int tilesN = a.N / BN;
+    // tile raster: column groups of GW tiles, all row bands inside a group before the next group, and each XCD gets a
+    // contiguous run of that order -- the blocks co-resident on one XCD then share <= GW weight panels and a few row
+    // bands, which fit its 4 MB L2 (PMC: 74 % -> L2 hit rate with the plain row-major order on N = 3072).
+    const int tilesN = a.N / BN, tilesM = (a.M + BM - 1) / BM;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (id / tilesN) * BM, n0 = (id % tilesN) * BN;
+    constexpr int GW = 8;
+    const int per_group = tilesM * GW;
+    const int grp = id / per_group, rem = id - grp * per_group;
+    const int gw = min(GW, tilesN - grp * GW);
+    const int m0 = (rem / gw) * BM, n0 = (grp * GW + rem % gw) * BN;
     const T* __restrict__ A = (const T*)a.A;
     const T* __restrict__ B = (const T*)a.B;
 
