@@ -52,6 +52,7 @@ struct mmhip_engine {
     std::vector<TextAct> tact;
     size_t ids_all, mask_all, pos_ids, maskbias, x0, xhat_emb, rstd_emb;
     size_t v_patches, v_pe, v_x, v_ln, v_qkv, v_ctx, v_h, v_out;                             // ViT ping-pong
+    size_t g_partial;
     size_t g_dx, g_dx2, g_dpre, g_ddrop, g_dpre1, g_ddrop1, g_dqkv, g_dctx, g_du;                               // backward temporaries
     // heads (fp32) ----------------------------------------------------------------------
     size_t h_vpool, h_tpool, h_txt_e, h_img_e, h_txt_n, h_img_n, h_txt_inv, h_img_inv, h_logits;
@@ -233,6 +234,10 @@ void build_workspace(mmhip_engine& e) {
     e.v_h = w.take(Mv * I * 2); e.v_out = w.take(Mv * H * 2);
     e.g_dx = w.take(Mt * H * 2); e.g_dx2 = w.take(Mt * H * 2); e.g_dpre = w.take(Mt * H * 2); e.g_ddrop = w.take(Mt * H * 2); e.g_dpre1 = w.take(Mt * H * 2); e.g_ddrop1 = w.take(Mt * H * 2);
     e.g_dqkv = w.take(Mt * 3 * H * 2); e.g_dctx = w.take(Mt * H * 2); e.g_du = w.take(Mt * I * 2);
+    {
+        size_t pf = partial_floats_rows((int)Mt, (int)H, 3), pc = partial_floats_colsum((int)Mt, (int)(3 * H > I ? 3 * H : I));
+        e.g_partial = w.take((pf > pc ? pf : pc) * 4);
+    }
     auto f = [&](size_t n) { return w.take(n * 4); };
     e.h_vpool = f(Bm * H); e.h_tpool = f(Bm * H); e.h_txt_e = f(Bm * E); e.h_img_e = f(Bm * E); e.h_txt_n = f(Bm * E); e.h_img_n = f(Bm * E);
     e.h_txt_inv = f(Bm); e.h_img_inv = f(Bm); e.h_logits = f(Bm * Bm);
@@ -523,7 +528,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     char *dx = e.ws + e.g_dx, *dpre2 = e.ws + e.g_dpre, *ddrop2 = e.ws + e.g_ddrop, *dpre1 = e.ws + e.g_dpre1, *ddrop1 = e.ws + e.g_ddrop1;
     char *du = e.ws + e.g_du, *dx2 = e.ws + e.g_dx2, *dctx = e.ws + e.g_dctx, *dqkv = e.ws + e.g_dqkv;
     // ---- x' = LN2(pre2), pre2 = drop(fc2(h)) + a1
-    LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mt, H};
+    LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mt, H, e.wsp<float>(e.g_partial)};
     CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
     const DropCfg d_ffn = make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr);
     const char* df = dpre2;
@@ -531,16 +536,16 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
     { G g(df, H, e.ws + w.fc2T, H, du, I, Mt, I, H); g.mul_gelu_grad(e.ws + a.u, I); if (int r = run_gemm(e, g, s)) return r; }
     { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mt, H, I); g.residual(dpre2, H); if (int r = run_gemm(e, g, s)) return r; }
-    CHECK_HIP(launch_colsum(df, Mt, H, H, Gd + o.fc2_b, dt, s));
-    CHECK_HIP(launch_colsum(du, Mt, I, I, Gd + o.fc1_b, dt, s));
+    CHECK_HIP(launch_colsum(df, Mt, H, H, Gd + o.fc2_b, dt, s, e.wsp<float>(e.g_partial)));
+    CHECK_HIP(launch_colsum(du, Mt, I, I, Gd + o.fc1_b, dt, s, e.wsp<float>(e.g_partial)));
     // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
-    LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mt, H};
+    LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mt, H, e.wsp<float>(e.g_partial)};
     CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
     const char* dout = dpre1;
     if (d_ao.thresh16) { CHECK_HIP(launch_dropout16(dpre1, ddrop1, (size_t)Mt * H, d_ao, dt, s)); dout = ddrop1; }
     { G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H); if (int r = run_gemm(e, g, s)) return r; }
-    CHECK_HIP(launch_colsum(dout, Mt, H, H, Gd + o.ao_b, dt, s));
+    CHECK_HIP(launch_colsum(dout, Mt, H, H, Gd + o.ao_b, dt, s, e.wsp<float>(e.g_partial)));
     AttnBwdArgs ab;
     memset(&ab, 0, sizeof(ab));
     ab.qkv = e.ws + a.qkv; ab.maskbias = e.wsp<float>(e.maskbias); ab.ctx = e.ws + a.ctx; ab.dctx = dctx; ab.lse = e.wsp<float>(a.lse);
@@ -549,7 +554,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     ab.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
     CHECK_HIP(launch_attn_bwd(ab, dt, s));
     { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.residual(dpre1, H); if (int r = run_gemm(e, g, s)) return r; }
-    CHECK_HIP(launch_colsum(dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, s));
+    CHECK_HIP(launch_colsum(dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, s, e.wsp<float>(e.g_partial)));
     // ---- all four weight gradients of the layer in one grouped launch (432 tiles of 128x128, no split-K, plain stores)
     GemmTNProblem pr[4];
     pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mt, H, I, H, I, I, 0};          // dW2[H,I]   = df^T h
@@ -572,6 +577,7 @@ int embed_backward(mmhip_engine& e, hipStream_t s) {
     b.posts = e.Bt; b.T = e.T; b.H = c.hidden; b.pad_id = c.pad_id;
     b.pos_pad_id = c.txt_kind == MMHIP_TXT_XLMR ? c.pad_id : -1;     // nn.Embedding(padding_idx=...) rows get no gradient
     b.drop = make_drop(c.p_hidden, e.seed, STREAM_EMBED, e.train_mode);
+    b.partial = e.wsp<float>(e.g_partial);
     CHECK_HIP(launch_embed_bwd(b, e.dt(), s));
     return 0;
 }

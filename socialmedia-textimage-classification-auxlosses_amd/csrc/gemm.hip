@@ -477,19 +477,11 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     int t = a.tile ? a.tile : env;
     if (t == 3 && a.N % 256) t = 2;
     if (t >= 1 && t <= 5) return t;
-    const double eff[4] = {0, 0.62, 0.80, 1.0};
-    const int bm[4] = {0, 128, 256, 256}, bn[4] = {0, 128, 128, 256}, slots[4] = {0, 512, 256, 256};
-    int best = 1;
-    double best_score = -1;
-    for (int c = 1; c <= 3; ++c) {
-        if (a.N % bn[c]) continue;
-        const long tiles = (long)((a.M + bm[c] - 1) / bm[c]) * (a.N / bn[c]);
-        const long waves = (tiles + slots[c] - 1) / slots[c];
-        const double useful = (double)a.M * a.N / ((double)waves * slots[c] * bm[c] * bn[c]);
-        const double score = useful * eff[c];
-        if (score > best_score) { best_score = score; best = c; }
-    }
-    return best;
+    // measured on MI355X (tools/gemm_bench.py, random bf16): with K = 768..3072 and N <= 3072 the 128x128 tile at two
+    // blocks per CU is best or within 5 %; 256x256 wins once K is long and it still fills >= half the CUs.
+    const long tiles256 = (long)((a.M + 255) / 256) * (a.N / 256);
+    if (a.N % 256 == 0 && a.K >= 2048 && tiles256 >= 128) return 3;
+    return 1;
 }
 
 template <typename T>

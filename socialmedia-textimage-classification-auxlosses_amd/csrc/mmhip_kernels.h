@@ -77,8 +77,9 @@ struct LNBwdArgs {
     const void* dy; const void* x; const float* gamma; const float* mean; const float* rstd;
     void* dx;             // 16-bit
     const void* dres;     // optional 16-bit tensor added to dx (gradient arriving through the residual branch)
-    float* dgamma; float* dbeta;   // fp32, atomically accumulated
+    float* dgamma; float* dbeta;   // fp32, accumulated (+=)
     int rows, width;
+    float* partial;       // optional workspace of partial_floats_rows(rows, width, 2) floats: two-stage column reduction
 };
 hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s);
 hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s);
@@ -100,13 +101,16 @@ struct EmbedBwdArgs {
     float* dword; float* dpos; float* dtype; float* dgamma; float* dbeta;
     int posts, T, H, pad_id, pos_pad_id;
     DropCfg drop;
+    float* partial;       // optional workspace of partial_floats_rows(posts*T, H, 3) floats
 };
 hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s);
 hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s);
 
 hipError_t launch_patchify(const float* pixels, void* out, int B, int img, int patch, int dtype, hipStream_t s);
 hipError_t launch_vit_assemble(const void* patches, const float* cls, const float* pos, void* x, int B, int P, int H, int dtype, hipStream_t s);
-hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s);   // out[c] += sum_r x[r][c]
+hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s, float* partial = nullptr);   // out[c] += sum_r x[r][c]
+size_t partial_floats_rows(int rows, int width, int nvec);
+size_t partial_floats_colsum(int rows, int cols);
 hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s);
 hipError_t launch_cast_transpose(const float* src, void* dst, int rows, int cols, int dtype, hipStream_t s);   // dst[c][r] = src[r][c]
 hipError_t launch_gather_rows_f32(const void* src, size_t src_stride, float* out, int ldo, int rows, int H, int dtype, hipStream_t s);

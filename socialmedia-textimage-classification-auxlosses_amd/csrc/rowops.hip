@@ -136,9 +136,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
             for (int e = 0; e < 4; ++e) { red[0][w][(lane + 64 * t) * 4 + e] = dg[t][e]; red[1][w][(lane + 64 * t) * 4 + e] = db[t][e]; }
     __syncthreads();
     for (int c = threadIdx.x; c < a.width; c += 256) {
-        atomicAdd(a.dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-        atomicAdd(a.dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        if (a.partial) {      // [2][gridDim.x][width]: reduced by reduce_partials_kernel (no same-address atomic storm)
+            a.partial[(size_t)blockIdx.x * a.width + c] = sg;
+            a.partial[((size_t)gridDim.x + blockIdx.x) * a.width + c] = sb;
+        } else {
+            atomicAdd(a.dgamma + c, sg);
+            atomicAdd(a.dbeta + c, sb);
+        }
     }
+}
+// out[c] += sum_i partial[i][c]   (i < n); one thread per column, coalesced across columns
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 3 < n; i += 4) {
+        s0 += partial[(size_t)i * cols + c]; s1 += partial[(size_t)(i + 1) * cols + c];
+        s2 += partial[(size_t)(i + 2) * cols + c]; s3 += partial[(size_t)(i + 3) * cols + c];
+    }
+    for (; i < n; ++i) s0 += partial[(size_t)i * cols + c];
+    out[c] += (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------------------------------------ text embeddings
@@ -295,9 +315,18 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
             }
     __syncthreads();
     for (int c = threadIdx.x; c < a.H; c += 256) {
-        atomicAdd(a.dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-        atomicAdd(a.dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
-        atomicAdd(a.dtype + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+        const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        const float st = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
+        if (a.partial) {
+            a.partial[(size_t)blockIdx.x * a.H + c] = sg;
+            a.partial[((size_t)gridDim.x + blockIdx.x) * a.H + c] = sb;
+            a.partial[((size_t)2 * gridDim.x + blockIdx.x) * a.H + c] = st;
+        } else {
+            atomicAdd(a.dgamma + c, sg);
+            atomicAdd(a.dbeta + c, sb);
+            atomicAdd(a.dtype + c, st);
+        }
     }
 }
 
@@ -344,7 +373,7 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const T* __restrict__
 // out[c] += sum_r x[r][c]   (bias gradients).  grid (ceil(cols/256), row chunks); lanes own 4 columns each.
 static constexpr int COLSUM_ROWS = 64;
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int cols, int ld, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int cols, int ld, float* __restrict__ out, float* __restrict__ partial) {
     __shared__ float red[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
@@ -362,7 +391,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     for (int e = 0; e < 4; ++e) red[w][lane * 4 + e] = s[e];
     __syncthreads();
     const int cc = blockIdx.x * 256 + threadIdx.x;
-    if (cc < cols) atomicAdd(out + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (cc < cols) {
+        const float sres = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (partial) partial[(size_t)blockIdx.y * cols + cc] = sres;
+        else atomicAdd(out + cc, sres);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ casts
@@ -452,12 +485,19 @@ hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s) {
     else hipLaunchKernelGGL(ln_fwd_kernel<f16_t>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }
+size_t partial_floats_rows(int rows, int width, int nvec) { return (size_t)nvec * ((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK) * width; }
+size_t partial_floats_colsum(int rows, int cols) { return (size_t)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS) * cols; }
+
 hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
     if (a.width % 4 || a.width > 1024) return hipErrorInvalidValue;
     const int grid = (a.rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
     if (dtype == DT_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    if (a.partial) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((a.width + 255) / 256), dim3(256), 0, s, a.partial, grid, a.width, a.dgamma);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((a.width + 255) / 256), dim3(256), 0, s, a.partial + (size_t)grid * a.width, grid, a.width, a.dbeta);
+    }
     return hipGetLastError();
 }
 hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s) {
@@ -474,6 +514,11 @@ hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s) {
     const int grid = (a.posts * a.T + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
     if (dtype == DT_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(embed_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    if (a.partial) {
+        float* outs[3] = {a.dgamma, a.dbeta, a.dtype};
+        for (int k = 0; k < 3; ++k)
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((a.H + 255) / 256), dim3(256), 0, s, a.partial + (size_t)k * grid * a.H, grid, a.H, outs[k]);
+    }
     return hipGetLastError();
 }
 hipError_t launch_patchify(const float* pixels, void* out, int B, int img, int patch, int dtype, hipStream_t s) {
@@ -491,12 +536,13 @@ hipError_t launch_vit_assemble(const void* patches, const float* cls, const floa
     else hipLaunchKernelGGL(vit_assemble_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, (const f16_t*)patches, cls, pos, (f16_t*)x, B, P, H);
     return hipGetLastError();
 }
-hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s) {
+hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s, float* partial) {
     if (rows <= 0 || cols <= 0) return hipSuccess;
     if (cols % 4 || ld % 4) return hipErrorInvalidValue;
     dim3 grid((cols + 255) / 256, (rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
-    if (dtype == DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, cols, ld, out);
-    else hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, rows, cols, ld, out);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, cols, ld, out, partial);
+    else hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, rows, cols, ld, out, partial);
+    if (partial) hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial, (int)grid.y, cols, out);
     return hipGetLastError();
 }
 hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s) {
