@@ -147,18 +147,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
         }
     }
 }
-// out[c] += sum_i partial[i][c]   (i < n); one thread per column, coalesced across columns
+// out[c] += sum_i partial[i][c]   (i < n).  Block = 64 columns x 4 waves; grid.y splits the partial rows; each wave
+// walks its rows with 4 independent accumulators; the 4 waves combine through LDS and one atomic per column per
+// block finishes (grid.y-way contention only).
+static constexpr int RP_SPLIT = 8;
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n, int cols, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int i = 0;
-    for (; i + 3 < n; i += 4) {
-        s0 += partial[(size_t)i * cols + c]; s1 += partial[(size_t)(i + 1) * cols + c];
-        s2 += partial[(size_t)(i + 2) * cols + c]; s3 += partial[(size_t)(i + 3) * cols + c];
+    if (c < cols) {
+        const int stride = 4 * gridDim.y;
+        int i = blockIdx.y * 4 + w;
+        for (; i + 3 * stride < n; i += 4 * stride) {
+            s0 += partial[(size_t)i * cols + c];
+            s1 += partial[(size_t)(i + stride) * cols + c];
+            s2 += partial[(size_t)(i + 2 * stride) * cols + c];
+            s3 += partial[(size_t)(i + 3 * stride) * cols + c];
+        }
+        for (; i < n; i += stride) s0 += partial[(size_t)i * cols + c];
     }
-    for (; i < n; ++i) s0 += partial[(size_t)i * cols + c];
-    out[c] += (s0 + s1) + (s2 + s3);
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && c < cols) atomicAdd(out + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+static inline void launch_reduce_partials(const float* partial, int n, int cols, float* out, hipStream_t s) {
+    const int split = n >= 4 * RP_SPLIT ? RP_SPLIT : 1;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64, split), dim3(256), 0, s, partial, n, cols, out);
 }
 
 // ------------------------------------------------------------------------------------------------ text embeddings
@@ -495,8 +510,8 @@ hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s) {
     if (dtype == DT_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
     if (a.partial) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((a.width + 255) / 256), dim3(256), 0, s, a.partial, grid, a.width, a.dgamma);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((a.width + 255) / 256), dim3(256), 0, s, a.partial + (size_t)grid * a.width, grid, a.width, a.dbeta);
+        launch_reduce_partials(a.partial, grid, a.width, a.dgamma, s);
+        launch_reduce_partials(a.partial + (size_t)grid * a.width, grid, a.width, a.dbeta, s);
     }
     return hipGetLastError();
 }
@@ -517,7 +532,7 @@ hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s) {
     if (a.partial) {
         float* outs[3] = {a.dgamma, a.dbeta, a.dtype};
         for (int k = 0; k < 3; ++k)
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((a.H + 255) / 256), dim3(256), 0, s, a.partial + (size_t)k * grid * a.H, grid, a.H, outs[k]);
+            launch_reduce_partials(a.partial + (size_t)k * grid * a.H, grid, a.H, outs[k], s);
     }
     return hipGetLastError();
 }
@@ -542,7 +557,7 @@ hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, 
     dim3 grid((cols + 255) / 256, (rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
     if (dtype == DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, cols, ld, out, partial);
     else hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, rows, cols, ld, out, partial);
-    if (partial) hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial, (int)grid.y, cols, out);
+    if (partial) launch_reduce_partials(partial, (int)grid.y, cols, out, s);
     return hipGetLastError();
 }
 hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s) {
