@@ -1,0 +1,71 @@
+"""Input pipeline to the model boundary -- mirrors reference models/datasets.py:125-190 (MM_Dataset) and
+models/utils.py:133-200 (prepare_data): tweet normalisation, tokenisation to max_length=128 with padding='max_length',
+image -> 224x224, rescale 1/255, mean = std = 0.5 (the ViT image processor's defaults), one-hot int64 labels."""
+import os
+import re
+
+import numpy as np
+import torch
+
+from .config import MODEL_DIR_DICT
+from .utils import balanced_class_weights
+
+_URL = re.compile(r"(https?://\S+|www\.\S+)")
+_USER = re.compile(r"@\w+")
+
+
+def normalize_tweet(text):
+    """reference preprocessing/text_processing.py:180-248 (core rules): @user -> @USER, URLs -> HTTPURL"""
+    text = _URL.sub("HTTPURL", str(text))
+    text = _USER.sub("@USER", text)
+    return " ".join(text.split())
+
+
+def prepare_data(data, num_labels, testing=False, nsamples=-1, seed=30):
+    """reference models/utils.py:133-200: --testing samples 200 rows; split column -> train/val/test; one-hot labels;
+    sklearn-'balanced' class weights from the training split"""
+    if testing:
+        data = data.sample(min(200, len(data)), random_state=seed)
+    parts = {s: data[data.split == s] for s in ("train", "val", "test")}
+    if nsamples > 0:
+        parts["train"] = parts["train"].sample(min(nsamples, len(parts["train"])), random_state=seed)
+    onehot = lambda df: np.eye(num_labels, dtype=np.int64)[df.label.values.astype(int)]
+    weights = balanced_class_weights(parts["train"].label.values, num_labels)
+    return parts["train"], onehot(parts["train"]), parts["val"], onehot(parts["val"]), parts["test"], onehot(parts["test"]), weights
+
+
+class MM_Dataset(torch.utils.data.Dataset):
+    """item layout of reference models/datasets.py:125-190"""
+
+    def __init__(self, tweet_ids, texts, labels, tokenizer, max_length, img_file_fmt, image=224):
+        self.ids, self.texts, self.labels = tweet_ids, texts, labels
+        self.tok, self.max_length, self.fmt, self.image = tokenizer, max_length, img_file_fmt, image
+
+    def __len__(self):
+        return len(self.ids)
+
+    def _pixels(self, tid):
+        from PIL import Image
+        path = self.fmt.format(tid)
+        if not os.path.exists(path):
+            path = path.replace(".jpg", ".png")               # reference :164-167 jpg -> png fallback
+        img = Image.open(path).convert("RGB").resize((self.image, self.image), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
+        return ((x - 0.5) / 0.5).unsqueeze(0)
+
+    def __getitem__(self, i):
+        enc = self.tok(normalize_tweet(self.texts[i]), padding="max_length", truncation=True, max_length=self.max_length, return_tensors="pt")
+        return {"input_ids": enc["input_ids"], "attention_mask": enc["attention_mask"], "pixel_values": self._pixels(self.ids[i]),
+                "labels": torch.from_numpy(self.labels[i]), "data_id": torch.tensor(int(self.ids[i]))}
+
+
+def loaders_from_data_key(cfg, args, trainer):
+    from transformers import AutoTokenizer
+    tdir = MODEL_DIR_DICT[args.txt_model_name]
+    if not os.path.isdir(tdir):
+        raise FileNotFoundError(f"tokenizer directory {tdir!r} (config.MODEL_DIR_DICT) not found: use --synthetic, or place the model there")
+    tok = AutoTokenizer.from_pretrained(tdir)
+    tr, ytr, va, yva, te, yte, w = prepare_data(cfg.data, cfg.num_labels, args.testing, args.nsamples, args.seed)
+    mk = lambda df, y: MM_Dataset(df.tweet_id.values, df.text.values, y, tok, cfg.max_length, cfg.img_fmt, trainer.model.arch["image"])
+    dl = lambda ds, sh: torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh)
+    return dl(mk(tr, ytr), True), dl(mk(va, yva), False), dl(mk(te, yte), False), w
