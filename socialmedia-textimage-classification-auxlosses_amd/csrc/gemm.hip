@@ -147,33 +147,40 @@ void gemm_nt_kernel(GemmNTArgs a) {
     // ---- epilogue: accumulators -> wave-private fp32 LDS chunk (32 rows) -> row-contiguous 16-B global stores
     float* ep = reinterpret_cast<float*>(smem + w * C::EP_WAVE);
     const int fl = a.flags;
-    constexpr int LPR = C::TN / 8;                 // lanes per row
-    constexpr int RPP = 64 / LPR;                  // rows per pass
+    constexpr int LPR = C::TN / 8;                 // lanes per row (8 outputs = 16 B each)
+    constexpr int RPP = 64 / LPR;                  // rows per pass; lanes >= RPP*LPR idle when 64 % LPR != 0
+    constexpr int PASSES = (32 + RPP - 1) / RPP;
+    const bool ep_lane = lane < RPP * LPR;
     const int c8 = (lane % LPR) * 8;
     const int n = n0 + wn * C::TN + c8;
     float bias8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-    if (fl & GEMM_BIAS) {
+    if ((fl & GEMM_BIAS) && ep_lane) {
         f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + n), b1 = *reinterpret_cast<const f32x4*>(a.bias + n + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
+    // the staging region is wave-private and LDS operations of one wave execute in order: no barrier inside the loop
 #pragma unroll
     for (int ch = 0; ch < C::TM / 32; ++ch) {
-        if (ch) __syncthreads();                   // previous chunk fully read before it is overwritten
+        // compiler-level ordering only (other lanes of this wave read what this lane writes): keep chunk ch's reads
+        // above chunk ch+1's writes and the writes above the reads; no instruction is emitted
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int j = 0; j < C::FN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ep[(ii * 16 + (lane >> 4) * 4 + r) * C::EP_LD + j * 16 + (lane & 15)] = acc[ch * 2 + ii][j][r];
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int p = 0; p < 32 / RPP; ++p) {
+        for (int p = 0; p < PASSES; ++p) {
             const int row = p * RPP + lane / LPR;
             const int m = m0 + wm * C::TM + ch * 32 + row;
-            if (m >= a.M) continue;
+            if (!ep_lane || row >= 32 || m >= a.M) continue;
             f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + row * C::EP_LD + c8), v1 = *reinterpret_cast<const f32x4*>(ep + row * C::EP_LD + c8 + 4);
             float v[8];
 #pragma unroll
@@ -281,7 +288,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
     }
     auto stage = [&](int buf, int mstep) {
         char* base = smem + buf * C::STAGE;
-        const size_t ao = (size_t)mstep * 64 * P.lda, bo = (size_t)mstep * 64 * P.ldb;
+        const size_t ao = g.accumulate == 2 ? 0 : (size_t)mstep * 64 * P.lda, bo = g.accumulate == 2 ? 0 : (size_t)mstep * 64 * P.ldb;
 #pragma unroll
         for (int i = 0; i < C::AI; ++i)
             __builtin_amdgcn_global_load_lds(MM_GLB(asrc[i] + ao), MM_LDS(base + (w * C::AI + i) * 1024), 16, 0, 0);
@@ -359,7 +366,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
                 const int n = n0 + wn_ * 64 + i * 16 + (lane >> 4) * 4 + r;
                 const int c = c0 + wc_ * 64 + j * 16 + (lane & 15);
                 float* dst = Cp + (size_t)n * P.ldc + c;
-                if (g.accumulate) atomicAdd(dst, acc[i][j][r]);
+                if (g.accumulate == 1) atomicAdd(dst, acc[i][j][r]);
                 else *dst = acc[i][j][r];
             }
 }
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(256) void slow_tn_kernel(GemmTNProblem P, int accum
 // ------------------------------------------------------------------------------------------------ launchers
 static bool nt_fast_ok(const GemmNTArgs& a) {
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    return a.N % 128 == 0 && a.K % BK == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&
+    return (a.N % 128 == 0 || (a.N % 192 == 0 && a.tile >= 6)) && a.K % BK == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&
            (!(a.flags & GEMM_RESIDUAL) || (a.ldres % 8 == 0 && al(a.residual))) &&
            (!(a.flags & GEMM_AUX_PRE) || (a.ldaux % 8 == 0 && al(a.aux))) &&
            (!(a.flags & GEMM_MUL_GELU_GRAD) || (a.ldmul % 8 == 0 && al(a.mul_in))) &&
@@ -470,13 +477,14 @@ static void launch_nt_t(const GemmNTArgs& a, hipStream_t s) {
 }
 
 // tile choice: explicit (a.tile: 1 = 128x128 2-stage, 2 = 256x128 2-stage, 3 = 256x256 2-stage, 4 = 128x128 4-stage ring,
-// 5 = 256x128 3-stage ring) or by a wave-quantisation x intensity score
+// 5 = 256x128 3-stage ring, 6 = 128x192 2-stage, 7 = 256x192 2-stage) or measured rules
 static int choose_nt_tile(const GemmNTArgs& a) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_NT_TILE"); env = e ? atoi(e) : 0; }
     int t = a.tile ? a.tile : env;
     if (t == 3 && a.N % 256) t = 2;
-    if (t >= 1 && t <= 5) return t;
+    if ((t == 6 || t == 7) && a.N % 192) t = 1;
+    if (t >= 1 && t <= 7) return t;
     // measured on MI355X (tools/gemm_bench.py, random bf16): with K = 768..3072 and N <= 3072 the 128x128 tile at two
     // blocks per CU is best or within 5 %; 256x256 wins once K is long and it still fills >= half the CUs.
     const long tiles256 = (long)((a.M + 255) / 256) * (a.N / 256);
@@ -487,6 +495,8 @@ static int choose_nt_tile(const GemmNTArgs& a) {
 template <typename T>
 static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
     switch (choose_nt_tile(a)) {
+        case 7: launch_nt_t<T, 256, 192, 4, 2, 2>(a, s); break;
+        case 6: launch_nt_t<T, 128, 192, 2, 2, 2>(a, s); break;
         case 5: launch_nt_t<T, 256, 128, 4, 2, 3>(a, s); break;
         case 4: launch_nt_t<T, 128, 128, 2, 2, 4>(a, s); break;
         case 3: launch_nt_t<T, 256, 256, 2, 4, 2>(a, s); break;
