@@ -51,8 +51,10 @@ __device__ __forceinline__ void stage_image(char* img, const T* src, int ld, int
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+// NW waves per (post, head); wave w takes query tiles w, w+NW, ...  Online soft-max over the key tiles keeps one 32x32
+// score tile live at a time (~100 VGPRs -> 4 waves per SIMD) instead of all of them (490 VGPRs, 1 wave per SIMD).
+template <typename T, int NKT, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
@@ -64,9 +66,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int head = blockIdx.x, post = blockIdx.y;
     const int S = a.S;
     const T* base = (const T*)a.qkv + (size_t)post * S * a.ld_qkv + head * HD;
-    stage_image<T>(Kimg, base + a.hidden, a.ld_qkv, S, SP, false, tid, 256);
-    stage_image<T>(Vimg, base + 2 * a.hidden, a.ld_qkv, S, SP, true, tid, 256);
-    for (int k = tid; k < SP; k += 256) {
+    stage_image<T>(Kimg, base + a.hidden, a.ld_qkv, S, SP, false, tid, NW * 64);
+    stage_image<T>(Vimg, base + 2 * a.hidden, a.ld_qkv, S, SP, true, tid, NW * 64);
+    for (int k = tid; k < SP; k += NW * 64) {
         float b = (k < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f) : -INFINITY;
         mb[k] = b * LOG2E;
     }
@@ -74,62 +76,62 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int r = lane & 31, h2 = lane >> 5;
     const float sc = a.scale * LOG2E;
     const int nqt = (S + 31) / 32;
-    for (int qt = w; qt < nqt; qt += 4) {
-        const int qrow = min(qt * 32 + r, S - 1);
+    const bool dropping = a.drop.thresh16 != 0;
+    for (int qt = w; qt < nqt; qt += NW) {
+        const int q = qt * 32 + r;
+        const int qrow = min(q, S - 1);
         const T* qp = base + (size_t)qrow * a.ld_qkv + 8 * h2;
         v8 qf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const v8*>(qp + 16 * s);
-        // S^T tiles: acc[kt][reg] = score(key = kt*32 + (reg&3) + 8*(reg>>2) + 4*h2, query = qt*32 + r)
-        f32x16 acc[NKT];
-#pragma unroll
+        const uint32_t ebase = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)qrow) * (uint32_t)S;
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x16 oacc[2] = {f32x16{}, f32x16{}};
+#pragma unroll 1
         for (int kt = 0; kt < NKT; ++kt) {
-            acc[kt] = f32x16{};
+            // S^T tile: acc[reg] = score(key = kt*32 + (reg&3) + 8*(reg>>2) + 4*h2, query q)
+            f32x16 acc = f32x16{};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 v8 kf = lds_read8<T>(Kimg, rowimg_off(kt * 32 + r, 2 * s + h2));
-                acc[kt] = mfma32(kf, qf[s], acc[kt]);
+                acc = mfma32(kf, qf[s], acc);
             }
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+            float tmax = -INFINITY;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 b = *reinterpret_cast<const f32x4*>(mb + kt * 32 + 8 * g + 4 * h2);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = acc[kt][4 * g + e] * sc + b[e];
-                    acc[kt][4 * g + e] = v;
-                    mx = fmaxf(mx, v);
+                    const float v = acc[4 * g + e] * sc + b[e];
+                    acc[4 * g + e] = v;
+                    tmax = fmaxf(tmax, v);
                 }
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);
+            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;        // a fully masked tile contributes nothing
+            const float alpha = exp2f(m_run - m_safe);                      // first tile: exp2(-inf) = 0
+            float psum = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float p = exp2f(acc[kt][e] - mx);
-                acc[kt][e] = p;
-                sum += p;
+                const float p = exp2f(acc[e] - m_safe);
+                acc[e] = p;
+                psum += p;
             }
-        sum += __shfl_xor(sum, 32);
-        const int q = qt * 32 + r;
-        if (a.lse && h2 == 0 && q < S) a.lse[((size_t)post * a.heads + head) * S + q] = (mx + log2f(sum)) * (1.0f / LOG2E);
-        const float inv = 1.0f / sum;
-        const bool dropping = a.drop.thresh16 != 0;
-        const uint32_t ebase = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)min(q, S - 1)) * (uint32_t)S;
-        f32x16 oacc[2] = {f32x16{}, f32x16{}};
+            psum += __shfl_xor(psum, 32);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 v8 pf;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int reg = 8 * s2 + j;
-                    float p = acc[kt][reg] * inv;
+                    float p = acc[reg];
                     if (dropping) {
                         const int key = kt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
                         p = mm_keep(ebase + (uint32_t)key, a.drop) ? p * a.drop.keep_scale : 0.f;
@@ -143,7 +145,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 }
             }
         }
-        // oacc[dt][reg] = O(query q, d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h2)
+        if (a.lse && h2 == 0 && q < S) a.lse[((size_t)post * a.heads + head) * S + q] = (m_run + log2f(l_run)) * (1.0f / LOG2E);
+        const float inv = 1.0f / l_run;
+        // oacc[dt][reg] = O(query q, d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h2), still to be divided by the soft-max sum
         if (q < S) {
             T* op = (T*)a.ctx + ((size_t)post * S + q) * a.ld_ctx + head * HD;
 #pragma unroll
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 for (int g = 0; g < 4; ++g) {
                     v4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = from_f<T>(oacc[dt][4 * g + e]);
+                    for (int e = 0; e < 4; ++e) o[e] = from_f<T>(oacc[dt][4 * g + e] * inv);
                     *reinterpret_cast<v4*>(op + dt * 32 + 8 * g + 4 * h2) = o;
                 }
         }
@@ -321,19 +325,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-template <typename T, int NKT>
+template <typename T, int NKT, int NW>
 static void launch_fwd_t(const AttnArgs& a, hipStream_t s) {
     const int lds = 2 * NKT * 32 * 128 + NKT * 32 * 4;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
-    hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), dim3(a.heads, a.posts), dim3(256), lds, s, a);
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+    hipLaunchKernelGGL((attn_fwd_kernel<T, NKT, NW>), dim3(a.heads, a.posts), dim3(NW * 64), lds, s, a);
 }
 template <typename T>
 static hipError_t launch_fwd_d(const AttnArgs& a, hipStream_t s) {
-    if (a.S <= 32) launch_fwd_t<T, 1>(a, s);
-    else if (a.S <= 64) launch_fwd_t<T, 2>(a, s);
-    else if (a.S <= 128) launch_fwd_t<T, 4>(a, s);
-    else if (a.S <= 224) launch_fwd_t<T, 7>(a, s);
+    if (a.S <= 32) launch_fwd_t<T, 1, 1>(a, s);
+    else if (a.S <= 64) launch_fwd_t<T, 2, 2>(a, s);
+    else if (a.S <= 128) launch_fwd_t<T, 4, 4>(a, s);
+    else if (a.S <= 224) launch_fwd_t<T, 7, 8>(a, s);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -305,17 +305,12 @@ SmallGemmArgs small(const void* A, int lda, const float* W, int ldw, const float
 
 // ------------------------------------------------------------------------------------------------ weights
 int refresh_layer(mmhip_engine& e, const float* base, const LayerOff& o, const LayerW16& w, bool transposed, hipStream_t s) {
-    const int H = e.cfg.hidden, I = e.cfg.inter, dt = e.dt();
-    CHECK_HIP(launch_cast(base + o.qkv_w, e.ws + w.qkv, (size_t)3 * H * H, dt, s));
-    CHECK_HIP(launch_cast(base + o.ao_w, e.ws + w.ao, (size_t)H * H, dt, s));
-    CHECK_HIP(launch_cast(base + o.fc1_w, e.ws + w.fc1, (size_t)I * H, dt, s));
-    CHECK_HIP(launch_cast(base + o.fc2_w, e.ws + w.fc2, (size_t)H * I, dt, s));
-    if (transposed) {
-        CHECK_HIP(launch_cast_transpose(base + o.qkv_w, e.ws + w.qkvT, 3 * H, H, dt, s));
-        CHECK_HIP(launch_cast_transpose(base + o.ao_w, e.ws + w.aoT, H, H, dt, s));
-        CHECK_HIP(launch_cast_transpose(base + o.fc1_w, e.ws + w.fc1T, I, H, dt, s));
-        CHECK_HIP(launch_cast_transpose(base + o.fc2_w, e.ws + w.fc2T, H, I, dt, s));
-    }
+    const int H = e.cfg.hidden, I = e.cfg.inter;
+    CastMat m[4] = {{base + o.qkv_w, e.ws + w.qkv, transposed ? e.ws + w.qkvT : nullptr, 3 * H, H, 0},
+                    {base + o.ao_w, e.ws + w.ao, transposed ? e.ws + w.aoT : nullptr, H, H, 0},
+                    {base + o.fc1_w, e.ws + w.fc1, transposed ? e.ws + w.fc1T : nullptr, I, H, 0},
+                    {base + o.fc2_w, e.ws + w.fc2, transposed ? e.ws + w.fc2T : nullptr, H, I, 0}};
+    CHECK_HIP(launch_cast_group(m, 4, e.dt(), s));
     return 0;
 }
 

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void slow_tn_kernel(GemmTNProblem P, int accum
 // ------------------------------------------------------------------------------------------------ launchers
 static bool nt_fast_ok(const GemmNTArgs& a) {
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    return (a.N % 128 == 0 || (a.N % 192 == 0 && a.tile >= 6)) && a.K % BK == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&
+    return (a.N % 128 == 0 || a.N % 192 == 0) && a.K % BK == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&
            (!(a.flags & GEMM_RESIDUAL) || (a.ldres % 8 == 0 && al(a.residual))) &&
            (!(a.flags & GEMM_AUX_PRE) || (a.ldaux % 8 == 0 && al(a.aux))) &&
            (!(a.flags & GEMM_MUL_GELU_GRAD) || (a.ldmul % 8 == 0 && al(a.mul_in))) &&
@@ -483,13 +483,24 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if (env < 0) { const char* e = getenv("MMHIP_NT_TILE"); env = e ? atoi(e) : 0; }
     int t = a.tile ? a.tile : env;
     if (t == 3 && a.N % 256) t = 2;
-    if ((t == 6 || t == 7) && a.N % 192) t = 1;
+    if ((t == 6 || t == 7) && a.N % 192) t = 0;
+    if ((t >= 1 && t <= 5) && a.N % 128) t = 0;
     if (t >= 1 && t <= 7) return t;
-    // measured on MI355X (tools/gemm_bench.py, random bf16): with K = 768..3072 and N <= 3072 the 128x128 tile at two
-    // blocks per CU is best or within 5 %; 256x256 wins once K is long and it still fills >= half the CUs.
-    const long tiles256 = (long)((a.M + 255) / 256) * (a.N / 256);
-    if (a.N % 256 == 0 && a.K >= 2048 && tiles256 >= 128) return 3;
-    return 1;
+    if (a.N % 128 && a.N % 192 == 0 && a.N % 256) { /* only the 192-wide tiles divide N */ }
+    // The kernels are bound by the per-CU LDS-DMA fill rate (profiles/r01_*): rank the tiles by the bytes one CU stages
+    // per k-step = ceil(tiles / 256 CUs) * (BM + BN), with penalties calibrated on tools/gemm_bench.py for the tiles
+    // that run one 8-wave block per CU (no second block to overlap barriers with).
+    struct Cand { int id, bm, bn; double pen; };
+    const Cand cands[4] = {{1, 128, 128, 1.0}, {6, 128, 192, 1.0}, {7, 256, 192, 1.15}, {3, 256, 256, 1.45}};
+    int best = 1;
+    double best_cost = 1e30;
+    for (const Cand& c : cands) {
+        if (a.N % c.bn) continue;
+        const long tiles = (long)((a.M + c.bm - 1) / c.bm) * (a.N / c.bn);
+        const double cost = (double)((tiles + 255) / 256) * (c.bm + c.bn) * c.pen;
+        if (cost < best_cost * 0.999) { best_cost = cost; best = c.id; }
+    }
+    return best;
 }
 
 template <typename T>

@@ -112,6 +112,10 @@ hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, 
 size_t partial_floats_rows(int rows, int width, int nvec);
 size_t partial_floats_colsum(int rows, int cols);
 hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s);
+static constexpr int CAST_MAX_GROUP = 4;
+struct CastMat { const float* src; void* dst; void* dstT; int rows, cols, tile_start; };
+struct CastGroup { CastMat m[CAST_MAX_GROUP]; int count; };
+hipError_t launch_cast_group(const CastMat* mats, int count, int dtype, hipStream_t s);   // dst = cast(src), dstT = cast(src)^T (optional)
 hipError_t launch_cast_transpose(const float* src, void* dst, int rows, int cols, int dtype, hipStream_t s);   // dst[c][r] = src[r][c]
 hipError_t launch_gather_rows_f32(const void* src, size_t src_stride, float* out, int ldo, int rows, int H, int dtype, hipStream_t s);
 hipError_t launch_dropout16(const void* src, void* dst, size_t n, const DropCfg& d, int dtype, hipStream_t s);

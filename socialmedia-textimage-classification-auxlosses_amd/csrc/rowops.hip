@@ -438,6 +438,40 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
         if (r0 + r < rows && c0 + c < cols) dst[(size_t)(c0 + c) * rows + r0 + r] = from_f<T>(tile[r][c]);
     }
 }
+// grouped weight refresh: for each matrix of the group read every fp32 64x64 tile once, write the 16-bit copy and
+// (optionally) the transposed 16-bit copy -- one launch per layer instead of eight
+template <typename T>
+__global__ __launch_bounds__(256) void cast_dual_kernel(CastGroup g) {
+    __shared__ float tile[64][65];
+    int id = blockIdx.x, pi = 0;
+#pragma unroll
+    for (int i = 1; i < CAST_MAX_GROUP; ++i)
+        if (i < g.count && id >= g.m[i].tile_start) pi = i;
+    const CastMat& M = g.m[pi];
+    id -= M.tile_start;
+    const int tc = (M.cols + 63) / 64;
+    const int r0 = (id / tc) * 64, c0 = (id % tc) * 64;
+    T* dst = (T*)M.dst;
+    T* dstT = (T*)M.dstT;
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {          // 16 float4 per row
+        const int r = i >> 4, c = (i & 15) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < M.rows && c0 + c < M.cols) {
+            load4<float>(M.src + (size_t)(r0 + r) * M.cols + c0 + c, v);
+            store4<T>(dst + (size_t)(r0 + r) * M.cols + c0 + c, v);
+        }
+        tile[r][c] = v[0]; tile[r][c + 1] = v[1]; tile[r][c + 2] = v[2]; tile[r][c + 3] = v[3];
+    }
+    if (!dstT) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+        const int c = i >> 4, r = (i & 15) * 4;
+        if (c0 + c < M.cols && r0 + r < M.rows) {
+            float v[4] = {tile[r][c], tile[r + 1][c], tile[r + 2][c], tile[r + 3][c]};
+            store4<T>(dstT + (size_t)(c0 + c) * M.rows + r0 + r, v);
+        }
+    }
+}
 // dx[post*T + t][:] = (t == 0) ? d[post][:] : 0        (gradient of the last hidden state: only CLS rows are read)
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restrict__ d, T* __restrict__ dx, int posts, int Tn, int H) {
@@ -571,6 +605,22 @@ hipError_t launch_cast_transpose(const float* src, void* dst, int rows, int cols
     dim3 grid((cols + 63) / 64, (rows + 63) / 64);
     if (dtype == DT_BF16) hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, rows, cols);
     else hipLaunchKernelGGL(cast_transpose_kernel<f16_t>, grid, dim3(256), 0, s, src, (f16_t*)dst, rows, cols);
+    return hipGetLastError();
+}
+hipError_t launch_cast_group(const CastMat* mats, int count, int dtype, hipStream_t s) {
+    CastGroup g;
+    g.count = 0;
+    int tiles = 0;
+    for (int i = 0; i < count && i < CAST_MAX_GROUP; ++i) {
+        CastMat m = mats[i];
+        if (m.rows % 4 || m.cols % 4) return hipErrorInvalidValue;
+        m.tile_start = tiles;
+        tiles += ((m.rows + 63) / 64) * ((m.cols + 63) / 64);
+        g.m[g.count++] = m;
+    }
+    if (!tiles) return hipSuccess;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(cast_dual_kernel<bf16_t>, dim3(tiles), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(cast_dual_kernel<f16_t>, dim3(tiles), dim3(256), 0, s, g);
     return hipGetLastError();
 }
 hipError_t launch_dropout16(const void* src, void* dst, size_t n, const DropCfg& d, int dtype, hipStream_t s) {
