@@ -9,6 +9,23 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _cpu_share():
+    """threads to use for CPU reference math: the process's CPU share, not the host's core count (a GPU box shows
+    256 logical CPUs but grants ~16; oversubscribing torch's thread pool makes the references 10x slower)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+try:
+    import torch
+    torch.set_num_threads(_cpu_share())
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

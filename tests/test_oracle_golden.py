@@ -9,7 +9,6 @@ import torch
 
 from oracle import mm_oracle as O
 
-torch.set_num_threads(max(1, os.cpu_count() or 1))
 
 
 def load(golden_dir, name):
