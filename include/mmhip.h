@@ -86,12 +86,21 @@ int mmhip_loss(mmhip_handle h, const int64_t* onehot, const float* class_w, cons
  * (which must be zero where a fresh gradient is wanted).  Pass NULL pointers to use the gradients mmhip_loss left in
  * the handle, or explicit fp32 output gradients (autograd binding).  Stages let a data-parallel caller start the
  * all-reduce of finished parameter ranges while later stages run: stage 0 = heads, 1..layers_txt = text layers
- * last -> first, layers_txt+1 = embeddings.  mmhip_backward runs all of them. */
+ * last -> first, layers_txt+1 = embeddings.  mmhip_backward runs all of them and the finish.
+ * Internal concurrency: the engine forks an internal stream from the caller's stream (events) for work that is off the
+ * critical path -- the frozen image tower beside the text tower in mmhip_forward, a layer's parameter gradients beside the
+ * next layer's activation gradients in backward -- and joins it before mmhip_forward returns / in mmhip_backward_finish.
+ * With stages: the gradient range of stage k is final in the caller's stream order once stage k+1 has been enqueued for
+ * k = 0 and for the embeddings stage, and for a text-layer stage once mmhip_backward_finish (or two further stages) has
+ * been enqueued; a caller that wants per-stage exchange calls mmhip_backward_join_stage(k) first. MMHIP_OVERLAP=0 disables. */
 int mmhip_backward(mmhip_handle h, const float* d_out_cls, const float* d_logits_per_text, const float* d_out_tim,
                    const float* d_mm_features, void* stream);
 int mmhip_backward_begin(mmhip_handle h, const float* d_out_cls, const float* d_logits_per_text, const float* d_out_tim,
                          const float* d_mm_features, void* stream);
 int mmhip_backward_stage(mmhip_handle h, int stage, void* stream);
+int mmhip_backward_finish(mmhip_handle h, void* stream);
+/* make the caller's stream wait for the side-stream work of text-layer stage `stage` (no-op for other stages) */
+int mmhip_backward_join_stage(mmhip_handle h, int stage, void* stream);
 int mmhip_num_backward_stages(mmhip_handle h);
 /* element range [begin, end) of the trainable flat buffer whose gradients are final after `stage` */
 int mmhip_stage_grad_range(mmhip_handle h, int stage, uint64_t* begin, uint64_t* end);

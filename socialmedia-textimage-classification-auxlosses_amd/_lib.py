@@ -47,6 +47,8 @@ _SIGS = {
     "mmhip_backward": (I, [P, P, P, P, P, P]),
     "mmhip_backward_begin": (I, [P, P, P, P, P, P]),
     "mmhip_backward_stage": (I, [P, I, P]),
+    "mmhip_backward_finish": (I, [P, P]),
+    "mmhip_backward_join_stage": (I, [P, I, P]),
     "mmhip_num_backward_stages": (I, [P]),
     "mmhip_stage_grad_range": (I, [P, I, C.POINTER(U64), C.POINTER(U64)]),
     "mmhip_adamw": (I, [P, P, P, P, U64, F, F, F, F, F, I, F, I, P]),

@@ -5,6 +5,7 @@
 #include <vector>
 #include <cstring>
 #include <cmath>
+#include <cstdlib>
 #include "mmhip_common.h"
 #include "mmhip_kernels.h"
 #include "../../include/mmhip.h"
@@ -52,7 +53,8 @@ struct mmhip_engine {
     std::vector<TextAct> tact;
     size_t ids_all, mask_all, pos_ids, maskbias, x0, xhat_emb, rstd_emb;
     size_t v_patches, v_pe, v_x, v_ln, v_qkv, v_ctx, v_h, v_out;                             // ViT ping-pong
-    size_t g_partial;
+    size_t g_partial, g_partial_side;
+    size_t g_set[2][6];      // double-buffered backward temporaries read by the side stream: dpre2, ddrop2, du, dpre1, ddrop1, dqkv
     size_t g_dx, g_dx2, g_dpre, g_ddrop, g_dpre1, g_ddrop1, g_dqkv, g_dctx, g_du;                               // backward temporaries
     // heads (fp32) ----------------------------------------------------------------------
     size_t h_vpool, h_tpool, h_txt_e, h_img_e, h_txt_n, h_img_n, h_txt_inv, h_img_inv, h_logits;
@@ -63,6 +65,11 @@ struct mmhip_engine {
     int B = 0, T = 0, Bt = 0; bool itm = false, train_mode = false, fwd_done = false, bwd_begun = false;
     uint64_t seed = 0;
     const float *bd_out_cls = nullptr, *bd_logits = nullptr, *bd_out_tim = nullptr, *bd_feats = nullptr;
+    // internal side stream (ViT forward beside the text forward; weight gradients beside the dX chain) -------------
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_vit = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_tn[2] = {nullptr, nullptr};
+    bool tn_pending[2] = {false, false};
+    int overlap = -1;          // -1 = read MMHIP_OVERLAP on first use
     // GEMM timing ----------------------------------------------------------------------
     bool timing = false;
     struct Ev { hipEvent_t a, b; double flops; };
@@ -234,9 +241,13 @@ void build_workspace(mmhip_engine& e) {
     e.v_h = w.take(Mv * I * 2); e.v_out = w.take(Mv * H * 2);
     e.g_dx = w.take(Mt * H * 2); e.g_dx2 = w.take(Mt * H * 2); e.g_dpre = w.take(Mt * H * 2); e.g_ddrop = w.take(Mt * H * 2); e.g_dpre1 = w.take(Mt * H * 2); e.g_ddrop1 = w.take(Mt * H * 2);
     e.g_dqkv = w.take(Mt * 3 * H * 2); e.g_dctx = w.take(Mt * H * 2); e.g_du = w.take(Mt * I * 2);
+    e.g_set[0][0] = e.g_dpre; e.g_set[0][1] = e.g_ddrop; e.g_set[0][2] = e.g_du; e.g_set[0][3] = e.g_dpre1; e.g_set[0][4] = e.g_ddrop1; e.g_set[0][5] = e.g_dqkv;
+    e.g_set[1][0] = w.take(Mt * H * 2); e.g_set[1][1] = w.take(Mt * H * 2); e.g_set[1][2] = w.take(Mt * I * 2);
+    e.g_set[1][3] = w.take(Mt * H * 2); e.g_set[1][4] = w.take(Mt * H * 2); e.g_set[1][5] = w.take(Mt * 3 * H * 2);
     {
         size_t pf = partial_floats_rows((int)Mt, (int)H, 3), pc = partial_floats_colsum((int)Mt, (int)(3 * H > I ? 3 * H : I));
         e.g_partial = w.take((pf > pc ? pf : pc) * 4);
+        e.g_partial_side = w.take((pf > pc ? pf : pc) * 4);
     }
     auto f = [&](size_t n) { return w.take(n * 4); };
     e.h_vpool = f(Bm * H); e.h_tpool = f(Bm * H); e.h_txt_e = f(Bm * E); e.h_img_e = f(Bm * E); e.h_txt_n = f(Bm * E); e.h_img_n = f(Bm * E);
@@ -302,6 +313,17 @@ SmallGemmArgs small(const void* A, int lda, const float* W, int ldw, const float
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.act = act; a.accumulate = acc;
     return a;
 }
+
+// ------------------------------------------------------------------------------------------------ side stream
+int side_init(mmhip_engine& e) {
+    if (e.overlap < 0) { const char* v = getenv("MMHIP_OVERLAP"); e.overlap = v ? atoi(v) : 1; }
+    if (!e.overlap || e.side) return 0;
+    CHECK_HIP(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
+    hipEvent_t* evs[6] = {&e.ev_fork, &e.ev_vit, &e.ev_ready[0], &e.ev_ready[1], &e.ev_tn[0], &e.ev_tn[1]};
+    for (auto ev : evs) CHECK_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    return 0;
+}
+inline bool use_side(const mmhip_engine& e) { return e.overlap > 0 && e.side && !e.timing; }
 
 // ------------------------------------------------------------------------------------------------ weights
 int refresh_layer(mmhip_engine& e, const float* base, const LayerOff& o, const LayerW16& w, bool transposed, hipStream_t s) {
@@ -520,8 +542,17 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     const TextAct& a = e.tact[l];
     const char* x_in = l ? e.ws + e.tact[l - 1].out : e.ws + e.x0;
     const bool tr = e.train_mode;
-    char *dx = e.ws + e.g_dx, *dpre2 = e.ws + e.g_dpre, *ddrop2 = e.ws + e.g_ddrop, *dpre1 = e.ws + e.g_dpre1, *ddrop1 = e.ws + e.g_ddrop1;
-    char *du = e.ws + e.g_du, *dx2 = e.ws + e.g_dx2, *dctx = e.ws + e.g_dctx, *dqkv = e.ws + e.g_dqkv;
+    // temporaries that the weight-gradient GEMMs read are double-buffered per layer parity so that the side stream may
+    // still be consuming layer l's set while the main stream runs layer l-1 on the other one
+    const int set = l & 1;
+    const bool side = use_side(e);
+    char *dx = e.ws + e.g_dx, *dx2 = e.ws + e.g_dx2, *dctx = e.ws + e.g_dctx;
+    char *dpre2 = e.ws + e.g_set[set][0], *ddrop2 = e.ws + e.g_set[set][1], *du = e.ws + e.g_set[set][2];
+    char *dpre1 = e.ws + e.g_set[set][3], *ddrop1 = e.ws + e.g_set[set][4], *dqkv = e.ws + e.g_set[set][5];
+    if (side && e.tn_pending[set]) {           // the set was last read by layer l+2's side work
+        CHECK_HIP(hipStreamWaitEvent(s, e.ev_tn[set], 0));
+        e.tn_pending[set] = false;
+    }
     // ---- x' = LN2(pre2), pre2 = drop(fc2(h)) + a1
     LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mt, H, e.wsp<float>(e.g_partial)};
     CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
@@ -531,8 +562,6 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
     { G g(df, H, e.ws + w.fc2T, H, du, I, Mt, I, H); g.mul_gelu_grad(e.ws + a.u, I); if (int r = run_gemm(e, g, s)) return r; }
     { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mt, H, I); g.residual(dpre2, H); if (int r = run_gemm(e, g, s)) return r; }
-    CHECK_HIP(launch_colsum(df, Mt, H, H, Gd + o.fc2_b, dt, s, e.wsp<float>(e.g_partial)));
-    CHECK_HIP(launch_colsum(du, Mt, I, I, Gd + o.fc1_b, dt, s, e.wsp<float>(e.g_partial)));
     // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
     LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mt, H, e.wsp<float>(e.g_partial)};
     CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
@@ -540,7 +569,6 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     const char* dout = dpre1;
     if (d_ao.thresh16) { CHECK_HIP(launch_dropout16(dpre1, ddrop1, (size_t)Mt * H, d_ao, dt, s)); dout = ddrop1; }
     { G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H); if (int r = run_gemm(e, g, s)) return r; }
-    CHECK_HIP(launch_colsum(dout, Mt, H, H, Gd + o.ao_b, dt, s, e.wsp<float>(e.g_partial)));
     AttnBwdArgs ab;
     memset(&ab, 0, sizeof(ab));
     ab.qkv = e.ws + a.qkv; ab.maskbias = e.wsp<float>(e.maskbias); ab.ctx = e.ws + a.ctx; ab.dctx = dctx; ab.lse = e.wsp<float>(a.lse);
@@ -548,15 +576,41 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     ab.scale = 1.0f / sqrtf((float)(H / c.heads));
     ab.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
     CHECK_HIP(launch_attn_bwd(ab, dt, s));
+    // ---- parameter gradients of the layer: off the critical path -> side stream (bias column sums + all four weight
+    // gradients in one grouped launch: 432 tiles of 128x128, no split-K, plain stores)
+    hipStream_t ps = s;
+    float* partial = e.wsp<float>(e.g_partial);
+    if (side) {
+        CHECK_HIP(hipEventRecord(e.ev_ready[set], s));
+        CHECK_HIP(hipStreamWaitEvent(e.side, e.ev_ready[set], 0));
+        ps = e.side;
+        partial = e.wsp<float>(e.g_partial_side);
+    }
     { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.residual(dpre1, H); if (int r = run_gemm(e, g, s)) return r; }
-    CHECK_HIP(launch_colsum(dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, s, e.wsp<float>(e.g_partial)));
-    // ---- all four weight gradients of the layer in one grouped launch (432 tiles of 128x128, no split-K, plain stores)
+    CHECK_HIP(launch_colsum(df, Mt, H, H, Gd + o.fc2_b, dt, ps, partial));
+    CHECK_HIP(launch_colsum(du, Mt, I, I, Gd + o.fc1_b, dt, ps, partial));
+    CHECK_HIP(launch_colsum(dout, Mt, H, H, Gd + o.ao_b, dt, ps, partial));
+    CHECK_HIP(launch_colsum(dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, ps, partial));
     GemmTNProblem pr[4];
     pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mt, H, I, H, I, I, 0};          // dW2[H,I]   = df^T h
     pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mt, I, H, I, H, H, 0};         // dW1[I,H]   = du^T a1
     pr[2] = GemmTNProblem{dqkv, x_in, Gd + o.qkv_w, Mt, 3 * H, H, 3 * H, H, H, 0};      // dWqkv[3H,H] = dqkv^T x_in
     pr[3] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mt, H, H, H, H, H, 0};       // dWo[H,H]   = dout^T ctx
-    CHECK_HIP(launch_gemm_tn(pr, 4, 0, dt, 0, s));
+    CHECK_HIP(launch_gemm_tn(pr, 4, 0, dt, 0, ps));
+    if (side) {
+        CHECK_HIP(hipEventRecord(e.ev_tn[set], e.side));
+        e.tn_pending[set] = true;
+    }
+    return 0;
+}
+
+// join the side stream: after this, every gradient is final in the caller's stream order
+int backward_finish(mmhip_engine& e, hipStream_t s) {
+    for (int set = 0; set < 2; ++set)
+        if (e.tn_pending[set]) {
+            CHECK_HIP(hipStreamWaitEvent(s, e.ev_tn[set], 0));
+            e.tn_pending[set] = false;
+        }
     return 0;
 }
 
@@ -605,6 +659,12 @@ int mmhip_create(const mmhip_config* cfg, mmhip_handle* out) {
 }
 void mmhip_destroy(mmhip_handle h) {
     if (!h) return;
+    if (h->side) {
+        (void)hipStreamSynchronize(h->side);
+        for (hipEvent_t ev : {h->ev_fork, h->ev_vit, h->ev_ready[0], h->ev_ready[1], h->ev_tn[0], h->ev_tn[1]})
+            if (ev) (void)hipEventDestroy(ev);
+        (void)hipStreamDestroy(h->side);
+    }
     for (auto& ev : h->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     delete h;
 }
@@ -657,8 +717,19 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
         CHECK_HIP(hipMemcpyAsync(e.ws + e.ids_all + nb, tim_ids, nb, hipMemcpyDeviceToDevice, s));
         CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all + nb, tim_mask, nb, hipMemcpyDeviceToDevice, s));
     }
-    if (int r = vit_forward(e, pixels, s)) return r;
-    if (int r = text_forward(e, s)) return r;
+    if (int r = side_init(e)) return r;
+    if (use_side(e)) {
+        // the frozen image tower does not depend on the text tower: run it on the side stream, join before the heads
+        CHECK_HIP(hipEventRecord(e.ev_fork, s));
+        CHECK_HIP(hipStreamWaitEvent(e.side, e.ev_fork, 0));
+        if (int r = vit_forward(e, pixels, e.side)) return r;
+        CHECK_HIP(hipEventRecord(e.ev_vit, e.side));
+        if (int r = text_forward(e, s)) return r;
+        CHECK_HIP(hipStreamWaitEvent(s, e.ev_vit, 0));
+    } else {
+        if (int r = vit_forward(e, pixels, s)) return r;
+        if (int r = text_forward(e, s)) return r;
+    }
     if (int r = heads_forward(e, out_cls, logits_per_text, out_tim, mm_features, s)) return r;
     e.fwd_done = true;
     return 0;
@@ -711,7 +782,8 @@ int mmhip_backward_begin(mmhip_handle h, const float* d_out_cls, const float* d_
         return MMHIP_E_STATE;      // no mmhip_loss before, and no explicit gradients
     }
     e.bwd_begun = true;
-    return 0;
+    e.tn_pending[0] = e.tn_pending[1] = false;
+    return side_init(e);
 }
 int mmhip_backward_stage(mmhip_handle h, int stage, void* stream) {
     if (!h || !h->bwd_begun) return MMHIP_E_STATE;
@@ -723,12 +795,28 @@ int mmhip_backward_stage(mmhip_handle h, int stage, void* stream) {
     if (stage == L + 1) return embed_backward(e, s);
     return MMHIP_E_INVALID;
 }
+int mmhip_backward_join_stage(mmhip_handle h, int stage, void* stream) {
+    if (!h || !h->bwd_begun) return MMHIP_E_STATE;
+    mmhip_engine& e = *h;
+    const int L = e.cfg.layers_txt;
+    if (stage < 1 || stage > L) return 0;
+    const int set = (L - stage) & 1;
+    if (e.tn_pending[set]) {
+        CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, e.ev_tn[set], 0));
+        e.tn_pending[set] = false;
+    }
+    return 0;
+}
+int mmhip_backward_finish(mmhip_handle h, void* stream) {
+    if (!h || !h->bwd_begun) return MMHIP_E_STATE;
+    return backward_finish(*h, (hipStream_t)stream);
+}
 int mmhip_backward(mmhip_handle h, const float* d_out_cls, const float* d_logits, const float* d_out_tim, const float* d_feats, void* stream) {
     if (int r = mmhip_backward_begin(h, d_out_cls, d_logits, d_out_tim, d_feats, stream)) return r;
     const int n = mmhip_num_backward_stages(h);
     for (int st = 0; st < n; ++st)
         if (int r = mmhip_backward_stage(h, st, stream)) return r;
-    return 0;
+    return mmhip_backward_finish(h, stream);
 }
 
 int mmhip_adamw(float* p, float* g, float* m, float* v, uint64_t n, float lr, float beta1, float beta2, float eps,

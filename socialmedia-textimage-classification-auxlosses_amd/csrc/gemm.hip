@@ -487,20 +487,12 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if ((t >= 1 && t <= 5) && a.N % 128) t = 0;
     if (t >= 1 && t <= 7) return t;
     if (a.N % 128 && a.N % 192 == 0 && a.N % 256) { /* only the 192-wide tiles divide N */ }
-    // The kernels are bound by the per-CU LDS-DMA fill rate (profiles/r01_*): rank the tiles by the bytes one CU stages
-    // per k-step = ceil(tiles / 256 CUs) * (BM + BN), with penalties calibrated on tools/gemm_bench.py for the tiles
-    // that run one 8-wave block per CU (no second block to overlap barriers with).
-    struct Cand { int id, bm, bn; double pen; };
-    const Cand cands[4] = {{1, 128, 128, 1.0}, {6, 128, 192, 1.0}, {7, 256, 192, 1.15}, {3, 256, 256, 1.45}};
-    int best = 1;
-    double best_cost = 1e30;
-    for (const Cand& c : cands) {
-        if (a.N % c.bn) continue;
-        const long tiles = (long)((a.M + c.bm - 1) / c.bm) * (a.N / c.bn);
-        const double cost = (double)((tiles + 255) / 256) * (c.bm + c.bn) * c.pen;
-        if (cost < best_cost * 0.999) { best_cost = cost; best = c.id; }
-    }
-    return best;
+    // Measured inside the training step (bench.py with MMHIP_NT_TILE forced, profiles/r01_tile_sweep.txt): 128x128 at two
+    // blocks per CU is as fast as any other tile for every shape of this model; the isolated micro-benchmark gains of the
+    // 192-wide tiles (tools/gemm_bench.py) do not survive the cold caches between dependent kernels.  The wider tiles
+    // stay selectable (a.tile / MMHIP_NT_TILE) and serve N that only 192 divides.
+    if (a.N % 128 == 0) return 1;
+    return 6;
 }
 
 template <typename T>
@@ -537,11 +529,12 @@ static void launch_tn_t(const GemmTNGroup& g, int tiles, hipStream_t s) {
     hipLaunchKernelGGL((gemm_tn_kernel<T, BNN, BNC, WN, WC, NS>), dim3(tiles), dim3(C::NTHR), C::LDS, s, g);
 }
 
-// variant: 1 = 128x128 2-stage, 2 = 128x128 4-stage ring, 3 = 256x128 3-stage ring (default); env MMHIP_TN_TILE overrides
+// variant: 1 = 128x128 2-stage (default: fastest inside the step with the four dW of a layer grouped, 432 tiles),
+// 2 = 128x128 4-stage ring, 3 = 256x128 3-stage ring; env MMHIP_TN_TILE overrides
 hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_TN_TILE"); env = e ? atoi(e) : 0; }
-    int variant = (force_slow >> 4) ? (force_slow >> 4) : (env ? env : 3);
+    int variant = (force_slow >> 4) ? (force_slow >> 4) : (env ? env : 1);
     force_slow &= 1;
     const int bnn = variant == 3 ? 256 : 128;
     GemmTNGroup g;
