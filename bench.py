@@ -115,7 +115,6 @@ def main():
 
     # ---- extra: forward+backward only (no optimizer / refresh), same batch
     lib, m = _lib.lib(), trainer.model
-    trainer.flush()
     sync()
     t1 = time.perf_counter()
     nfb = max(3, args.steps // 4)
@@ -151,7 +150,7 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("BASELINE config 3: Bernice+ViT-B/16, attention fusion, ITC+ITM, bs=64/GPU" if args.aux else
                                 "BASELINE config 2: Bernice+ViT-B/16, attention fusion, no aux loss, bs=64/GPU"),
-                   "step": "full train step: fwd + loss + bwd + grad exchange + AdamW + weight refresh (the update of step n runs at the start of step n+1, beside its image tower)",
+                   "step": "full train step: fwd + loss + bwd + grad exchange + AdamW + weight refresh",
                    "posts_per_gpu": B, "text_tokens": T, "image": a["image"], "vocab": a["vocab"], "parallelism": f"dp{world}",
                    "weights": "random-init at true shapes"},
         "fwd_bwd_ms": round(fb_ms, 3), "fwd_bwd_posts_per_s": round(world * B / (fb_ms * 1e-3), 1),

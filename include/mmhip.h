@@ -75,12 +75,6 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
                   const int64_t* tim_mask, int B, int T, int train, uint64_t seed, float* out_cls, float* logits_per_text,
                   float* out_tim, float* mm_features, void* stream);
 
-/* ---- optional: enqueue the (frozen) image tower of the NEXT mmhip_forward now, on the engine's side stream, forked from
- * `stream` at this point.  Work enqueued on `stream` afterwards (e.g. the previous step's mmhip_adamw + refresh of the
- * text weights, which the image tower never reads) then runs beside it.  The next mmhip_forward with the same B and the
- * same pixels skips the image tower and joins the prefetched one. */
-int mmhip_prefetch_vision(mmhip_handle h, const float* pixels, int B, void* stream);
-
 /* ---- loss mixing of MMLate_Model.train (models/mm_late.py:471-487) on the outputs of the last forward, fused with its
  * own backward: loss[4] = {total, cls, itc, itm}; the output gradients stay inside the handle for mmhip_backward(NULL...).
  * onehot int64 [B,C] (models/datasets.py one-hot labels), class_w fp32 [C] or NULL (run_mm_late.py:85),

@@ -43,7 +43,6 @@ _SIGS = {
     "mmhip_bind": (I, [P, P, P, P, P, U64]),
     "mmhip_refresh_weights": (I, [P, I, P]),
     "mmhip_forward": (I, [P, P, P, P, P, P, I, I, I, U64, P, P, P, P, P]),
-    "mmhip_prefetch_vision": (I, [P, P, I, P]),
     "mmhip_loss": (I, [P, P, P, P, F, F, F, P, P, P]),
     "mmhip_backward": (I, [P, P, P, P, P, P]),
     "mmhip_backward_begin": (I, [P, P, P, P, P, P]),

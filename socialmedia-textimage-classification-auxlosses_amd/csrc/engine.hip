@@ -69,7 +69,6 @@ struct mmhip_engine {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_vit = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_tn[2] = {nullptr, nullptr};
     bool tn_pending[2] = {false, false};
-    bool vit_prefetched = false; int vit_B = 0;
     int overlap = -1;          // -1 = read MMHIP_OVERLAP on first use
     // GEMM timing ----------------------------------------------------------------------
     bool timing = false;
@@ -719,44 +718,20 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
         CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all + nb, tim_mask, nb, hipMemcpyDeviceToDevice, s));
     }
     if (int r = side_init(e)) return r;
-    const bool pre = e.vit_prefetched && e.vit_B == B;      // mmhip_prefetch_vision already enqueued the image tower
-    e.vit_prefetched = false;
     if (use_side(e)) {
         // the frozen image tower does not depend on the text tower: run it on the side stream, join before the heads
-        if (!pre) {
-            CHECK_HIP(hipEventRecord(e.ev_fork, s));
-            CHECK_HIP(hipStreamWaitEvent(e.side, e.ev_fork, 0));
-            if (int r = vit_forward(e, pixels, e.side)) return r;
-            CHECK_HIP(hipEventRecord(e.ev_vit, e.side));
-        }
-        if (int r = text_forward(e, s)) return r;
-        CHECK_HIP(hipStreamWaitEvent(s, e.ev_vit, 0));
-    } else {
-        if (!pre) { if (int r = vit_forward(e, pixels, s)) return r; }
-        if (int r = text_forward(e, s)) return r;
-    }
-    if (int r = heads_forward(e, out_cls, logits_per_text, out_tim, mm_features, s)) return r;
-    e.fwd_done = true;
-    return 0;
-}
-
-int mmhip_prefetch_vision(mmhip_handle h, const float* pixels, int B, void* stream) {
-    if (!h || !h->ws) return MMHIP_E_STATE;
-    if (!pixels || B < 1) return MMHIP_E_INVALID;
-    mmhip_engine& e = *h;
-    if (B > e.cfg.max_posts) return MMHIP_E_CAPACITY;
-    hipStream_t s = (hipStream_t)stream;
-    if (int r = side_init(e)) return r;
-    e.B = B;
-    if (use_side(e)) {
         CHECK_HIP(hipEventRecord(e.ev_fork, s));
         CHECK_HIP(hipStreamWaitEvent(e.side, e.ev_fork, 0));
         if (int r = vit_forward(e, pixels, e.side)) return r;
         CHECK_HIP(hipEventRecord(e.ev_vit, e.side));
+        if (int r = text_forward(e, s)) return r;
+        CHECK_HIP(hipStreamWaitEvent(s, e.ev_vit, 0));
     } else {
         if (int r = vit_forward(e, pixels, s)) return r;
+        if (int r = text_forward(e, s)) return r;
     }
-    e.vit_prefetched = true; e.vit_B = B;
+    if (int r = heads_forward(e, out_cls, logits_per_text, out_tim, mm_features, s)) return r;
+    e.fwd_done = true;
     return 0;
 }
 

@@ -377,26 +377,14 @@ class MMLate_Model(object):
         self.model = MM_Model(self.num_labels, txt_model_name, img_model_name, config.dropout, fusion_name=fusion_name, **model_kw)
         self.device = self.model.device_
         self._opt = None
-        self._pending = None          # (lr, weight_decay, step) of an optimizer update not yet applied (see train_step)
         self.world = mmdist.world_size()
 
     # ---- checkpoints (reference :343-345, :529-531): plain state_dict with the reference's keys
     def load_saved_model(self, model_path):
-        self.flush()
         self.model.load_state_dict(torch.load(model_path, map_location=self.device))
 
     def save_model(self, model_path):
-        self.flush()
         torch.save(self.model.state_dict(), model_path)
-
-    def flush(self):
-        """apply a deferred optimizer update (train_step leaves the update of step n pending so that it can run beside the
-        image tower of step n+1; anything that reads the weights other than train_step calls this first)"""
-        if self._pending is not None:
-            lr, wd, step = self._pending
-            self._pending = None
-            self._adamw(lr, wd, step)
-            self.model._refresh_weights(2)
 
     # ---- ITM negative sampling, reference :389-414 (same numpy RNG stream: one choice([True, False]) per row and one
     # choice(list(others)) per swapped row; sources are read from the original ids, so swaps do not chain)
@@ -430,14 +418,6 @@ class MMLate_Model(object):
             tim = self.prepare_itm_inputs(ids, mask)
         tim_ids, tim_mask, lbl_tim = tim if tim is not None else (None, None, None)
         m.train()
-        if self._pending is not None:
-            # step n-1's AdamW + weight refresh touch only text / head weights; the frozen image tower of this step does not
-            # read them: start it on the engine's side stream first, then apply the update on this stream beside it
-            px = pixel_values.to(self.device, torch.float32).contiguous()
-            m._ensure(ids.shape[0], ids.shape[1])
-            _lib.check(lib.mmhip_prefetch_vision(m._handle, _lib.ptr(px), ids.shape[0], s), "prefetch_vision")
-            self.flush()
-            pixel_values = px
         m._engine_forward(ids, mask, pixel_values, tim_ids, tim_mask)
         w_cls, w_itc, w_itm = self.loss_weights()
         onehot = onehot.to(self.device, torch.int64).contiguous()
@@ -461,7 +441,8 @@ class MMLate_Model(object):
             works += mmdist.exchange_stage(m, n_stage - 1, n_stage, self.use_clip_loss, self.use_tim_loss)
         for w in works:
             w.wait()
-        self._pending = (lr, weight_decay, step)      # applied at the start of the next train_step / by flush()
+        self._adamw(lr, weight_decay, step)
+        m._refresh_weights(2)
         return loss, ncorr
 
     def _adamw(self, lr, weight_decay, step):
@@ -519,7 +500,6 @@ class MMLate_Model(object):
 
     def eval(self, dataloader, loss_fn=None, tim_loss_fn=None, iadds_loss_fn=None, class_weight=None):
         """reference :534-638: forward without dropout, same loss mix (ITM inputs re-sampled, :565-568), argmax."""
-        self.flush()
         m, lib = self.model, _lib.lib()
         if class_weight is None and loss_fn is not None and getattr(loss_fn, "weight", None) is not None:
             class_weight = loss_fn.weight

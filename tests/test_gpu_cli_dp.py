@@ -61,7 +61,6 @@ sl = slice(rank * B, (rank + 1) * B)
 np.random.seed(30 + rank)
 tim = tr.prepare_itm_inputs(ids[sl].cuda(), mask[sl].cuda())
 loss, _ = tr.train_step(ids[sl].cuda(), mask[sl].cuda(), px[sl], oh[sl], None, 1e-3, 0.00025, 1, tim=tim)
-tr.flush()
 torch.save({"p": tr.model._flat_train.cpu(), "tim": [t.cpu() for t in tim], "loss": loss.cpu()}, os.environ["OUT"] + f"/rank{rank}.pt")
 torch.distributed.barrier()
 if rank == 0:

@@ -207,7 +207,6 @@ def test_trainer_step_and_itm_sampling():
     for step in range(1, 9):
         loss, nc = tr.train_step(ids.cuda(), mask.cuda(), pixels, onehot, None, 1e-3, 0.00025, step)
         losses.append(loss[0].item())
-    tr.flush()          # the last step's optimizer update is deferred (runs beside the next step's image tower)
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     for k, p0 in never.items():
         assert torch.equal(dict(tr.model.named_parameters())[k].detach(), p0), k
