@@ -236,3 +236,66 @@ def test_full_size_properties():
     assert rel_err(c[0], a[0][perm.cuda()]) < 1e-5 and rel_err(c[4], a[4][perm.cuda()]) < 1e-5
     assert rel_err(c[1], a[1][perm.cuda()][:, perm.cuda()]) < 1e-5
     assert torch.equal(d[0], a[0])
+
+
+@pytest.mark.parametrize("B,T,itm", [(3, 50, True), (1, 32, True), (5, 128, False), (2, 7, False)])
+def test_ragged_shapes_match_oracle(B, T, itm):
+    """row counts that are not multiples of any tile (generic GEMM paths, partial attention tiles, B == 1 ITM rule)"""
+    cfg = O.OracleConfig(layers_txt=2, layers_img=1, vocab=400, max_pos=130, num_labels=4, p_hidden=0.0, p_attn=0.0, p_head=0.0)
+    model = build(cfg, "f16", "bernice", B, T)
+    P = O.make_params(cfg, 9)
+    load_oracle_params(model, P)
+    model.train()
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, B, T, 100 + B, True)
+    np.random.seed(30)
+    tim_ids, tim_mask, lbl = O.prepare_itm_inputs(ids, mask)
+    tim = (tim_ids, tim_mask) if itm else None
+    dev = model.device_
+    out_cls, lpt, out_tim, _, feats = model(ids, mask, pixels, tim_inputs=tim)
+    loss = O.mix_loss(out_cls, onehot.to(dev), None, lpt, out_tim, lbl.to(dev), True, itm)
+    loss.backward()
+    Pg = {k: v.clone().requires_grad_(O.trainable(k)) for k, v in P.items()}
+    r = O.mm_forward(Pg, ids, mask, pixels, cfg, tim)
+    ref = O.mix_loss(r[0], onehot, None, r[1], r[2], lbl, True, itm)
+    ref.backward()
+    assert rel_err(out_cls, r[0].detach()) < TOL_OUT["f16"] and rel_err(feats, r[4].detach()) < TOL_OUT["f16"]
+    assert abs(loss.item() - ref.item()) < 1e-3 * abs(ref.item())
+    for k, p in model.named_parameters():
+        if Pg[k].grad is None or k.endswith("key.bias") or k == "fc_K.bias":
+            assert p.grad is None or k.endswith("key.bias") or k == "fc_K.bias", k
+            continue
+        e = (p.grad.cpu() - Pg[k].grad).norm().item() / max(Pg[k].grad.norm().item(), 1e-20)
+        assert e < TOL_GRAD["f16"], (k, e)
+
+
+def test_capacity_growth_param_updates_and_errors():
+    from smtc_amd import _lib
+    cfg = O.OracleConfig(layers_txt=1, layers_img=1, vocab=300, max_pos=130, num_labels=2)
+    model = build(cfg, "bf16", "bernice", 2, 32)
+    model.eval()
+    ids, mask, pixels, _ = O.synthetic_batch(cfg, 6, 64, 3, True)
+    with torch.no_grad():
+        small = model(ids[:2, :32], mask[:2, :32], pixels[:2])[0]
+        big = model(ids, mask, pixels)[0]                    # B and T beyond the creation capacity: workspace is re-made
+        again = model(ids[:2, :32], mask[:2, :32], pixels[:2])[0]
+        assert big.shape == (6, 2) and torch.equal(small, again)
+        # in-place parameter change (what optimizer.step / load_state_dict do) must reach the 16-bit GEMM operands
+        w = dict(model.named_parameters())["dual_encoder.text_model.encoder.layer.0.intermediate.dense.weight"]
+        w.mul_(1.5)
+        changed = model(ids[:2, :32], mask[:2, :32], pixels[:2])[0]
+        assert not torch.equal(changed, small)
+        w.div_(1.5)
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        model.load_state_dict(sd)
+        assert rel_err(model(ids[:2, :32], mask[:2, :32], pixels[:2])[0], small) < 1e-6
+        with pytest.raises(ValueError):
+            model(ids[:2], mask[:2], pixels[:2, :, :200, :200])
+        with pytest.raises(_lib.MMHipError):
+            model(torch.cat([ids, ids, ids], 1)[:2, :160], torch.cat([mask, mask, mask], 1)[:2, :160], pixels[:2])   # T > 128
+    with pytest.raises(NotImplementedError):
+        MM_Model(2, "bernice", "vit", 0.05, "gmu")
+    # train() applies dropout, eval() does not
+    model.train()
+    with torch.no_grad():
+        a, b = model(ids[:2, :32], mask[:2, :32], pixels[:2])[0], model(ids[:2, :32], mask[:2, :32], pixels[:2])[0]
+    assert not torch.equal(a, b)
