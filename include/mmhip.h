@@ -42,6 +42,9 @@ typedef struct mmhip_config {
     float p_hidden, p_attn, p_head;      /* text hidden / attention-prob dropout, --dropout */
     int dtype;                           /* MMHIP_BF16 | MMHIP_F16: storage + MFMA operand type of activations */
     int max_posts, max_text_len;         /* capacity: B <= max_posts, T <= max_text_len (ITM doubles the text rows) */
+    float loss_scale;                    /* gradient scale inside the 16-bit text tower; 0 = default (1 for bf16, 1024 for f16:
+                                            f16 has 5 exponent bits, deep-layer activation gradients ~1e-6 would be subnormal).
+                                            train_grad is always in true units. */
 } mmhip_config;
 
 typedef struct mmhip_param_info {

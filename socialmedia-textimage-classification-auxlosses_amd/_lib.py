@@ -18,7 +18,7 @@ class Config(C.Structure):
                 ("ln_eps_txt", C.c_float), ("ln_eps_img", C.c_float), ("image", C.c_int), ("patch", C.c_int),
                 ("proj_dim", C.c_int), ("num_labels", C.c_int), ("fusion", C.c_int), ("p_hidden", C.c_float),
                 ("p_attn", C.c_float), ("p_head", C.c_float), ("dtype", C.c_int), ("max_posts", C.c_int),
-                ("max_text_len", C.c_int)]
+                ("max_text_len", C.c_int), ("loss_scale", C.c_float)]
 
 
 class ParamInfo(C.Structure):

@@ -77,6 +77,9 @@ struct mmhip_engine {
 
     template <typename U> U* wsp(size_t off) const { return reinterpret_cast<U*>(ws + off); }
     int dt() const { return cfg.dtype; }
+    // f16 activations: gradients inside the text tower are carried multiplied by gscale() (range, not precision) and
+    // every fp32 parameter gradient is written multiplied by 1 / gscale(); bf16 needs none
+    float gscale() const { return cfg.loss_scale > 0.f ? cfg.loss_scale : (cfg.dtype == MMHIP_F16 ? 1024.f : 1.f); }
     size_t esz() const { return 2; }
 };
 
@@ -527,7 +530,7 @@ int heads_backward(mmhip_engine& e, hipStream_t s) {
         CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_dprepool), H, W + e.t_pool_w, H, nullptr, dxcls, H, B, H, H, ACT_NONE, 1), s));
     }
     // gradient of the last hidden state: CLS rows only
-    CHECK_HIP(launch_scatter_cls_rows(dxcls, e.ws + e.g_dx, Bt, T, H, dt, s));
+    CHECK_HIP(launch_scatter_cls_rows(dxcls, e.ws + e.g_dx, Bt, T, H, dt, s, e.gscale()));
     return 0;
 }
 
@@ -554,7 +557,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
         e.tn_pending[set] = false;
     }
     // ---- x' = LN2(pre2), pre2 = drop(fc2(h)) + a1
-    LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mt, H, e.wsp<float>(e.g_partial)};
+    LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mt, H, e.wsp<float>(e.g_partial), 1.0f / e.gscale()};
     CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
     const DropCfg d_ffn = make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr);
     const char* df = dpre2;
@@ -563,7 +566,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     { G g(df, H, e.ws + w.fc2T, H, du, I, Mt, I, H); g.mul_gelu_grad(e.ws + a.u, I); if (int r = run_gemm(e, g, s)) return r; }
     { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mt, H, I); g.residual(dpre2, H); if (int r = run_gemm(e, g, s)) return r; }
     // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
-    LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mt, H, e.wsp<float>(e.g_partial)};
+    LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mt, H, e.wsp<float>(e.g_partial), 1.0f / e.gscale()};
     CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
     const char* dout = dpre1;
@@ -587,16 +590,16 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
         partial = e.wsp<float>(e.g_partial_side);
     }
     { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.residual(dpre1, H); if (int r = run_gemm(e, g, s)) return r; }
-    CHECK_HIP(launch_colsum(df, Mt, H, H, Gd + o.fc2_b, dt, ps, partial));
-    CHECK_HIP(launch_colsum(du, Mt, I, I, Gd + o.fc1_b, dt, ps, partial));
-    CHECK_HIP(launch_colsum(dout, Mt, H, H, Gd + o.ao_b, dt, ps, partial));
-    CHECK_HIP(launch_colsum(dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, ps, partial));
+    CHECK_HIP(launch_colsum(df, Mt, H, H, Gd + o.fc2_b, dt, ps, partial, 1.0f / e.gscale()));
+    CHECK_HIP(launch_colsum(du, Mt, I, I, Gd + o.fc1_b, dt, ps, partial, 1.0f / e.gscale()));
+    CHECK_HIP(launch_colsum(dout, Mt, H, H, Gd + o.ao_b, dt, ps, partial, 1.0f / e.gscale()));
+    CHECK_HIP(launch_colsum(dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, ps, partial, 1.0f / e.gscale()));
     GemmTNProblem pr[4];
     pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mt, H, I, H, I, I, 0};          // dW2[H,I]   = df^T h
     pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mt, I, H, I, H, H, 0};         // dW1[I,H]   = du^T a1
     pr[2] = GemmTNProblem{dqkv, x_in, Gd + o.qkv_w, Mt, 3 * H, H, 3 * H, H, H, 0};      // dWqkv[3H,H] = dqkv^T x_in
     pr[3] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mt, H, H, H, H, H, 0};       // dWo[H,H]   = dout^T ctx
-    CHECK_HIP(launch_gemm_tn(pr, 4, 0, dt, 0, ps));
+    CHECK_HIP(launch_gemm_tn(pr, 4, 0, dt, 0, ps, 1.0f / e.gscale()));
     if (side) {
         CHECK_HIP(hipEventRecord(e.ev_tn[set], e.side));
         e.tn_pending[set] = true;
@@ -627,6 +630,7 @@ int embed_backward(mmhip_engine& e, hipStream_t s) {
     b.pos_pad_id = c.txt_kind == MMHIP_TXT_XLMR ? c.pad_id : -1;     // nn.Embedding(padding_idx=...) rows get no gradient
     b.drop = make_drop(c.p_hidden, e.seed, STREAM_EMBED, e.train_mode);
     b.partial = e.wsp<float>(e.g_partial);
+    b.alpha = 1.0f / e.gscale();
     CHECK_HIP(launch_embed_bwd(b, e.dt(), s));
     return 0;
 }

@@ -366,8 +366,8 @@ void gemm_tn_kernel(GemmTNGroup g) {
                 const int n = n0 + wn_ * 64 + i * 16 + (lane >> 4) * 4 + r;
                 const int c = c0 + wc_ * 64 + j * 16 + (lane & 15);
                 float* dst = Cp + (size_t)n * P.ldc + c;
-                if (g.accumulate == 1) atomicAdd(dst, acc[i][j][r]);
-                else *dst = acc[i][j][r];
+                if (g.accumulate == 1) atomicAdd(dst, acc[i][j][r] * g.alpha);
+                else *dst = acc[i][j][r] * g.alpha;
             }
 }
 
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void slow_nt_kernel(GemmNTArgs a) {
     else ((T*)a.C)[(size_t)m * a.ldc + n] = from_f<T>(v);
 }
 template <typename T>
-__global__ __launch_bounds__(256) void slow_tn_kernel(GemmTNProblem P, int accumulate) {
+__global__ __launch_bounds__(256) void slow_tn_kernel(GemmTNProblem P, int accumulate, float alpha) {
     const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     if (c >= P.Nc) return;
     const T* A = (const T*)P.A;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void slow_tn_kernel(GemmTNProblem P, int accum
     float s = 0.f;
     for (int m = 0; m < P.M; ++m) s += to_f<T>(A[(size_t)m * P.lda + n]) * to_f<T>(B[(size_t)m * P.ldb + c]);
     float* dst = P.C + (size_t)n * P.ldc + c;
-    *dst = accumulate ? *dst + s : s;
+    *dst = accumulate ? *dst + s * alpha : s * alpha;
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -508,9 +508,15 @@ static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
     }
 }
 
+static bool debug_force_slow() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MMHIP_FORCE_SLOW"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
-    if (nt_fast_ok(a) && !a.force_slow) {
+    if (nt_fast_ok(a) && !a.force_slow && !debug_force_slow()) {
         if (dtype == DT_BF16) launch_nt_d<bf16_t>(a, s);
         else launch_nt_d<f16_t>(a, s);
     } else {
@@ -531,15 +537,16 @@ static void launch_tn_t(const GemmTNGroup& g, int tiles, hipStream_t s) {
 
 // variant: 1 = 128x128 2-stage (default: fastest inside the step with the four dW of a layer grouped, 432 tiles),
 // 2 = 128x128 4-stage ring, 3 = 256x128 3-stage ring; env MMHIP_TN_TILE overrides
-hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s) {
+hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_TN_TILE"); env = e ? atoi(e) : 0; }
     int variant = (force_slow >> 4) ? (force_slow >> 4) : (env ? env : 1);
-    force_slow &= 1;
+    force_slow = (force_slow & 1) | (debug_force_slow() ? 1 : 0);
     const int bnn = variant == 3 ? 256 : 128;
     GemmTNGroup g;
     g.count = 0;
     g.accumulate = accumulate;
+    g.alpha = alpha;
     int tiles = 0;
     auto flush = [&]() {
         if (!g.count) return;
@@ -566,8 +573,8 @@ hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate,
             if (g.count == GEMM_TN_MAX_GROUP) flush();
         } else if (P.M > 0) {
             dim3 grid((P.Nc + 255) / 256, P.Nn);
-            if (dtype == DT_BF16) hipLaunchKernelGGL(slow_tn_kernel<bf16_t>, grid, dim3(256), 0, s, P, accumulate);
-            else hipLaunchKernelGGL(slow_tn_kernel<f16_t>, grid, dim3(256), 0, s, P, accumulate);
+            if (dtype == DT_BF16) hipLaunchKernelGGL(slow_tn_kernel<bf16_t>, grid, dim3(256), 0, s, P, accumulate, alpha);
+            else hipLaunchKernelGGL(slow_tn_kernel<f16_t>, grid, dim3(256), 0, s, P, accumulate, alpha);
         }
     }
     flush();

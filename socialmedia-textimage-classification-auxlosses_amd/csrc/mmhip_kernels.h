@@ -36,6 +36,7 @@ struct GemmTNProblem {
 struct GemmTNGroup {
     GemmTNProblem p[GEMM_TN_MAX_GROUP];
     int count, accumulate;
+    float alpha;              // C (+)= alpha * A^T B   (un-does the f16 gradient scale)
 };
 struct SmallGemmArgs {
     const void* A; const float* W; const float* bias; float* out;
@@ -43,7 +44,7 @@ struct SmallGemmArgs {
     int sam, sak, sbk, sbn;   // element strides of A(m,k) and B(k,n); filled by the launch_small_* wrappers
 };
 hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s);
-hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s);
+hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha = 1.0f);
 hipError_t launch_small_nt(const SmallGemmArgs& a, int a_dtype, hipStream_t s);   // out[M,N] = act(A[M,K] W[N,K]^T + b)
 hipError_t launch_small_nn(const SmallGemmArgs& a, hipStream_t s);                // out[M,N] = A[M,K] W[K,N]
 hipError_t launch_small_tn(const SmallGemmArgs& a, int b_dtype, int n_rows, hipStream_t s);  // out[n_rows,N] = A[M,n_rows]^T B[M,N]
@@ -80,6 +81,7 @@ struct LNBwdArgs {
     float* dgamma; float* dbeta;   // fp32, accumulated (+=)
     int rows, width;
     float* partial;       // optional workspace of partial_floats_rows(rows, width, 2) floats: two-stage column reduction
+    float alpha;          // dgamma / dbeta += alpha * (...)   (0 is read as 1)
 };
 hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s);
 hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s);
@@ -102,13 +104,14 @@ struct EmbedBwdArgs {
     int posts, T, H, pad_id, pos_pad_id;
     DropCfg drop;
     float* partial;       // optional workspace of partial_floats_rows(posts*T, H, 3) floats
+    float alpha;          // every parameter gradient is multiplied by alpha (0 is read as 1)
 };
 hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s);
 hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s);
 
 hipError_t launch_patchify(const float* pixels, void* out, int B, int img, int patch, int dtype, hipStream_t s);
 hipError_t launch_vit_assemble(const void* patches, const float* cls, const float* pos, void* x, int B, int P, int H, int dtype, hipStream_t s);
-hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s, float* partial = nullptr);   // out[c] += sum_r x[r][c]
+hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s, float* partial = nullptr, float alpha = 1.0f);   // out[c] += sum_r x[r][c]
 size_t partial_floats_rows(int rows, int width, int nvec);
 size_t partial_floats_colsum(int rows, int cols);
 hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s);
@@ -119,7 +122,7 @@ hipError_t launch_cast_group(const CastMat* mats, int count, int dtype, hipStrea
 hipError_t launch_cast_transpose(const float* src, void* dst, int rows, int cols, int dtype, hipStream_t s);   // dst[c][r] = src[r][c]
 hipError_t launch_gather_rows_f32(const void* src, size_t src_stride, float* out, int ldo, int rows, int H, int dtype, hipStream_t s);
 hipError_t launch_dropout16(const void* src, void* dst, size_t n, const DropCfg& d, int dtype, hipStream_t s);
-hipError_t launch_scatter_cls_rows(const float* d, void* dx, int posts, int T, int H, int dtype, hipStream_t s);
+hipError_t launch_scatter_cls_rows(const float* d, void* dx, int posts, int T, int H, int dtype, hipStream_t s, float scale = 1.0f);
 
 // ---------------------------------------------------------------- heads
 struct FusionAttnArgs {

@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
             a.partial[(size_t)blockIdx.x * a.width + c] = sg;
             a.partial[((size_t)gridDim.x + blockIdx.x) * a.width + c] = sb;
         } else {
-            atomicAdd(a.dgamma + c, sg);
-            atomicAdd(a.dbeta + c, sb);
+            const float al = a.alpha == 0.f ? 1.f : a.alpha;
+            atomicAdd(a.dgamma + c, sg * al);
+            atomicAdd(a.dbeta + c, sb * al);
         }
     }
 }
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
 // walks its rows with 4 independent accumulators; the 4 waves combine through LDS and one atomic per column per
 // block finishes (grid.y-way contention only).
 static constexpr int RP_SPLIT = 8;
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n, int cols, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n, int cols, float* __restrict__ out, float alpha) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -169,11 +170,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
     red[w][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (w == 0 && c < cols) atomicAdd(out + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    if (w == 0 && c < cols) atomicAdd(out + c, (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * alpha);
 }
-static inline void launch_reduce_partials(const float* partial, int n, int cols, float* out, hipStream_t s) {
+static inline void launch_reduce_partials(const float* partial, int n, int cols, float* out, hipStream_t s, float alpha = 1.0f) {
     const int split = n >= 4 * RP_SPLIT ? RP_SPLIT : 1;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64, split), dim3(256), 0, s, partial, n, cols, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64, split), dim3(256), 0, s, partial, n, cols, out, alpha);
 }
 
 // ------------------------------------------------------------------------------------------------ text embeddings
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
     __shared__ float red[3][4][1024];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nch = a.H >> 2, rows = a.posts * a.T;
+    const float al = a.alpha == 0.f ? 1.f : a.alpha;
     float dg[MAXC][4], db[MAXC][4], dt[MAXC][4], gam[MAXC][4];
 #pragma unroll
     for (int t = 0; t < MAXC; ++t) {
@@ -314,8 +316,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     const float o = rstd * (g[t][e] - c1 - xh[t][e] * c2);
                     dt[t][e] += o;
-                    if (wrow) atomicAdd(wrow + c * 4 + e, o);
-                    if (prow) atomicAdd(prow + c * 4 + e, o);
+                    if (wrow) atomicAdd(wrow + c * 4 + e, o * al);
+                    if (prow) atomicAdd(prow + c * 4 + e, o * al);
                 }
             }
         }
@@ -338,9 +340,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
             a.partial[((size_t)gridDim.x + blockIdx.x) * a.H + c] = sb;
             a.partial[((size_t)2 * gridDim.x + blockIdx.x) * a.H + c] = st;
         } else {
-            atomicAdd(a.dgamma + c, sg);
-            atomicAdd(a.dbeta + c, sb);
-            atomicAdd(a.dtype + c, st);
+            atomicAdd(a.dgamma + c, sg * al);
+            atomicAdd(a.dbeta + c, sb * al);
+            atomicAdd(a.dtype + c, st * al);
         }
     }
 }
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const T* __restrict__
 // out[c] += sum_r x[r][c]   (bias gradients).  grid (ceil(cols/256), row chunks); lanes own 4 columns each.
 static constexpr int COLSUM_ROWS = 64;
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int cols, int ld, float* __restrict__ out, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int cols, int ld, float* __restrict__ out, float* __restrict__ partial, float alpha) {
     __shared__ float red[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     if (cc < cols) {
         const float sres = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         if (partial) partial[(size_t)blockIdx.y * cols + cc] = sres;
-        else atomicAdd(out + cc, sres);
+        else atomicAdd(out + cc, sres * alpha);
     }
 }
 
@@ -474,14 +476,18 @@ __global__ __launch_bounds__(256) void cast_dual_kernel(CastGroup g) {
 }
 // dx[post*T + t][:] = (t == 0) ? d[post][:] : 0        (gradient of the last hidden state: only CLS rows are read)
 template <typename T>
-__global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restrict__ d, T* __restrict__ dx, int posts, int Tn, int H) {
+__global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restrict__ d, T* __restrict__ dx, int posts, int Tn, int H, float scale) {
     const int hc = H / 4;
     const size_t total = (size_t)posts * Tn * hc;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int c = (idx % hc) * 4;
         const size_t row = idx / hc;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (row % Tn == 0) load4<float>(d + (row / Tn) * H + c, v);
+        if (row % Tn == 0) {
+            load4<float>(d + (row / Tn) * H + c, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= scale;
+        }
         store4<T>(dx + row * H + c, v);
     }
 }
@@ -544,8 +550,9 @@ hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s) {
     if (dtype == DT_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
     if (a.partial) {
-        launch_reduce_partials(a.partial, grid, a.width, a.dgamma, s);
-        launch_reduce_partials(a.partial + (size_t)grid * a.width, grid, a.width, a.dbeta, s);
+        const float al = a.alpha == 0.f ? 1.f : a.alpha;
+        launch_reduce_partials(a.partial, grid, a.width, a.dgamma, s, al);
+        launch_reduce_partials(a.partial + (size_t)grid * a.width, grid, a.width, a.dbeta, s, al);
     }
     return hipGetLastError();
 }
@@ -566,7 +573,7 @@ hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s) {
     if (a.partial) {
         float* outs[3] = {a.dgamma, a.dbeta, a.dtype};
         for (int k = 0; k < 3; ++k)
-            launch_reduce_partials(a.partial + (size_t)k * grid * a.H, grid, a.H, outs[k], s);
+            launch_reduce_partials(a.partial + (size_t)k * grid * a.H, grid, a.H, outs[k], s, a.alpha == 0.f ? 1.f : a.alpha);
     }
     return hipGetLastError();
 }
@@ -585,13 +592,13 @@ hipError_t launch_vit_assemble(const void* patches, const float* cls, const floa
     else hipLaunchKernelGGL(vit_assemble_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, (const f16_t*)patches, cls, pos, (f16_t*)x, B, P, H);
     return hipGetLastError();
 }
-hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s, float* partial) {
+hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s, float* partial, float alpha) {
     if (rows <= 0 || cols <= 0) return hipSuccess;
     if (cols % 4 || ld % 4) return hipErrorInvalidValue;
     dim3 grid((cols + 255) / 256, (rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
-    if (dtype == DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, cols, ld, out, partial);
-    else hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, rows, cols, ld, out, partial);
-    if (partial) launch_reduce_partials(partial, (int)grid.y, cols, out, s);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, cols, ld, out, partial, alpha);
+    else hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, rows, cols, ld, out, partial, alpha);
+    if (partial) launch_reduce_partials(partial, (int)grid.y, cols, out, s, alpha);
     return hipGetLastError();
 }
 hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s) {
@@ -637,11 +644,11 @@ hipError_t launch_gather_rows_f32(const void* src, size_t src_stride, float* out
     else hipLaunchKernelGGL(gather_rows_f32_kernel<f16_t>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const f16_t*)src, src_stride, out, ldo, rows, H);
     return hipGetLastError();
 }
-hipError_t launch_scatter_cls_rows(const float* d, void* dx, int posts, int T, int H, int dtype, hipStream_t s) {
+hipError_t launch_scatter_cls_rows(const float* d, void* dx, int posts, int T, int H, int dtype, hipStream_t s, float scale) {
     if (posts <= 0) return hipSuccess;
     const size_t total = (size_t)posts * T * (H / 4);
-    if (dtype == DT_BF16) hipLaunchKernelGGL(scatter_cls_kernel<bf16_t>, dim3(cap_grid(total)), dim3(256), 0, s, d, (bf16_t*)dx, posts, T, H);
-    else hipLaunchKernelGGL(scatter_cls_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, d, (f16_t*)dx, posts, T, H);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(scatter_cls_kernel<bf16_t>, dim3(cap_grid(total)), dim3(256), 0, s, d, (bf16_t*)dx, posts, T, H, scale);
+    else hipLaunchKernelGGL(scatter_cls_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, d, (f16_t*)dx, posts, T, H, scale);
     return hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ def test_exports_match_header(lib):
 def _cfg(**kw):
     base = dict(hidden=768, heads=12, inter=3072, layers_txt=2, layers_img=2, vocab=1000, max_pos=130, type_vocab=1, txt_kind=1,
                 pad_id=1, ln_eps_txt=1e-5, ln_eps_img=1e-12, image=224, patch=16, proj_dim=512, num_labels=3, fusion=1,
-                p_hidden=0.1, p_attn=0.1, p_head=0.05, dtype=0, max_posts=4, max_text_len=64)
+                p_hidden=0.1, p_attn=0.1, p_head=0.05, dtype=0, max_posts=4, max_text_len=64, loss_scale=0.0)
     base.update(kw)
     return _lib.Config(**base)
 
