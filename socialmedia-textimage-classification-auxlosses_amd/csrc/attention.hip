@@ -170,7 +170,7 @@ __device__ __forceinline__ int ds_off(int row, int ch, int sp_chunks) {   // [64
 }
 
 template <typename T, int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;

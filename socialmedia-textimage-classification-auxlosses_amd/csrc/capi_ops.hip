@@ -124,7 +124,10 @@ int mmhip_op_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma
 int mmhip_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                            void* dx, const void* dres, float* dgamma, float* dbeta, int rows, int width, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return MMHIP_E_INVALID;
-    LNBwdArgs a{dy, x, gamma, mean, rstd, dx, dres, dgamma, dbeta, rows, width, nullptr, 1.0f};
+    LNBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dy = dy; a.x = x; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.dx = dx; a.dres = dres; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.rows = rows; a.width = width; a.alpha = 1.0f;
     CHECK_HIP(launch_layernorm_bwd(a, dtype, (hipStream_t)stream));
     return 0;
 }

@@ -557,20 +557,21 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
         e.tn_pending[set] = false;
     }
     // ---- x' = LN2(pre2), pre2 = drop(fc2(h)) + a1
-    LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mt, H, e.wsp<float>(e.g_partial), 1.0f / e.gscale()};
-    CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
+    // LN backward also emits the dropout-backward copy and the bias gradient of the Linear that fed the LN
     const DropCfg d_ffn = make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr);
-    const char* df = dpre2;
-    if (d_ffn.thresh16) { CHECK_HIP(launch_dropout16(dpre2, ddrop2, (size_t)Mt * H, d_ffn, dt, s)); df = ddrop2; }
+    LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mt, H,
+                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ffn.thresh16 ? ddrop2 : nullptr, Gd + o.fc2_b, d_ffn};
+    CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
+    const char* df = d_ffn.thresh16 ? ddrop2 : dpre2;
     // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
     { G g(df, H, e.ws + w.fc2T, H, du, I, Mt, I, H); g.mul_gelu_grad(e.ws + a.u, I); if (int r = run_gemm(e, g, s)) return r; }
     { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mt, H, I); g.residual(dpre2, H); if (int r = run_gemm(e, g, s)) return r; }
     // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
-    LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mt, H, e.wsp<float>(e.g_partial), 1.0f / e.gscale()};
-    CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
-    const char* dout = dpre1;
-    if (d_ao.thresh16) { CHECK_HIP(launch_dropout16(dpre1, ddrop1, (size_t)Mt * H, d_ao, dt, s)); dout = ddrop1; }
+    LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mt, H,
+                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ao.thresh16 ? ddrop1 : nullptr, Gd + o.ao_b, d_ao};
+    CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
+    const char* dout = d_ao.thresh16 ? ddrop1 : dpre1;
     { G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H); if (int r = run_gemm(e, g, s)) return r; }
     AttnBwdArgs ab;
     memset(&ab, 0, sizeof(ab));
@@ -590,9 +591,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
         partial = e.wsp<float>(e.g_partial_side);
     }
     { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.residual(dpre1, H); if (int r = run_gemm(e, g, s)) return r; }
-    CHECK_HIP(launch_colsum(df, Mt, H, H, Gd + o.fc2_b, dt, ps, partial, 1.0f / e.gscale()));
     CHECK_HIP(launch_colsum(du, Mt, I, I, Gd + o.fc1_b, dt, ps, partial, 1.0f / e.gscale()));
-    CHECK_HIP(launch_colsum(dout, Mt, H, H, Gd + o.ao_b, dt, ps, partial, 1.0f / e.gscale()));
     CHECK_HIP(launch_colsum(dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, ps, partial, 1.0f / e.gscale()));
     GemmTNProblem pr[4];
     pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mt, H, I, H, I, I, 0};          // dW2[H,I]   = df^T h

@@ -82,6 +82,9 @@ struct LNBwdArgs {
     int rows, width;
     float* partial;       // optional workspace of partial_floats_rows(rows, width, 2) floats: two-stage column reduction
     float alpha;          // dgamma / dbeta += alpha * (...)   (0 is read as 1)
+    // fused tail (optional): dx_drop = dropout-backward(dx) with the forward's mask (drop.thresh16 != 0), and
+    // colsum_out[c] += alpha * sum_rows (dx_drop or dx)[.][c]   -- the bias gradient of the Linear that produced the LN input
+    void* dx_drop; float* colsum_out; DropCfg drop;
 };
 hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s);
 hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s);

@@ -73,14 +73,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
 static constexpr int LN_ROWS_PER_BLOCK = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
-    __shared__ float red[2][4][1024];
+    __shared__ float red[3][4][1024];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nch = a.width >> 2;
-    float dg[MAXC][4], db[MAXC][4], gam[MAXC][4];
+    const bool dropping = a.dx_drop != nullptr && a.drop.thresh16 != 0;
+    float dg[MAXC][4], db[MAXC][4], dc[MAXC][4], gam[MAXC][4];
 #pragma unroll
     for (int t = 0; t < MAXC; ++t) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dg[t][e] = 0.f; db[t][e] = 0.f; gam[t][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { dg[t][e] = 0.f; db[t][e] = 0.f; dc[t][e] = 0.f; gam[t][e] = 0.f; }
         if (lane + 64 * t < nch) load4<float>(a.gamma + (lane + 64 * t) * 4, gam[t]);
     }
     const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK;
@@ -126,34 +127,51 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
                     for (int e = 0; e < 4; ++e) o[e] += r[e];
                 }
                 store4<T>(dx + c * 4, o);
+                if (dropping) {
+                    const uint32_t e0 = (uint32_t)row * (uint32_t)a.width + (uint32_t)c * 4u;
+                    bool k0, k1, k2, k3;
+                    mm_keep2(e0, a.drop, k0, k1);
+                    mm_keep2(e0 + 2, a.drop, k2, k3);
+                    o[0] = k0 ? o[0] * a.drop.keep_scale : 0.f;
+                    o[1] = k1 ? o[1] * a.drop.keep_scale : 0.f;
+                    o[2] = k2 ? o[2] * a.drop.keep_scale : 0.f;
+                    o[3] = k3 ? o[3] * a.drop.keep_scale : 0.f;
+                    store4<T>((T*)a.dx_drop + (size_t)row * a.width + c * 4, o);
+                }
+                if (a.colsum_out) {      // sums of the values as the bias-gradient consumer sees them (16-bit rounded)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dc[t][e] += to_f<T>(from_f<T>(o[e]));
+                }
             }
         }
     }
+    const int nvec = a.colsum_out ? 3 : 2;
 #pragma unroll
     for (int t = 0; t < MAXC; ++t)
         if (lane + 64 * t < nch)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { red[0][w][(lane + 64 * t) * 4 + e] = dg[t][e]; red[1][w][(lane + 64 * t) * 4 + e] = db[t][e]; }
+            for (int e = 0; e < 4; ++e) {
+                const int c = (lane + 64 * t) * 4 + e;
+                red[0][w][c] = dg[t][e]; red[1][w][c] = db[t][e]; red[2][w][c] = dc[t][e];
+            }
     __syncthreads();
-    for (int c = threadIdx.x; c < a.width; c += 256) {
-        const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-        const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        if (a.partial) {      // [2][gridDim.x][width]: reduced by reduce_partials_kernel (no same-address atomic storm)
-            a.partial[(size_t)blockIdx.x * a.width + c] = sg;
-            a.partial[((size_t)gridDim.x + blockIdx.x) * a.width + c] = sb;
-        } else {
-            const float al = a.alpha == 0.f ? 1.f : a.alpha;
-            atomicAdd(a.dgamma + c, sg * al);
-            atomicAdd(a.dbeta + c, sb * al);
+    float* outs[3] = {a.dgamma, a.dbeta, a.colsum_out};
+    for (int c = threadIdx.x; c < a.width; c += 256)
+        for (int v = 0; v < nvec; ++v) {
+            const float sres = red[v][0][c] + red[v][1][c] + red[v][2][c] + red[v][3][c];
+            if (a.partial) a.partial[((size_t)v * gridDim.x + blockIdx.x) * a.width + c] = sres;   // [nvec][grid][width]
+            else atomicAdd(outs[v] + c, sres * (a.alpha == 0.f ? 1.f : a.alpha));
         }
-    }
 }
 // out[c] += sum_i partial[i][c]   (i < n).  Block = 64 columns x 4 waves; grid.y splits the partial rows; each wave
 // walks its rows with 4 independent accumulators; the 4 waves combine through LDS and one atomic per column per
 // block finishes (grid.y-way contention only).
 static constexpr int RP_SPLIT = 8;
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n, int cols, float* __restrict__ out, float alpha) {
+struct ReduceOuts { float* out[3]; };
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial0, int n, int cols, ReduceOuts outs, float alpha) {
     __shared__ float red[4][64];
+    const float* __restrict__ partial = partial0 + (size_t)blockIdx.z * n * cols;     // vector blockIdx.z of [nvec][n][cols]
+    float* __restrict__ out = outs.out[blockIdx.z];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -172,9 +190,12 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     __syncthreads();
     if (w == 0 && c < cols) atomicAdd(out + c, (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * alpha);
 }
-static inline void launch_reduce_partials(const float* partial, int n, int cols, float* out, hipStream_t s, float alpha = 1.0f) {
+static inline void launch_reduce_partials(const float* partial, int n, int cols, float* out, hipStream_t s, float alpha = 1.0f,
+                                          float* out1 = nullptr, float* out2 = nullptr) {
     const int split = n >= 4 * RP_SPLIT ? RP_SPLIT : 1;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64, split), dim3(256), 0, s, partial, n, cols, out, alpha);
+    const int nvec = out2 ? 3 : (out1 ? 2 : 1);
+    ReduceOuts o{{out, out1, out2}};
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64, split, nvec), dim3(256), 0, s, partial, n, cols, o, alpha);
 }
 
 // ------------------------------------------------------------------------------------------------ text embeddings
@@ -540,7 +561,9 @@ hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s) {
     else hipLaunchKernelGGL(ln_fwd_kernel<f16_t>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }
-size_t partial_floats_rows(int rows, int width, int nvec) { return (size_t)nvec * ((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK) * width; }
+size_t partial_floats_rows(int rows, int width, int nvec) {   // LN backward may use 3 vectors
+    if (nvec < 3) nvec = 3;
+    return (size_t)nvec * ((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK) * width; }
 size_t partial_floats_colsum(int rows, int cols) { return (size_t)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS) * cols; }
 
 hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s) {
@@ -551,8 +574,7 @@ hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s) {
     else hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
     if (a.partial) {
         const float al = a.alpha == 0.f ? 1.f : a.alpha;
-        launch_reduce_partials(a.partial, grid, a.width, a.dgamma, s, al);
-        launch_reduce_partials(a.partial + (size_t)grid * a.width, grid, a.width, a.dbeta, s, al);
+        launch_reduce_partials(a.partial, grid, a.width, a.dgamma, s, al, a.dbeta, a.colsum_out);
     }
     return hipGetLastError();
 }
@@ -571,9 +593,7 @@ hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s) {
     if (dtype == DT_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(embed_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
     if (a.partial) {
-        float* outs[3] = {a.dgamma, a.dbeta, a.dtype};
-        for (int k = 0; k < 3; ++k)
-            launch_reduce_partials(a.partial + (size_t)k * grid * a.H, grid, a.H, outs[k], s, a.alpha == 0.f ? 1.f : a.alpha);
+        launch_reduce_partials(a.partial, grid, a.H, a.dgamma, s, a.alpha == 0.f ? 1.f : a.alpha, a.dbeta, a.dtype);
     }
     return hipGetLastError();
 }
