@@ -24,12 +24,14 @@ static constexpr int BK = 64;
 // counted wait: at most N of this wave's vector-memory operations (LDS-DMA loads here) may still be in flight
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int NS>
+// NL > 0: role-specialised variant -- WM*WN consumer waves (ds_read + MFMA only) and NL loader waves that stream the
+// operand tiles into an NS-deep LDS ring with LDS-DMA (counted vmcnt); one raw s_barrier per k-step couples them.
+template <int BM, int BN, int WM, int WN, int NS, int NL = 0>
 struct NTCfg {
-    static constexpr int NW = WM * WN, NTHR = NW * 64;
+    static constexpr int NW = WM * WN, NLOAD = NL ? NL : NW, NTHR = (NW + NL) * 64;
     static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    static constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;        // LDS-DMA wave-instructions per wave per stage
+    static constexpr int AI = BM / 8 / NLOAD, BI = BN / 8 / NLOAD;  // LDS-DMA wave-instructions per loading wave per stage
     static constexpr int EP_LD = TN + 4;                            // fp32 staging row stride (floats)
     static constexpr int EP_WAVE = 32 * EP_LD * 4;                  // 32-row chunk per wave
     static constexpr int LDS = (NS * STAGE > NW * EP_WAVE) ? NS * STAGE : NW * EP_WAVE;
@@ -37,10 +39,10 @@ struct NTCfg {
     static constexpr int LPS = AI + BI;                             // LDS-DMA instructions per wave per stage
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(WM * WN * 64, (NTCfg<BM, BN, WM, WN, NS>::BLOCKS_PER_CU * WM * WN) / 4)
+template <typename T, int BM, int BN, int WM, int WN, int NS, int NL = 0>
+__global__ __launch_bounds__((WM * WN + NL) * 64, (NTCfg<BM, BN, WM, WN, NS, NL>::BLOCKS_PER_CU * (WM * WN + NL)) / 4)
 void gemm_nt_kernel(GemmNTArgs a) {
-    using C = NTCfg<BM, BN, WM, WN, NS>;
+    using C = NTCfg<BM, BN, WM, WN, NS, NL>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -60,18 +62,20 @@ void gemm_nt_kernel(GemmNTArgs a) {
 
     // ---- LDS-DMA staging: one wave instruction = 8 tile rows x 128 B; lane -> (row, 16-B slot)
     const int lrow = lane >> 3, slot = lane & 7;
+    const bool is_loader = NL == 0 || w >= C::NW;
+    const int lw = NL ? (w - C::NW) & (C::NLOAD - 1) : w;          // index among the loading waves
     const T* asrc[C::AI];
     const T* bsrc[C::BI];
 #pragma unroll
     for (int i = 0; i < C::AI; ++i) {
-        const int row = (w * C::AI + i) * 8 + lrow;
+        const int row = (lw * C::AI + i) * 8 + lrow;
         const int chunk = slot ^ (row & 7);                 // source-side swizzle
         const int gm = min(m0 + row, a.M - 1);              // rows past M read a valid row, never stored
         asrc[i] = A + (size_t)gm * a.lda + chunk * 8;
     }
 #pragma unroll
     for (int i = 0; i < C::BI; ++i) {
-        const int row = (w * C::BI + i) * 8 + lrow;
+        const int row = (lw * C::BI + i) * 8 + lrow;
         const int chunk = slot ^ (row & 7);
         bsrc[i] = B + (size_t)(n0 + row) * a.ldb + chunk * 8;
     }
@@ -79,10 +83,10 @@ void gemm_nt_kernel(GemmNTArgs a) {
         char* base = smem + buf * C::STAGE;
 #pragma unroll
         for (int i = 0; i < C::AI; ++i)
-            __builtin_amdgcn_global_load_lds(MM_GLB(asrc[i] + k0), MM_LDS(base + (w * C::AI + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(MM_GLB(asrc[i] + k0), MM_LDS(base + (lw * C::AI + i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < C::BI; ++i)
-            __builtin_amdgcn_global_load_lds(MM_GLB(bsrc[i] + k0), MM_LDS(base + C::A_BYTES + (w * C::BI + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(MM_GLB(bsrc[i] + k0), MM_LDS(base + C::A_BYTES + (lw * C::BI + i) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[C::FM][C::FN];
@@ -112,7 +116,36 @@ void gemm_nt_kernel(GemmNTArgs a) {
                 for (int j = 0; j < C::FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
         }
     };
-    if constexpr (NS == 2) {
+    if constexpr (NL > 0) {
+        // ---- role-specialised ring.  Step t: loaders wait until their share of tile t has landed (at most NS-2 younger
+        // tiles still in flight), everybody meets at one s_barrier (tile t complete; buffer (t-1)%NS free), loaders restage
+        // that buffer with tile t+NS-1, consumers multiply tile t.
+        if (w >= C::NW) {
+#pragma unroll
+            for (int p = 0; p < NS - 1; ++p)
+                if (p < nk) stage(p, p * BK);
+            int sbuf = NS - 1;
+            for (int t = 0; t < nk; ++t) {
+                const int ahead = nk - 1 - t;
+                if (ahead >= NS - 2) wait_vmcnt<(NS - 2) * C::LPS>();
+                else if (NS > 3 && ahead == 1) wait_vmcnt<C::LPS>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (t + NS - 1 < nk) stage(sbuf, (t + NS - 1) * BK);
+                sbuf = (sbuf + 1 == NS) ? 0 : sbuf + 1;
+            }
+            __builtin_amdgcn_s_barrier();          // matches the consumers' "operand buffers free" barrier below
+            return;                                // loaders take no part in the epilogue
+        }
+        int buf = 0;
+        for (int t = 0; t < nk; ++t) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");         // keep the tile's ds_reads below the barrier
+            compute(buf);
+            buf = (buf + 1 == NS) ? 0 : buf + 1;
+        }
+        __builtin_amdgcn_s_barrier();
+    } else if constexpr (NS == 2) {
         // two buffers, one tile of prefetch; __syncthreads drains the LDS-DMA queue (vmcnt(0)) at every step
         stage(0, 0);
         __syncthreads();
@@ -467,17 +500,18 @@ static bool nt_fast_ok(const GemmNTArgs& a) {
            (!(a.flags & GEMM_BIAS) || al(a.bias)) && a.M > 0;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int NL = 0>
 static void launch_nt_t(const GemmNTArgs& a, hipStream_t s) {
-    using C = NTCfg<BM, BN, WM, WN, NS>;
+    using C = NTCfg<BM, BN, WM, WN, NS, NL>;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN, NS, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN, NS>), dim3(grid), dim3(C::NTHR), C::LDS, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN, NS, NL>), dim3(grid), dim3(C::NTHR), C::LDS, s, a);
 }
 
 // tile choice: explicit (a.tile: 1 = 128x128 2-stage, 2 = 256x128 2-stage, 3 = 256x256 2-stage, 4 = 128x128 4-stage ring,
-// 5 = 256x128 3-stage ring, 6 = 128x192 2-stage, 7 = 256x192 2-stage) or measured rules
+// 5 = 256x128 3-stage ring, 6 = 128x192 2-stage, 7 = 256x192 2-stage, 8 = 128x128 role-specialised (4 MFMA + 4 loader
+// waves, 4-stage ring), 9 = 256x128 role-specialised (8 + 4 waves, 3-stage ring)) or measured rules
 static int choose_nt_tile(const GemmNTArgs& a) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_NT_TILE"); env = e ? atoi(e) : 0; }
@@ -485,7 +519,8 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if (t == 3 && a.N % 256) t = 2;
     if ((t == 6 || t == 7) && a.N % 192) t = 0;
     if ((t >= 1 && t <= 5) && a.N % 128) t = 0;
-    if (t >= 1 && t <= 7) return t;
+    if ((t == 8 || t == 9) && a.N % 128) t = 0;
+    if (t >= 1 && t <= 9) return t;
     if (a.N % 128 && a.N % 192 == 0 && a.N % 256) { /* only the 192-wide tiles divide N */ }
     // Measured inside the training step (bench.py with MMHIP_NT_TILE forced, profiles/r01_tile_sweep.txt): 128x128 at two
     // blocks per CU is as fast as any other tile for every shape of this model; the isolated micro-benchmark gains of the
@@ -498,6 +533,8 @@ static int choose_nt_tile(const GemmNTArgs& a) {
 template <typename T>
 static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
     switch (choose_nt_tile(a)) {
+        case 9: launch_nt_t<T, 256, 128, 4, 2, 3, 4>(a, s); break;    // 8 consumers + 4 loaders, 3-stage ring
+        case 8: launch_nt_t<T, 128, 128, 2, 2, 4, 4>(a, s); break;    // 4 consumers + 4 loaders, 4-stage ring
         case 7: launch_nt_t<T, 256, 192, 4, 2, 2>(a, s); break;
         case 6: launch_nt_t<T, 128, 192, 2, 2, 2>(a, s); break;
         case 5: launch_nt_t<T, 256, 128, 4, 2, 3>(a, s); break;
