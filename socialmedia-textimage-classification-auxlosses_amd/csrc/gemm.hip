@@ -526,6 +526,11 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     // blocks per CU is as fast as any other tile for every shape of this model; the isolated micro-benchmark gains of the
     // 192-wide tiles (tools/gemm_bench.py) do not survive the cold caches between dependent kernels.  The wider tiles
     // stay selectable (a.tile / MMHIP_NT_TILE) and serve N that only 192 divides.
+    static int rule = -1;
+    if (rule < 0) { const char* e = getenv("MMHIP_NT_RULE"); rule = e ? atoi(e) : 2; }   // 2: measured best inside the step
+    if (rule == 1 && a.N % 128 == 0 && a.N <= 768 && a.M >= 4096) return 9;        // experiment: WS 256x128 for narrow outputs
+    if (rule == 2 && a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9;
+    if (rule == 3) { if (a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9; if (a.N % 192 == 0) return 6; }
     if (a.N % 128 == 0) return 1;
     return 6;
 }
