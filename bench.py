@@ -138,7 +138,7 @@ def main():
     gms, gl, gf = Ct.c_double(), Ct.c_uint64(), Ct.c_double()
     _lib.check(lib.mmhip_gemm_timing(m._handle, 0, 1, Ct.byref(gms), Ct.byref(gl), Ct.byref(gf)))
     achieved = gf.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (128x128x64 MFMA 16x16x32, LDS-DMA staged)", "achieved": round(achieved, 1),
+    roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (MFMA 16x16x32, LDS-DMA staged; 128x128x64 tiles, role-specialised 256x128 for N<=768 & K>=2048)", "achieved": round(achieved, 1),
                 "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
                 "launches_per_step": int(gl.value // 2), "avg_launch_us": round(gms.value * 1e3 / max(1, gl.value), 2),
                 "gemm_ms_per_step": round(gms.value / 2, 3)}
