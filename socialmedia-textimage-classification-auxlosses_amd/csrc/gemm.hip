@@ -271,22 +271,22 @@ void gemm_nt_kernel(GemmNTArgs a) {
 // fragments are fetched with the hardware transposing read ds_read_b64_tr_b16 from [m][n] / [m][c] LDS images
 // (rows of TILE*2 bytes; the low 4 bits of the 16-B chunk index are XOR-ed with ((row&3)<<2 | (row>>2)&3):
 // conflict-free for the transposing reads, and a permutation inside each 256-B group so LDS-DMA stays line-friendly).
-template <int BNN, int BNC, int WN, int WC, int NS>
+template <int BNN, int BNC, int WN, int WC, int NS, int NL = 0>
 struct TNCfg {
-    static constexpr int NW = WN * WC, NTHR = NW * 64;
+    static constexpr int NW = WN * WC, NLOAD = NL ? NL : NW, NTHR = (NW + NL) * 64;
     static constexpr int A_ROW = BNN * 2, B_ROW = BNC * 2;                 // bytes per reduction row
     static constexpr int A_BYTES = 64 * A_ROW, B_BYTES = 64 * B_ROW, STAGE = A_BYTES + B_BYTES;
     static constexpr int A_RPI = 1024 / A_ROW, B_RPI = 1024 / B_ROW;       // reduction rows per LDS-DMA wave instruction
-    static constexpr int AI = 64 / A_RPI / NW, BI = 64 / B_RPI / NW;
+    static constexpr int AI = 64 / A_RPI / NLOAD, BI = 64 / B_RPI / NLOAD;
     static constexpr int LPS = AI + BI;
     static constexpr int LDS = NS * STAGE;
     static constexpr int BLOCKS_PER_CU = (LDS <= 80 * 1024) ? 2 : 1;
 };
 
-template <typename T, int BNN, int BNC, int WN, int WC, int NS>
-__global__ __launch_bounds__(WN * WC * 64, (TNCfg<BNN, BNC, WN, WC, NS>::BLOCKS_PER_CU * WN * WC) / 4)
+template <typename T, int BNN, int BNC, int WN, int WC, int NS, int NL = 0>
+__global__ __launch_bounds__((WN * WC + NL) * 64, (TNCfg<BNN, BNC, WN, WC, NS, NL>::BLOCKS_PER_CU * (WN * WC + NL)) / 4)
 void gemm_tn_kernel(GemmTNGroup g) {
-    using C = TNCfg<BNN, BNC, WN, WC, NS>;
+    using C = TNCfg<BNN, BNC, WN, WC, NS, NL>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -305,18 +305,19 @@ void gemm_tn_kernel(GemmTNGroup g) {
 
     auto fsw = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
     // staging: lane -> (row within the instruction, 16-B slot within the row); source chunk = slot ^ f(row)
+    const int lw = NL ? (w - C::NW) & (C::NLOAD - 1) : w;                    // index among the loading waves
     const T* asrc[C::AI];
     const T* bsrc[C::BI];
 #pragma unroll
     for (int i = 0; i < C::AI; ++i) {
         constexpr int SPR = C::A_ROW / 16;                                  // slots per row
-        const int row = (w * C::AI + i) * C::A_RPI + lane / SPR, slot = lane % SPR;
+        const int row = (lw * C::AI + i) * C::A_RPI + lane / SPR, slot = lane % SPR;
         asrc[i] = A + (size_t)row * P.lda + n0 + (slot ^ fsw(row)) * 8;
     }
 #pragma unroll
     for (int i = 0; i < C::BI; ++i) {
         constexpr int SPR = C::B_ROW / 16;
-        const int row = (w * C::BI + i) * C::B_RPI + lane / SPR, slot = lane % SPR;
+        const int row = (lw * C::BI + i) * C::B_RPI + lane / SPR, slot = lane % SPR;
         bsrc[i] = B + (size_t)row * P.ldb + c0 + (slot ^ fsw(row)) * 8;
     }
     auto stage = [&](int buf, int mstep) {
@@ -324,10 +325,10 @@ void gemm_tn_kernel(GemmTNGroup g) {
         const size_t ao = g.accumulate == 2 ? 0 : (size_t)mstep * 64 * P.lda, bo = g.accumulate == 2 ? 0 : (size_t)mstep * 64 * P.ldb;
 #pragma unroll
         for (int i = 0; i < C::AI; ++i)
-            __builtin_amdgcn_global_load_lds(MM_GLB(asrc[i] + ao), MM_LDS(base + (w * C::AI + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(MM_GLB(asrc[i] + ao), MM_LDS(base + (lw * C::AI + i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < C::BI; ++i)
-            __builtin_amdgcn_global_load_lds(MM_GLB(bsrc[i] + bo), MM_LDS(base + C::A_BYTES + (w * C::BI + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(MM_GLB(bsrc[i] + bo), MM_LDS(base + C::A_BYTES + (lw * C::BI + i) * 1024), 16, 0, 0);
     };
     f32x4 acc[4][4];
 #pragma unroll
@@ -362,7 +363,32 @@ void gemm_tn_kernel(GemmTNGroup g) {
         }
     };
     const int nsteps = P.M / 64;
-    if constexpr (NS == 2) {
+    if constexpr (NL > 0) {
+        // role-specialised ring (see gemm_nt_kernel): loader waves stream, consumer waves multiply, one barrier per step
+        if (w >= C::NW) {
+#pragma unroll
+            for (int p = 0; p < NS - 1; ++p)
+                if (p < nsteps) stage(p, p);
+            int sbuf = NS - 1;
+            for (int t = 0; t < nsteps; ++t) {
+                const int ahead = nsteps - 1 - t;
+                if (ahead >= NS - 2) wait_vmcnt<(NS - 2) * C::LPS>();
+                else if (NS > 3 && ahead == 1) wait_vmcnt<C::LPS>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (t + NS - 1 < nsteps) stage(sbuf, t + NS - 1);
+                sbuf = (sbuf + 1 == NS) ? 0 : sbuf + 1;
+            }
+            return;
+        }
+        int buf = 0;
+        for (int t = 0; t < nsteps; ++t) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            compute(buf);
+            buf = (buf + 1 == NS) ? 0 : buf + 1;
+        }
+    } else if constexpr (NS == 2) {
         stage(0, 0);
         __syncthreads();
         for (int t = 0; t < nsteps; ++t) {
@@ -569,22 +595,23 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <typename T, int BNN, int BNC, int WN, int WC, int NS>
+template <typename T, int BNN, int BNC, int WN, int WC, int NS, int NL = 0>
 static void launch_tn_t(const GemmTNGroup& g, int tiles, hipStream_t s) {
-    using C = TNCfg<BNN, BNC, WN, WC, NS>;
+    using C = TNCfg<BNN, BNC, WN, WC, NS, NL>;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BNN, BNC, WN, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
-    hipLaunchKernelGGL((gemm_tn_kernel<T, BNN, BNC, WN, WC, NS>), dim3(tiles), dim3(C::NTHR), C::LDS, s, g);
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BNN, BNC, WN, WC, NS, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
+    hipLaunchKernelGGL((gemm_tn_kernel<T, BNN, BNC, WN, WC, NS, NL>), dim3(tiles), dim3(C::NTHR), C::LDS, s, g);
 }
 
 // variant: 1 = 128x128 2-stage (default: fastest inside the step with the four dW of a layer grouped, 432 tiles),
-// 2 = 128x128 4-stage ring, 3 = 256x128 3-stage ring; env MMHIP_TN_TILE overrides
+// 2 = 128x128 4-stage ring, 3 = 256x128 3-stage ring, 4 = role-specialised 256x128 (8 MFMA + 4 loader waves, 3-stage
+// ring), 5 = role-specialised 128x128 (4 + 4, 4-stage ring); env MMHIP_TN_TILE overrides
 hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_TN_TILE"); env = e ? atoi(e) : 0; }
     int variant = (force_slow >> 4) ? (force_slow >> 4) : (env ? env : 1);
     force_slow = (force_slow & 1) | (debug_force_slow() ? 1 : 0);
-    const int bnn = variant == 3 ? 256 : 128;
+    const int bnn = (variant == 3 || variant == 4) ? 256 : 128;
     GemmTNGroup g;
     g.count = 0;
     g.accumulate = accumulate;
@@ -593,11 +620,15 @@ hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate,
     auto flush = [&]() {
         if (!g.count) return;
         if (dtype == DT_BF16) {
-            if (variant == 3) launch_tn_t<bf16_t, 256, 128, 4, 2, 3>(g, tiles, s);
+            if (variant == 4) launch_tn_t<bf16_t, 256, 128, 4, 2, 3, 4>(g, tiles, s);
+            else if (variant == 5) launch_tn_t<bf16_t, 128, 128, 2, 2, 4, 4>(g, tiles, s);
+            else if (variant == 3) launch_tn_t<bf16_t, 256, 128, 4, 2, 3>(g, tiles, s);
             else if (variant == 2) launch_tn_t<bf16_t, 128, 128, 2, 2, 4>(g, tiles, s);
             else launch_tn_t<bf16_t, 128, 128, 2, 2, 2>(g, tiles, s);
         } else {
-            if (variant == 3) launch_tn_t<f16_t, 256, 128, 4, 2, 3>(g, tiles, s);
+            if (variant == 4) launch_tn_t<f16_t, 256, 128, 4, 2, 3, 4>(g, tiles, s);
+            else if (variant == 5) launch_tn_t<f16_t, 128, 128, 2, 2, 4, 4>(g, tiles, s);
+            else if (variant == 3) launch_tn_t<f16_t, 256, 128, 4, 2, 3>(g, tiles, s);
             else if (variant == 2) launch_tn_t<f16_t, 128, 128, 2, 2, 4>(g, tiles, s);
             else launch_tn_t<f16_t, 128, 128, 2, 2, 2>(g, tiles, s);
         }

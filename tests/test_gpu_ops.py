@@ -109,7 +109,8 @@ def test_gemm_nt_epilogues(dt, M, N, K, slow):
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,Nn,Nc,slow", [(64, 128, 128, 0), (256, 256, 384, 0), (8192, 768, 768, 0), (1024, 2304, 768, 0),
                                           (96, 40, 72, 1), (64, 128, 128, 16), (256, 256, 384, 16), (128, 128, 256, 32),
-                                          (8192, 768, 768, 32), (64, 256, 128, 48), (192, 512, 384, 48), (8192, 768, 3072, 48)])
+                                          (8192, 768, 768, 32), (64, 256, 128, 48), (192, 512, 384, 48), (8192, 768, 3072, 48),
+                                          (64, 256, 128, 64), (448, 512, 384, 64), (8192, 768, 3072, 64), (128, 128, 256, 80), (8192, 768, 768, 80)])
 def test_gemm_tn(dt, M, Nn, Nc, slow):
     code, tdt = DT[dt]
     g = torch.Generator(device="cpu").manual_seed(M + Nn)
