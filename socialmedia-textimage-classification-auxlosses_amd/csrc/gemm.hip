@@ -603,13 +603,16 @@ static void launch_tn_t(const GemmTNGroup& g, int tiles, hipStream_t s) {
     hipLaunchKernelGGL((gemm_tn_kernel<T, BNN, BNC, WN, WC, NS, NL>), dim3(tiles), dim3(C::NTHR), C::LDS, s, g);
 }
 
-// variant: 1 = 128x128 2-stage (default: fastest inside the step with the four dW of a layer grouped, 432 tiles),
+// variant: 1 = 128x128 2-stage, 4 (default, fastest inside the step: 13.5 vs 14.2 ms) = role-specialised 256x128,
 // 2 = 128x128 4-stage ring, 3 = 256x128 3-stage ring, 4 = role-specialised 256x128 (8 MFMA + 4 loader waves, 3-stage
 // ring), 5 = role-specialised 128x128 (4 + 4, 4-stage ring); env MMHIP_TN_TILE overrides
 hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_TN_TILE"); env = e ? atoi(e) : 0; }
-    int variant = (force_slow >> 4) ? (force_slow >> 4) : (env ? env : 1);
+    int variant = (force_slow >> 4) ? (force_slow >> 4) : (env ? env : 4);
+    if (variant == 3 || variant == 4)          // the 256-row tiles need every problem's Nn to be a multiple of 256
+        for (int i = 0; i < count; ++i)
+            if (probs[i].Nn % 256) { variant = 1; break; }
     force_slow = (force_slow & 1) | (debug_force_slow() ? 1 : 0);
     const int bnn = (variant == 3 || variant == 4) ? 256 : 128;
     GemmTNGroup g;
