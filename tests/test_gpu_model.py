@@ -299,3 +299,34 @@ def test_capacity_growth_param_updates_and_errors():
     with torch.no_grad():
         a, b = model(ids[:2, :32], mask[:2, :32], pixels[:2])[0], model(ids[:2, :32], mask[:2, :32], pixels[:2])[0]
     assert not torch.equal(a, b)
+
+
+def test_full_size_backward_is_the_mean_of_half_batches():
+    """BASELINE size (12+12 layers, V=250002, T=128): without ITC/ITM posts are independent, so the gradient of the mean loss
+    over 64 posts equals the mean of the gradients over its two halves (dropout off).  Exercises every backward kernel at
+    the benchmark shapes without needing the CPU oracle at that size."""
+    from smtc_amd import _lib
+    cfg = O.OracleConfig(num_labels=2)
+    model = MM_Model(2, "bernice", "vit", 0.0, "attention", arch=dict(p_hidden=0.0, p_attn=0.0), max_posts=64, max_text_len=128, seed=2)
+    model.train()
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, 64, 128, 99, True)
+    dev = model.device_
+
+    def grads(sl):
+        model._flat_grad.zero_()
+        model._engine_forward(ids[sl], mask[sl], pixels[sl])
+        lo = torch.empty(4, device=dev)
+        oh = onehot[sl].to(dev).contiguous()
+        _lib.check(_lib.lib().mmhip_loss(model._handle, _lib.ptr(oh), None, None, 1.0, 0.0, 0.0, _lib.ptr(lo), None, _lib.stream_ptr()))
+        _lib.check(_lib.lib().mmhip_backward(model._handle, None, None, None, None, _lib.stream_ptr()))
+        return model._flat_grad.clone(), lo[0].item()
+
+    g_all, l_all = grads(slice(0, 64))
+    g_a, l_a = grads(slice(0, 32))
+    g_b, l_b = grads(slice(32, 64))
+    assert torch.isfinite(g_all).all()
+    assert abs(l_all - 0.5 * (l_a + l_b)) < 1e-5 * abs(l_all)
+    ref = 0.5 * (g_a + g_b)
+    for b, e in model.active_ranges(False, False):
+        err = (g_all[b:e] - ref[b:e]).norm().item() / max(ref[b:e].norm().item(), 1e-30)
+        assert err < 2e-3, (b, e, err)            # identical per-row arithmetic; only fp32 / 16-bit summation order differs
