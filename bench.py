@@ -138,8 +138,15 @@ def main():
     gms, gl, gf = Ct.c_double(), Ct.c_uint64(), Ct.c_double()
     _lib.check(lib.mmhip_gemm_timing(m._handle, 0, 1, Ct.byref(gms), Ct.byref(gl), Ct.byref(gf)))
     achieved = gf.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
+    # HBM bytes per launch of that kernel: PMC passes of this very command (FETCH_SIZE x2 per the gfx950 correction and
+    # WRITE_SIZE, collected in separate rocprofv3 --pmc runs; profiles/README.md) -- bench.py cannot run the profiler itself
+    traffic, tfile = None, os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    if os.path.exists(tfile) and not args.aux and B == 64 and world == 1:
+        with open(tfile) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
     roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (MFMA 16x16x32, LDS-DMA staged; 128x128x64 tiles, role-specialised 256x128 for N<=768 & K>=2048)", "achieved": round(achieved, 1),
-                "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
+                "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_gemm_traffic.json)",
+                "algorithmic_flops_per_launch": round(gf.value / max(1, gl.value)),
                 "launches_per_step": int(gl.value // 2), "avg_launch_us": round(gms.value * 1e3 / max(1, gl.value), 2),
                 "gemm_ms_per_step": round(gms.value / 2, 3)}
     mode = "aux" if args.aux else "plain"
