@@ -75,7 +75,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
     const int r = lane & 31, h2 = lane >> 5;
     const float sc = a.scale * LOG2E;
-    const int nqt = (S + 31) / 32;
+    const int nqt = a.q_tiles > 0 ? min((S + 31) / 32, a.q_tiles) : (S + 31) / 32;
     const bool dropping = a.drop.thresh16 != 0;
     for (int qt = w; qt < nqt; qt += NW) {
         const int q = qt * 32 + r;
@@ -230,12 +230,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
     const bool dropping = a.drop.thresh16 != 0;
     f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
     constexpr int NQT = NKT;
-    for (int pair = 0; pair < (NQT + 1) / 2; ++pair) {
+    const int qlim = a.q_tiles > 0 ? min(NQT, a.q_tiles) : NQT;      // later tiles carry a zero d ctx: nothing to do
+    for (int pair = 0; pair < (qlim + 1) / 2; ++pair) {
         if (has_keys) {
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
                 const int qt = pair * 2 + t2;
-                if (qt >= NQT) break;
+                if (qt >= qlim) break;
                 const int q0 = qt * 32;
                 const int qrow = min(q0 + r, S - 1);
                 f32x16 sacc = f32x16{}, pacc = f32x16{};
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
         {   // dQ tile (query tile pair*2 + (w>>1), d tile w&1) = dS[q][:] . K[:, d]
             const int qi = w >> 1, dt = w & 1;
             const int qt = pair * 2 + qi;
-            if (qt < NQT) {
+            if (qt < qlim) {
                 f32x16 dq = f32x16{};
 #pragma unroll
                 for (int ks = 0; ks < SP / 16; ++ks) {

@@ -69,6 +69,8 @@ struct mmhip_engine {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_vit = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_tn[2] = {nullptr, nullptr};
     bool tn_pending[2] = {false, false};
+    int cls_only = -1;         // -1 = read MMHIP_CLS_ONLY on first use; 1: the last text layer runs its post-attention part on CLS rows only
+    bool cls_compact = false;  // state of the last forward
     int overlap = -1;          // -1 = read MMHIP_OVERLAP on first use
     // GEMM timing ----------------------------------------------------------------------
     bool timing = false;
@@ -290,7 +292,7 @@ struct G {
     G& aux(void* p, int ld) { a.aux = p; a.ldaux = ld; a.flags |= GEMM_AUX_PRE; return *this; }
     G& residual(const void* p, int ld) { a.residual = p; a.ldres = ld; a.flags |= GEMM_RESIDUAL; return *this; }
     G& mul_gelu_grad(const void* p, int ld) { a.mul_in = p; a.ldmul = ld; a.flags |= GEMM_MUL_GELU_GRAD; return *this; }
-    G& dropout(const DropCfg& d) { a.drop = d; if (d.thresh16) a.flags |= GEMM_DROPOUT; return *this; }
+    G& dropout(const DropCfg& d, int row_mul = 1) { a.drop = d; a.drop_row_mul = row_mul; if (d.thresh16) a.flags |= GEMM_DROPOUT; return *this; }
 };
 int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
     if (e.timing) {
@@ -393,29 +395,38 @@ int text_forward(mmhip_engine& e, hipStream_t s) {
     ea.drop = make_drop(c.p_hidden, e.seed, STREAM_EMBED, tr);
     CHECK_HIP(launch_embed_fwd(ea, dt, s));
     const char* x = e.ws + e.x0;
+    if (e.cls_only < 0) { const char* v = getenv("MMHIP_CLS_ONLY"); e.cls_only = v ? atoi(v) : 1; }
+    e.cls_compact = false;
     for (int l = 0; l < c.layers_txt; ++l) {
         const LayerOff& o = e.txt[l];
         const LayerW16& w = e.txt_w16[l];
         const TextAct& a = e.tact[l];
         { G g(x, H, e.ws + w.qkv, H, e.ws + a.qkv, 3 * H, Mt, 3 * H, H); g.bias(W + o.qkv_b); if (int r = run_gemm(e, g, s)) return r; }
+        // Only the CLS row of the last layer's output is ever consumed (fusion query and pooler, mm_late.py:111,155-158):
+        // its attention needs query tile 0 only and everything after it runs on Bt rows (row stride T*H in the full
+        // tensors, compact [Bt, .] outputs).  Dropout indices keep the full-tensor numbering (row_mul = T).
+        const bool compact = e.cls_only > 0 && l == c.layers_txt - 1;
+        const int Mr = compact ? Bt : Mt, rs = compact ? T * H : H, rmul = compact ? T : 1;
         AttnArgs at;
         memset(&at, 0, sizeof(at));
         at.qkv = e.ws + a.qkv; at.maskbias = e.wsp<float>(e.maskbias); at.ctx = e.ws + a.ctx; at.lse = e.wsp<float>(a.lse);
         at.posts = Bt; at.S = T; at.heads = c.heads; at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
         at.scale = 1.0f / sqrtf((float)(H / c.heads));
         at.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
+        at.q_tiles = compact ? 1 : 0;
         CHECK_HIP(launch_attn_fwd(at, dt, s));
-        { G g(e.ws + a.ctx, H, e.ws + w.ao, H, e.ws + a.pre1, H, Mt, H, H);
-          g.bias(W + o.ao_b).dropout(make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr)).residual(x, H);
+        { G g(e.ws + a.ctx, rs, e.ws + w.ao, H, e.ws + a.pre1, H, Mr, H, H);
+          g.bias(W + o.ao_b).dropout(make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr), rmul).residual(x, rs);
           if (int r = run_gemm(e, g, s)) return r; }
-        LNArgs ln1{e.ws + a.pre1, e.ws + a.a1, W + o.ln1_w, W + o.ln1_b, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), Mt, H, H, H, c.ln_eps_txt};
+        LNArgs ln1{e.ws + a.pre1, e.ws + a.a1, W + o.ln1_w, W + o.ln1_b, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), Mr, H, H, H, c.ln_eps_txt};
         CHECK_HIP(launch_layernorm_fwd(ln1, dt, s));
-        { G g(e.ws + a.a1, H, e.ws + w.fc1, H, e.ws + a.h, I, Mt, I, H); g.bias(W + o.fc1_b).aux(e.ws + a.u, I).gelu(); if (int r = run_gemm(e, g, s)) return r; }
-        { G g(e.ws + a.h, I, e.ws + w.fc2, I, e.ws + a.pre2, H, Mt, H, I);
-          g.bias(W + o.fc2_b).dropout(make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr)).residual(e.ws + a.a1, H);
+        { G g(e.ws + a.a1, H, e.ws + w.fc1, H, e.ws + a.h, I, Mr, I, H); g.bias(W + o.fc1_b).aux(e.ws + a.u, I).gelu(); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + a.h, I, e.ws + w.fc2, I, e.ws + a.pre2, H, Mr, H, I);
+          g.bias(W + o.fc2_b).dropout(make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr), rmul).residual(e.ws + a.a1, H);
           if (int r = run_gemm(e, g, s)) return r; }
-        LNArgs ln2{e.ws + a.pre2, e.ws + a.out, W + o.ln2_w, W + o.ln2_b, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), Mt, H, H, H, c.ln_eps_txt};
+        LNArgs ln2{e.ws + a.pre2, e.ws + a.out, W + o.ln2_w, W + o.ln2_b, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), Mr, H, H, H, c.ln_eps_txt};
         CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
+        e.cls_compact = compact;
         x = e.ws + a.out;
     }
     return 0;
@@ -429,8 +440,9 @@ int heads_forward(mmhip_engine& e, float* out_cls, float* logits, float* out_tim
     const int P = (c.image / c.patch) * (c.image / c.patch) + 1;
     const float* W = e.train;
     const char* xt = text_last(e);
+    const int cs = e.cls_compact ? H : T * H;           // row stride of the CLS rows of the last hidden state
     // text pooler (first B posts) and ITC similarity -- HF dual encoder :261-274
-    CHECK_HIP(launch_small_nt(small(xt, T * H, W + e.t_pool_w, H, W + e.t_pool_b, e.wsp<float>(e.h_tpool), H, B, H, H, ACT_TANH), dt, s));
+    CHECK_HIP(launch_small_nt(small(xt, cs, W + e.t_pool_w, H, W + e.t_pool_b, e.wsp<float>(e.h_tpool), H, B, H, H, ACT_TANH), dt, s));
     CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_tpool), H, W + e.tproj_w, H, nullptr, e.wsp<float>(e.h_txt_e), E, B, E, H), DT_F32, s));
     CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_vpool), H, W + e.vproj_w, H, nullptr, e.wsp<float>(e.h_img_e), E, B, E, H), DT_F32, s));
     ItcArgs it{e.wsp<float>(e.h_txt_e), e.wsp<float>(e.h_img_e), W + e.logit_scale, e.wsp<float>(e.h_txt_n), e.wsp<float>(e.h_img_n),
@@ -438,9 +450,9 @@ int heads_forward(mmhip_engine& e, float* out_cls, float* logits, float* out_tim
     CHECK_HIP(launch_itc_fwd(it, s));
     // z = [x_t[:,0] | fused image feature]
     float* z = e.wsp<float>(e.h_z);
-    CHECK_HIP(launch_gather_rows_f32(xt, (size_t)T * H, z, 2 * H, Bt, H, dt, s));
+    CHECK_HIP(launch_gather_rows_f32(xt, (size_t)cs, z, 2 * H, Bt, H, dt, s));
     if (c.fusion == MMHIP_FUSION_ATTENTION) {
-        CHECK_HIP(launch_small_nt(small(xt, T * H, W + e.fq_w, H, W + e.fq_b, e.wsp<float>(e.h_q), H, Bt, H, H), dt, s));
+        CHECK_HIP(launch_small_nt(small(xt, cs, W + e.fq_w, H, W + e.fq_b, e.wsp<float>(e.h_q), H, Bt, H, H), dt, s));
         CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_q), H, W + e.fk_w, H, nullptr, e.wsp<float>(e.h_qk), H, Bt, H, H), s));
         FusionAttnArgs fa{e.wsp<float>(e.h_qk), e.ws + e.v_out, e.wsp<float>(e.h_prob), e.wsp<float>(e.h_xbar), Bt, B, P, H, 1.0f / sqrtf((float)H)};
         CHECK_HIP(launch_fusion_attn_fwd(fa, dt, s));
@@ -530,7 +542,8 @@ int heads_backward(mmhip_engine& e, hipStream_t s) {
         CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_dprepool), H, W + e.t_pool_w, H, nullptr, dxcls, H, B, H, H, ACT_NONE, 1), s));
     }
     // gradient of the last hidden state: CLS rows only
-    CHECK_HIP(launch_scatter_cls_rows(dxcls, e.ws + e.g_dx, Bt, T, H, dt, s, e.gscale()));
+    // gradient of the last hidden state: CLS rows only (compact [Bt, H] when the last layer ran on CLS rows)
+    CHECK_HIP(launch_scatter_cls_rows(dxcls, e.ws + e.g_dx, Bt, e.cls_compact ? 1 : T, H, dt, s, e.gscale()));
     return 0;
 }
 
@@ -549,6 +562,9 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     // still be consuming layer l's set while the main stream runs layer l-1 on the other one
     const int set = l & 1;
     const bool side = use_side(e);
+    // last layer in CLS-only mode: its gradient arrives as compact [Bt, H] rows; everything up to d ctx runs on Bt rows
+    const bool compact = e.cls_compact && l == c.layers_txt - 1;
+    const int Mr = compact ? Bt : Mt, rs = compact ? T * H : H, rmul = compact ? T : 1;
     char *dx = e.ws + e.g_dx, *dx2 = e.ws + e.g_dx2, *dctx = e.ws + e.g_dctx;
     char *dpre2 = e.ws + e.g_set[set][0], *ddrop2 = e.ws + e.g_set[set][1], *du = e.ws + e.g_set[set][2];
     char *dpre1 = e.ws + e.g_set[set][3], *ddrop1 = e.ws + e.g_set[set][4], *dqkv = e.ws + e.g_set[set][5];
@@ -556,32 +572,42 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
         CHECK_HIP(hipStreamWaitEvent(s, e.ev_tn[set], 0));
         e.tn_pending[set] = false;
     }
-    // ---- x' = LN2(pre2), pre2 = drop(fc2(h)) + a1
-    // LN backward also emits the dropout-backward copy and the bias gradient of the Linear that fed the LN
+    // ---- x' = LN2(pre2), pre2 = drop(fc2(h)) + a1.  LN backward also emits the dropout-backward copy and the bias
+    // gradient of the Linear that fed the LN
     const DropCfg d_ffn = make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr);
-    LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mt, H,
-                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ffn.thresh16 ? ddrop2 : nullptr, Gd + o.fc2_b, d_ffn};
+    LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mr, H,
+                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ffn.thresh16 ? ddrop2 : nullptr, Gd + o.fc2_b, d_ffn, rmul};
     CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
     const char* df = d_ffn.thresh16 ? ddrop2 : dpre2;
     // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
-    { G g(df, H, e.ws + w.fc2T, H, du, I, Mt, I, H); g.mul_gelu_grad(e.ws + a.u, I); if (int r = run_gemm(e, g, s)) return r; }
-    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mt, H, I); g.residual(dpre2, H); if (int r = run_gemm(e, g, s)) return r; }
+    { G g(df, H, e.ws + w.fc2T, H, du, I, Mr, I, H); g.mul_gelu_grad(e.ws + a.u, I); if (int r = run_gemm(e, g, s)) return r; }
+    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mr, H, I); g.residual(dpre2, H); if (int r = run_gemm(e, g, s)) return r; }
     // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
-    LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mt, H,
-                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ao.thresh16 ? ddrop1 : nullptr, Gd + o.ao_b, d_ao};
+    LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mr, H,
+                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ao.thresh16 ? ddrop1 : nullptr, Gd + o.ao_b, d_ao, rmul};
     CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
     const char* dout = d_ao.thresh16 ? ddrop1 : dpre1;
-    { G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H); if (int r = run_gemm(e, g, s)) return r; }
+    if (compact) {
+        // d ctx for the CLS rows only, spread into an otherwise-zero full tensor for the attention backward
+        { G g(dout, H, e.ws + w.aoT, H, dx2, H, Mr, H, H); if (int r = run_gemm(e, g, s)) return r; }
+        CHECK_HIP(hipMemsetAsync(dctx, 0, (size_t)Mt * H * 2, s));
+        CHECK_HIP(launch_scatter_rows16(dx2, dctx, Bt, (size_t)T * H, H, 0, dt, s));
+        CHECK_HIP(hipMemsetAsync(dqkv, 0, (size_t)Mt * 3 * H * 2, s));      // dQ of the skipped query tiles is zero
+    } else {
+        G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H);
+        if (int r = run_gemm(e, g, s)) return r;
+    }
     AttnBwdArgs ab;
     memset(&ab, 0, sizeof(ab));
     ab.qkv = e.ws + a.qkv; ab.maskbias = e.wsp<float>(e.maskbias); ab.ctx = e.ws + a.ctx; ab.dctx = dctx; ab.lse = e.wsp<float>(a.lse);
     ab.dqkv = dqkv; ab.posts = Bt; ab.S = T; ab.heads = c.heads; ab.ld_qkv = 3 * H; ab.ld_ctx = H; ab.hidden = H;
     ab.scale = 1.0f / sqrtf((float)(H / c.heads));
     ab.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
+    ab.q_tiles = compact ? 1 : 0;
     CHECK_HIP(launch_attn_bwd(ab, dt, s));
     // ---- parameter gradients of the layer: off the critical path -> side stream (bias column sums + all four weight
-    // gradients in one grouped launch: 432 tiles of 128x128, no split-K, plain stores)
+    // gradients in one grouped launch, no split-K, plain stores)
     hipStream_t ps = s;
     float* partial = e.wsp<float>(e.g_partial);
     if (side) {
@@ -590,14 +616,22 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
         ps = e.side;
         partial = e.wsp<float>(e.g_partial_side);
     }
-    { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.residual(dpre1, H); if (int r = run_gemm(e, g, s)) return r; }
-    CHECK_HIP(launch_colsum(du, Mt, I, I, Gd + o.fc1_b, dt, ps, partial, 1.0f / e.gscale()));
+    if (compact) {
+        // dx_in = dqkv . Wqkv, plus d pre1 on the CLS rows (the residual branch of the CLS rows)
+        { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); if (int r = run_gemm(e, g, s)) return r; }
+        CHECK_HIP(launch_scatter_rows16(dpre1, dx, Bt, (size_t)T * H, H, 1, dt, s));
+    } else {
+        G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H);
+        g.residual(dpre1, H);
+        if (int r = run_gemm(e, g, s)) return r;
+    }
+    CHECK_HIP(launch_colsum(du, Mr, I, I, Gd + o.fc1_b, dt, ps, partial, 1.0f / e.gscale()));
     CHECK_HIP(launch_colsum(dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, ps, partial, 1.0f / e.gscale()));
     GemmTNProblem pr[4];
-    pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mt, H, I, H, I, I, 0};          // dW2[H,I]   = df^T h
-    pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mt, I, H, I, H, H, 0};         // dW1[I,H]   = du^T a1
-    pr[2] = GemmTNProblem{dqkv, x_in, Gd + o.qkv_w, Mt, 3 * H, H, 3 * H, H, H, 0};      // dWqkv[3H,H] = dqkv^T x_in
-    pr[3] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mt, H, H, H, H, H, 0};       // dWo[H,H]   = dout^T ctx
+    pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mr, H, I, H, I, I, 0};           // dW2[H,I]   = df^T h
+    pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mr, I, H, I, H, H, 0};          // dW1[I,H]   = du^T a1
+    pr[2] = GemmTNProblem{dqkv, x_in, Gd + o.qkv_w, Mt, 3 * H, H, 3 * H, H, H, 0};       // dWqkv[3H,H] = dqkv^T x_in
+    pr[3] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mr, H, H, H, rs, H, 0};       // dWo[H,H]   = dout^T ctx (CLS rows: stride T*H)
     CHECK_HIP(launch_gemm_tn(pr, 4, 0, dt, 0, ps, 1.0f / e.gscale()));
     if (side) {
         CHECK_HIP(hipEventRecord(e.ev_tn[set], e.side));

@@ -238,7 +238,7 @@ void gemm_nt_kernel(GemmNTArgs a) {
                 for (int e = 0; e < 8; ++e) v[e] *= mm_gelu_grad(to_f<T>(u[e]));
             }
             if ((fl & GEMM_DROPOUT) && a.drop.thresh16) {
-                const uint32_t e0 = (uint32_t)m * (uint32_t)a.N + (uint32_t)n;
+                const uint32_t e0 = (uint32_t)m * (uint32_t)(a.drop_row_mul ? a.drop_row_mul : 1) * (uint32_t)a.N + (uint32_t)n;
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     bool k0, k1;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void slow_nt_kernel(GemmNTArgs a) {
     if (fl & GEMM_GELU) v = mm_gelu(v);
     if (fl & GEMM_TANH) v = tanhf(v);
     if (fl & GEMM_MUL_GELU_GRAD) v *= mm_gelu_grad(to_f<T>(((const T*)a.mul_in)[(size_t)m * a.ldmul + n]));
-    if ((fl & GEMM_DROPOUT) && a.drop.thresh16) v = mm_keep((uint32_t)m * (uint32_t)a.N + (uint32_t)n, a.drop) ? v * a.drop.keep_scale : 0.f;
+    if ((fl & GEMM_DROPOUT) && a.drop.thresh16) v = mm_keep((uint32_t)m * (uint32_t)(a.drop_row_mul ? a.drop_row_mul : 1) * (uint32_t)a.N + (uint32_t)n, a.drop) ? v * a.drop.keep_scale : 0.f;
     if (fl & GEMM_RESIDUAL) v += to_f<T>(((const T*)a.residual)[(size_t)m * a.ldres + n]);
     if (fl & GEMM_OUT_F32) ((float*)a.C)[(size_t)m * a.ldc + n] = v;
     else ((T*)a.C)[(size_t)m * a.ldc + n] = from_f<T>(v);

@@ -25,7 +25,9 @@ struct GemmNTArgs {
     int M, N, K, lda, ldb, ldc, ldaux, ldres, ldmul;
     int flags;
     int force_slow;
-    int tile;                 // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256
+    int tile;                 // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, ...
+    int drop_row_mul;         // dropout element index uses row m * drop_row_mul (0 = 1): compact CLS-row GEMMs keep the
+                              // masks of the full [posts*T, N] tensor
     DropCfg drop;
 };
 static constexpr int GEMM_TN_MAX_GROUP = 8;
@@ -58,6 +60,7 @@ struct AttnArgs {
     int posts, S, heads, ld_qkv, ld_ctx, hidden;
     float scale;
     DropCfg drop;
+    int q_tiles;          // > 0: only the first q_tiles 32-row query tiles are computed / written (last layer: CLS row only)
 };
 struct AttnBwdArgs {
     const void* qkv; const float* maskbias; const void* ctx; const void* dctx; const float* lse;
@@ -65,6 +68,7 @@ struct AttnBwdArgs {
     int posts, S, heads, ld_qkv, ld_ctx, hidden;
     float scale;
     DropCfg drop;
+    int q_tiles;          // > 0: d ctx is zero outside the first q_tiles query tiles; dQ of the other tiles is NOT written
 };
 hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s);
 hipError_t launch_attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t s);
@@ -85,6 +89,7 @@ struct LNBwdArgs {
     // fused tail (optional): dx_drop = dropout-backward(dx) with the forward's mask (drop.thresh16 != 0), and
     // colsum_out[c] += alpha * sum_rows (dx_drop or dx)[.][c]   -- the bias gradient of the Linear that produced the LN input
     void* dx_drop; float* colsum_out; DropCfg drop;
+    int drop_row_mul;     // dropout index uses row * drop_row_mul (0 = 1)
 };
 hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s);
 hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s);
@@ -124,6 +129,7 @@ struct CastGroup { CastMat m[CAST_MAX_GROUP]; int count; };
 hipError_t launch_cast_group(const CastMat* mats, int count, int dtype, hipStream_t s);   // dst = cast(src), dstT = cast(src)^T (optional)
 hipError_t launch_cast_transpose(const float* src, void* dst, int rows, int cols, int dtype, hipStream_t s);   // dst[c][r] = src[r][c]
 hipError_t launch_gather_rows_f32(const void* src, size_t src_stride, float* out, int ldo, int rows, int H, int dtype, hipStream_t s);
+hipError_t launch_scatter_rows16(const void* src, void* dst, int rows, size_t dst_stride, int H, int add, int dtype, hipStream_t s);   // dst[r*stride] (+)= src[r]
 hipError_t launch_dropout16(const void* src, void* dst, size_t n, const DropCfg& d, int dtype, hipStream_t s);
 hipError_t launch_scatter_cls_rows(const float* d, void* dx, int posts, int T, int H, int dtype, hipStream_t s, float scale = 1.0f);
 

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
                 }
                 store4<T>(dx + c * 4, o);
                 if (dropping) {
-                    const uint32_t e0 = (uint32_t)row * (uint32_t)a.width + (uint32_t)c * 4u;
+                    const uint32_t e0 = (uint32_t)row * (uint32_t)(a.drop_row_mul ? a.drop_row_mul : 1) * (uint32_t)a.width + (uint32_t)c * 4u;
                     bool k0, k1, k2, k3;
                     mm_keep2(e0, a.drop, k0, k1);
                     mm_keep2(e0 + 2, a.drop, k2, k3);
@@ -495,6 +495,23 @@ __global__ __launch_bounds__(256) void cast_dual_kernel(CastGroup g) {
         }
     }
 }
+// dst[r * dst_stride + c] (+)= src[r * H + c]: spread compact CLS rows into a full-row tensor
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows16_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, size_t dst_stride, int H, int add) {
+    const int hc = H / 4;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rows * hc; idx += gridDim.x * 256) {
+        const int rr = idx / hc, c = (idx % hc) * 4;
+        float v[4];
+        load4<T>(src + (size_t)rr * H + c, v);
+        if (add) {
+            float o[4];
+            load4<T>(dst + (size_t)rr * dst_stride + c, o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += o[e];
+        }
+        store4<T>(dst + (size_t)rr * dst_stride + c, v);
+    }
+}
 // dx[post*T + t][:] = (t == 0) ? d[post][:] : 0        (gradient of the last hidden state: only CLS rows are read)
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restrict__ d, T* __restrict__ dx, int posts, int Tn, int H, float scale) {
@@ -648,6 +665,13 @@ hipError_t launch_cast_group(const CastMat* mats, int count, int dtype, hipStrea
     if (!tiles) return hipSuccess;
     if (dtype == DT_BF16) hipLaunchKernelGGL(cast_dual_kernel<bf16_t>, dim3(tiles), dim3(256), 0, s, g);
     else hipLaunchKernelGGL(cast_dual_kernel<f16_t>, dim3(tiles), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+hipError_t launch_scatter_rows16(const void* src, void* dst, int rows, size_t dst_stride, int H, int add, int dtype, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (H % 4 || dst_stride % 4) return hipErrorInvalidValue;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(scatter_rows16_kernel<bf16_t>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, rows, dst_stride, H, add);
+    else hipLaunchKernelGGL(scatter_rows16_kernel<f16_t>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const f16_t*)src, (f16_t*)dst, rows, dst_stride, H, add);
     return hipGetLastError();
 }
 hipError_t launch_dropout16(const void* src, void* dst, size_t n, const DropCfg& d, int dtype, hipStream_t s) {
