@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void slow_tn_kernel(GemmTNProblem P, int accum
 // ------------------------------------------------------------------------------------------------ launchers
 static bool nt_fast_ok(const GemmNTArgs& a) {
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    return (a.N % 128 == 0 || a.N % 192 == 0) && a.K % BK == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&
+    return (a.N % 128 == 0 || a.N % 192 == 0 || a.N % 96 == 0) && a.K % BK == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&
            (!(a.flags & GEMM_RESIDUAL) || (a.ldres % 8 == 0 && al(a.residual))) &&
            (!(a.flags & GEMM_AUX_PRE) || (a.ldaux % 8 == 0 && al(a.aux))) &&
            (!(a.flags & GEMM_MUL_GELU_GRAD) || (a.ldmul % 8 == 0 && al(a.mul_in))) &&
@@ -546,7 +546,8 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if ((t == 6 || t == 7) && a.N % 192) t = 0;
     if ((t >= 1 && t <= 5) && a.N % 128) t = 0;
     if ((t == 8 || t == 9) && a.N % 128) t = 0;
-    if (t >= 1 && t <= 9) return t;
+    if (t == 10 && a.N % 96) t = 0;
+    if (t >= 1 && t <= 10) return t;
     if (a.N % 128 && a.N % 192 == 0 && a.N % 256) { /* only the 192-wide tiles divide N */ }
     // Measured inside the training step (bench.py with MMHIP_NT_TILE forced, profiles/r01_tile_sweep.txt): 128x128 at two
     // blocks per CU is as fast as any other tile for every shape of this model; the isolated micro-benchmark gains of the
@@ -557,13 +558,23 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if (rule == 1 && a.N % 128 == 0 && a.N <= 768 && a.M >= 4096) return 9;        // experiment: WS 256x128 for narrow outputs
     if (rule == 2 && a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9;
     if (rule == 3) { if (a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9; if (a.N % 192 == 0) return 6; }
+    if (rule == 5 || rule == 6) {
+        // rounds of the 512 block slots (two blocks per CU) x bytes staged per tile and k-step
+        if (rule == 6 && a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9;
+        const long tm = (a.M + 127) / 128;
+        const long c128 = a.N % 128 == 0 ? ((tm * (a.N / 128) + 511) / 512) * 256 : (1L << 60);
+        const long c96 = a.N % 96 == 0 ? ((tm * (a.N / 96) + 511) / 512) * 224 : (1L << 60);
+        if (c96 < c128) return 10;
+    }
     if (a.N % 128 == 0) return 1;
-    return 6;
+    if (a.N % 192 == 0) return 6;
+    return 10;
 }
 
 template <typename T>
 static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
     switch (choose_nt_tile(a)) {
+        case 10: launch_nt_t<T, 128, 96, 2, 2, 2>(a, s); break;       // 512 / 1536 tiles for N = 768 / 2304 at M = 8192: whole rounds
         case 9: launch_nt_t<T, 256, 128, 4, 2, 3, 4>(a, s); break;    // 8 consumers + 4 loaders, 3-stage ring
         case 8: launch_nt_t<T, 128, 128, 2, 2, 4, 4>(a, s); break;    // 4 consumers + 4 loaders, 4-stage ring
         case 7: launch_nt_t<T, 256, 192, 4, 2, 2>(a, s); break;

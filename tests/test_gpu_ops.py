@@ -65,7 +65,8 @@ def _gemm_ref(A, B, bias, act, resid, mulg, keep, scale):
                                         (200, 128, 64, 80), (8192, 2304, 768, 80), (2048, 3072, 768, 64), (300, 256, 128, 80),
                                         (1000, 768, 768, 96), (8192, 2304, 768, 96), (300, 192, 128, 96), (520, 384, 256, 112), (8192, 3072, 768, 112),
                                         (200, 128, 64, 128), (1000, 768, 768, 128), (8192, 2304, 768, 128), (2048, 768, 3072, 128),
-                                        (300, 128, 128, 144), (8192, 3072, 768, 144), (1000, 768, 2304, 144)])
+                                        (300, 128, 128, 144), (8192, 3072, 768, 144), (1000, 768, 2304, 144),
+                                        (200, 96, 64, 160), (8192, 768, 768, 160), (1000, 2304, 768, 160), (300, 480, 128, 0)])
 def test_gemm_nt_epilogues(dt, M, N, K, slow):
     """`slow`: bit 0 forces the generic kernel, bits 4.. pick the tile variant (16 = 128x128, 32 = 256x128, 48 = 256x256,
     64 = 128x128 4-stage ring, 80 = 256x128 3-stage ring, 96 = 128x192, 112 = 256x192,
