@@ -434,12 +434,13 @@ void gemm_tn_kernel(GemmTNGroup g) {
 // Heads (B = 64..128 posts as the row count; 2-4 labels): exact fp32 on the matrix cores.
 //   out[m][n] (+)= act( sum_k A(m,k) * B(k,n) + bias[n] ),   A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn]
 // v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, bit-exact fp32): lane l holds A[l&31][k = l>>5], B[k = l>>5][l&31].
-// A workgroup owns one 32x32 output tile; its 4 waves split K in 8-wide slices (wave w takes slices w, w+4, ...),
+// A workgroup owns one 32x32 output tile; its 8 waves split K in 8-wide slices (wave w takes slices w, w+8, ...),
 // each lane fetching 4 consecutive k per operand (one 16-byte load when that operand is k-contiguous), and the four
 // partial tiles are summed through LDS.  K order inside a slice is permuted identically for A and B.
+static constexpr int SG_WAVES = 8;       // the K loop is latency-bound (two dependent global loads per step): split it wide
 template <typename TA>
-__global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemmArgs a) {
-    __shared__ float red[4][32][33];
+__global__ __launch_bounds__(SG_WAVES * 64) void small_gemm_kernel(SmallGemmArgs a) {
+    __shared__ float red[SG_WAVES][32][32];      // lanes index the last dimension: conflict-free without padding
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemmArgs a) {
     const TA* Ap = (const TA*)a.A + (size_t)m * a.sam;
     const float* Bp = a.W + (size_t)n * a.sbn;
     f32x16 acc = f32x16{};
-    for (int k0 = w * 8 + h * 4; k0 < a.K; k0 += 32) {
+    for (int k0 = w * 8 + h * 4; k0 < a.K; k0 += 8 * SG_WAVES) {
         float av[4], bv[4];
         if (a.sak == 1 && k0 + 3 < a.K && sizeof(TA) == 4 && ((((uintptr_t)(Ap + k0)) & 15) == 0)) {
             f32x4 t = *reinterpret_cast<const f32x4*>(Ap + k0);
@@ -470,11 +471,13 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemmArgs a) {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) red[w][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] = acc[reg];
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+    for (int i = threadIdx.x; i < 32 * 32; i += SG_WAVES * 64) {
         const int row = i >> 5, col = i & 31;
         const int gm = m0 + row, gn = n0 + col;
         if (gm < a.M && gn < a.N) {
-            float v = red[0][row][col] + red[1][row][col] + red[2][row][col] + red[3][row][col];
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < SG_WAVES; ++ww) v += red[ww][row][col];
             if (a.bias) v += a.bias[gn];
             if (a.act == ACT_TANH) v = tanhf(v);
             else if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
@@ -671,9 +674,9 @@ hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate,
 hipError_t launch_small_gemm(const SmallGemmArgs& a, int a_dtype, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     dim3 grid((a.N + 31) / 32, (a.M + 31) / 32);
-    if (a_dtype == DT_F32) hipLaunchKernelGGL(small_gemm_kernel<float>, grid, dim3(256), 0, s, a);
-    else if (a_dtype == DT_BF16) hipLaunchKernelGGL(small_gemm_kernel<bf16_t>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(small_gemm_kernel<f16_t>, grid, dim3(256), 0, s, a);
+    if (a_dtype == DT_F32) hipLaunchKernelGGL(small_gemm_kernel<float>, grid, dim3(SG_WAVES * 64), 0, s, a);
+    else if (a_dtype == DT_BF16) hipLaunchKernelGGL(small_gemm_kernel<bf16_t>, grid, dim3(SG_WAVES * 64), 0, s, a);
+    else hipLaunchKernelGGL(small_gemm_kernel<f16_t>, grid, dim3(SG_WAVES * 64), 0, s, a);
     return hipGetLastError();
 }
 // out[M,N] = act(A[M,K] W[N,K]^T + b)

@@ -23,21 +23,26 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
 }
 
 // ------------------------------------------------------------------------------------------------ fusion attention
+// One workgroup per text post.  Each wave takes image tokens j = w, w+4, ...: a lane owns 12 of the 768 columns
+// (three 8-byte loads per token, independent across tokens, so the loads pipeline), dots reduce across the wave,
+// weighted sums accumulate in registers and are combined across the 4 waves through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void fusion_attn_fwd_kernel(FusionAttnArgs a) {
     __shared__ float q[1024];
     __shared__ float sc[256];
     __shared__ float red[4];
+    __shared__ float part[4][1024];
     const int bt = blockIdx.x, b = bt % a.B, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < a.H; c += 256) q[c] = a.qk[(size_t)bt * a.H + c];
     __syncthreads();
     const T* xv = (const T*)a.xv + (size_t)b * a.P * a.H;
+    const int nch = a.H >> 2;                   // 4-element chunks; lane owns chunks lane, lane+64, ...
     for (int j = w; j < a.P; j += 4) {
         float s = 0.f;
-        for (int c = lane * 4; c < a.H; c += 256) {
-            typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(xv + (size_t)j * a.H + c);
+        for (int ch = lane; ch < nch; ch += 64) {
+            typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(xv + (size_t)j * a.H + ch * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s += to_f<T>(x[e]) * q[c + e];
+            for (int e = 0; e < 4; ++e) s += to_f<T>(x[e]) * q[ch * 4 + e];
         }
         s = wave_sum(s);
         if (lane == 0) sc[j] = s * a.scale;
@@ -52,27 +57,48 @@ __global__ __launch_bounds__(256) void fusion_attn_fwd_kernel(FusionAttnArgs a) 
         a.prob[(size_t)bt * a.P + threadIdx.x] = e / sum;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < a.H; c += 256) {
-        float s = 0.f;
-        for (int j = 0; j < a.P; ++j) s += sc[j] * to_f<T>(xv[(size_t)j * a.H + c]);
-        a.xbar[(size_t)bt * a.H + c] = s;
+    float acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) acc[t][ee] = 0.f;
+    for (int j = w; j < a.P; j += 4) {
+        const float p = sc[j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ch = lane + 64 * t;
+            if (ch < nch) {
+                typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(xv + (size_t)j * a.H + ch * 4);
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) acc[t][ee] += p * to_f<T>(x[ee]);
+            }
+        }
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (lane + 64 * t < nch)
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) part[w][(lane + 64 * t) * 4 + ee] = acc[t][ee];
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.H; c += 256) a.xbar[(size_t)bt * a.H + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
 }
 template <typename T>
 __global__ __launch_bounds__(256) void fusion_attn_bwd_kernel(FusionAttnBwdArgs a) {
     __shared__ float dxb[1024];
     __shared__ float ds[256];
     __shared__ float red[4];
+    __shared__ float part[4][1024];
     const int bt = blockIdx.x, b = bt % a.B, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < a.H; c += 256) dxb[c] = a.dxbar[(size_t)bt * a.H + c];
     __syncthreads();
     const T* xv = (const T*)a.xv + (size_t)b * a.P * a.H;
+    const int nch = a.H >> 2;
     for (int j = w; j < a.P; j += 4) {
         float s = 0.f;
-        for (int c = lane * 4; c < a.H; c += 256) {
-            typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(xv + (size_t)j * a.H + c);
+        for (int ch = lane; ch < nch; ch += 64) {
+            typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(xv + (size_t)j * a.H + ch * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s += to_f<T>(x[e]) * dxb[c + e];
+            for (int e = 0; e < 4; ++e) s += to_f<T>(x[e]) * dxb[ch * 4 + e];
         }
         s = wave_sum(s);
         if (lane == 0) ds[j] = s;          // dp_j
@@ -84,11 +110,30 @@ __global__ __launch_bounds__(256) void fusion_attn_bwd_kernel(FusionAttnBwdArgs 
     __syncthreads();
     if (threadIdx.x < a.P) ds[threadIdx.x] = p * (dp - tsum) * a.scale;
     __syncthreads();
-    for (int c = threadIdx.x; c < a.H; c += 256) {
-        float s = 0.f;
-        for (int j = 0; j < a.P; ++j) s += ds[j] * to_f<T>(xv[(size_t)j * a.H + c]);
-        a.dqk[(size_t)bt * a.H + c] = s;
+    float acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) acc[t][ee] = 0.f;
+    for (int j = w; j < a.P; j += 4) {
+        const float d = ds[j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ch = lane + 64 * t;
+            if (ch < nch) {
+                typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(xv + (size_t)j * a.H + ch * 4);
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) acc[t][ee] += d * to_f<T>(x[ee]);
+            }
+        }
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (lane + 64 * t < nch)
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) part[w][(lane + 64 * t) * 4 + ee] = acc[t][ee];
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.H; c += 256) a.dqk[(size_t)bt * a.H + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
 }
 
 // ------------------------------------------------------------------------------------------------ ITC
