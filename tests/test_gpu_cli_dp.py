@@ -99,3 +99,26 @@ def test_two_rank_step_equals_averaged_single_process(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("DP_ERR")][0].split()
     assert line[3] == "True", line                      # replicas stay bit-identical
     assert float(line[1]) < 2e-6, line                  # == one process on the averaged gradients (fp32 sum order only)
+
+
+def test_cli_config0_real_pipeline(tmp_path):
+    """BASELINE configs[0]: run_mm_late.py --txt_model_name bernice --img_model_name vit --fusion_name attention --task 2
+    --testing, through the real input pipeline (data key CSV -> tweet normalisation -> tokenizer -> JPEG decode / resize /
+    normalise) on a generated dummy task (the reference ships header-only data keys); cwd and relative paths as the
+    reference uses them (../data, ../results, ../../../BERNICE)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_dummy_task
+    sys.path.insert(0, ROOT)
+    import smtc_amd  # noqa: F401
+    run_dir = make_dummy_task.main(str(tmp_path), 64, 1)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "smtc_amd.run_mm_late", "--txt_model_name", "bernice", "--img_model_name", "vit", "--fusion_name",
+                        "attention", "--task", "2", "--testing", "--use_clip_loss", "--epochs", "1", "--save_preds"],
+                       cwd=run_dir, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = os.path.join(os.path.dirname(run_dir), "results", "mm_late", "testing")
+    stem = os.path.join(out, "bernice-vit-attention_task2_seed30_itc0.1_")
+    mv = pd.read_csv(stem + "metrics_val.csv")
+    assert list(mv.columns) == ["metric", "epoch-0"] and np.isfinite(mv["epoch-0"]).all()
+    preds = pd.read_csv(stem + "preds.csv")
+    assert set(preds.prediction.unique()) <= {0, 1, 2, 3} and preds.data_id.between(1000, 1063).all()

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Create a dummy task tree laid out as the reference expects (cwd = <root>/work/models/run):
+    <root>/BERNICE/            tokenizer (tokenizers WordLevel, XLM-R special-token ids) + config.json (random-init shapes)
+    <root>/ViT/                config.json
+    <root>/work/models/data/   data_key_imgtxt_random.csv (task 2, TIR columns) + text-image/T{id}.jpg
+    <root>/work/models/results/mm_late/testing/
+so that  `cd <root>/work/models/run && python -m smtc_amd.run_mm_late --task 2 --testing ...`  exercises the real pipeline
+(data key -> normalize_tweet -> tokenizer -> PIL decode/resize/normalise -> model).  The shipped reference data keys are
+header-only, and no tokenizer / weights exist offline, hence this generator.
+usage: make_dummy_task.py ROOT [n_rows] [layers]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+
+def main(root, n=240, layers=2):
+    from PIL import Image
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors, trainers
+    from transformers import PreTrainedTokenizerFast
+    rng = np.random.RandomState(0)
+    words = [f"w{i}" for i in range(300)] + ["@USER", "HTTPURL", "sarcasm", "image", "text", "adds", "nothing"]
+    texts = []
+    for i in range(n):
+        k = rng.randint(3, 40)
+        t = " ".join(rng.choice(words, k))
+        if i % 5 == 0:
+            t += " https://t.co/abc" + str(i)
+        if i % 7 == 0:
+            t = "@someone " + t
+        texts.append(t)
+    run = os.path.join(root, "work", "models", "run")
+    data = os.path.join(root, "work", "models", "data")
+    os.makedirs(run, exist_ok=True)
+    os.makedirs(os.path.join(data, "text-image"), exist_ok=True)
+    os.makedirs(os.path.join(root, "work", "models", "results", "mm_late", "testing"), exist_ok=True)
+    # ---- data key, task 2 columns (models/config.py:18-26)
+    labels = rng.randint(0, 4, n)
+    cols = ["image_adds_text_repr", "image_adds_text_notrepr", "image_notadds_text_repr", "image_notadds_text_notrepr"]
+    split = np.array(["train"] * (n * 2 // 3) + ["val"] * (n // 6) + ["test"] * (n - n * 2 // 3 - n // 6))
+    with open(os.path.join(data, "data_key_imgtxt_random.csv"), "w") as f:
+        f.write("tweet_id,text," + ",".join(cols) + ",split\n")
+        for i in range(n):
+            onehot = ["1" if labels[i] == c else "0" for c in range(4)]
+            f.write(f"{1000 + i},\"{texts[i]}\"," + ",".join(onehot) + f",{split[i]}\n")
+            img = Image.fromarray(rng.randint(0, 256, (rng.randint(60, 300), rng.randint(60, 300), 3), dtype=np.uint8))
+            img.save(os.path.join(data, "text-image", f"T{1000 + i}.jpg"), quality=80)
+    # ---- tokenizer with the XLM-R special-token ids (<s> 0, <pad> 1, </s> 2, <unk> 3)
+    tok = Tokenizer(models.WordLevel(unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    trainer = trainers.WordLevelTrainer(special_tokens=["<s>", "<pad>", "</s>", "<unk>"])
+    from smtc_amd.datasets import normalize_tweet
+    tok.train_from_iterator([normalize_tweet(t) for t in texts], trainer)
+    tok.post_processor = processors.TemplateProcessing(single="<s> $A </s>", special_tokens=[("<s>", 0), ("</s>", 2)])
+    bdir, vdir = os.path.join(root, "BERNICE"), os.path.join(root, "ViT")
+    os.makedirs(bdir, exist_ok=True)
+    os.makedirs(vdir, exist_ok=True)
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", pad_token="<pad>", unk_token="<unk>",
+                                   cls_token="<s>", sep_token="</s>")
+    fast.save_pretrained(bdir)
+    with open(os.path.join(bdir, "config.json"), "w") as f:
+        json.dump({"model_type": "xlm-roberta", "vocab_size": max(64, tok.get_vocab_size()), "max_position_embeddings": 130, "type_vocab_size": 1,
+                   "num_hidden_layers": layers, "layer_norm_eps": 1e-5, "pad_token_id": 1, "hidden_dropout_prob": 0.1,
+                   "attention_probs_dropout_prob": 0.1, "hidden_size": 768, "num_attention_heads": 12, "intermediate_size": 3072}, f)
+    with open(os.path.join(vdir, "config.json"), "w") as f:
+        json.dump({"model_type": "vit", "num_hidden_layers": layers, "image_size": 224, "patch_size": 16, "layer_norm_eps": 1e-12,
+                   "hidden_size": 768, "num_attention_heads": 12, "intermediate_size": 3072}, f)
+    return run
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import smtc_amd  # noqa: F401
+    print(main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 240, int(sys.argv[3]) if len(sys.argv) > 3 else 2))
