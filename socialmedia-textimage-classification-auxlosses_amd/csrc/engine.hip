@@ -251,6 +251,8 @@ void build_workspace(mmhip_engine& e) {
     e.g_set[1][3] = w.take(Mt * H * 2); e.g_set[1][4] = w.take(Mt * H * 2); e.g_set[1][5] = w.take(Mt * 3 * H * 2);
     {
         size_t pf = partial_floats_rows((int)Mt, (int)H, 3), pc = partial_floats_colsum((int)Mt, (int)(3 * H > I ? 3 * H : I));
+        const size_t pe = partial_floats_embed((int)Bt, (int)Tm, (int)H);
+        if (pe > pf) pf = pe;
         e.g_partial = w.take((pf > pc ? pf : pc) * 4);
         e.g_partial_side = w.take((pf > pc ? pf : pc) * 4);
     }

@@ -28,7 +28,7 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
 // weighted sums accumulate in registers and are combined across the 4 waves through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void fusion_attn_fwd_kernel(FusionAttnArgs a) {
-    __shared__ float q[1024];
+    __shared__ __attribute__((aligned(16))) float q[1024];
     __shared__ float sc[256];
     __shared__ float red[4];
     __shared__ float part[4][1024];
@@ -37,15 +37,24 @@ __global__ __launch_bounds__(256) void fusion_attn_fwd_kernel(FusionAttnArgs a) 
     __syncthreads();
     const T* xv = (const T*)a.xv + (size_t)b * a.P * a.H;
     const int nch = a.H >> 2;                   // 4-element chunks; lane owns chunks lane, lane+64, ...
-    for (int j = w; j < a.P; j += 4) {
-        float s = 0.f;
+    // dots of 4 tokens at a time per wave: the four wave reductions interleave, hiding the cross-lane latency
+    for (int j0 = w * 4; j0 < a.P; j0 += 16) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ch = lane; ch < nch; ch += 64) {
-            typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(xv + (size_t)j * a.H + ch * 4);
+            const f32x4 qq = *reinterpret_cast<const f32x4*>(q + ch * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s += to_f<T>(x[e]) * q[ch * 4 + e];
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(j0 + u, a.P - 1);
+                typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(xv + (size_t)j * a.H + ch * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[u] += to_f<T>(x[e]) * qq[e];
+            }
         }
-        s = wave_sum(s);
-        if (lane == 0) sc[j] = s * a.scale;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], o);
+        if (lane < 4 && j0 + lane < a.P) sc[j0 + lane] = s[lane] * a.scale;
     }
     __syncthreads();
     const float v = threadIdx.x < a.P ? sc[threadIdx.x] : -INFINITY;
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(256) void fusion_attn_fwd_kernel(FusionAttnArgs a) 
 }
 template <typename T>
 __global__ __launch_bounds__(256) void fusion_attn_bwd_kernel(FusionAttnBwdArgs a) {
-    __shared__ float dxb[1024];
+    __shared__ __attribute__((aligned(16))) float dxb[1024];
     __shared__ float ds[256];
     __shared__ float red[4];
     __shared__ float part[4][1024];
@@ -93,15 +102,23 @@ __global__ __launch_bounds__(256) void fusion_attn_bwd_kernel(FusionAttnBwdArgs 
     __syncthreads();
     const T* xv = (const T*)a.xv + (size_t)b * a.P * a.H;
     const int nch = a.H >> 2;
-    for (int j = w; j < a.P; j += 4) {
-        float s = 0.f;
+    for (int j0 = w * 4; j0 < a.P; j0 += 16) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ch = lane; ch < nch; ch += 64) {
-            typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(xv + (size_t)j * a.H + ch * 4);
+            const f32x4 qq = *reinterpret_cast<const f32x4*>(dxb + ch * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s += to_f<T>(x[e]) * dxb[ch * 4 + e];
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(j0 + u, a.P - 1);
+                typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(xv + (size_t)j * a.H + ch * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[u] += to_f<T>(x[e]) * qq[e];
+            }
         }
-        s = wave_sum(s);
-        if (lane == 0) ds[j] = s;          // dp_j
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], o);
+        if (lane < 4 && j0 + lane < a.P) ds[j0 + lane] = s[lane];          // dp_j
     }
     __syncthreads();
     const float p = threadIdx.x < a.P ? a.prob[(size_t)bt * a.P + threadIdx.x] : 0.f;

@@ -122,6 +122,7 @@ hipError_t launch_vit_assemble(const void* patches, const float* cls, const floa
 hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s, float* partial = nullptr, float alpha = 1.0f);   // out[c] += sum_r x[r][c]
 size_t partial_floats_rows(int rows, int width, int nvec);
 size_t partial_floats_colsum(int rows, int cols);
+size_t partial_floats_embed(int posts, int T, int width);
 hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s);
 static constexpr int CAST_MAX_GROUP = 4;
 struct CastMat { const float* src; void* dst; void* dstT; int rows, cols, tile_start; };

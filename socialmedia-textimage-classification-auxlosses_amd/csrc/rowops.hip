@@ -277,23 +277,34 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a) {
 
 // backward: dropout -> LN backward (from saved xhat, rstd) -> scatter-add into word / position / type tables.
 // Rows of nn.Embedding(padding_idx=...) get no gradient (word row pad_id; XLM-R position row pad_id).
+// Block (t, g) = token slot t of posts 16g..16g+15, 4 posts per wave: every post of a slot normally shares one
+// position id, so the position-row gradient is summed in registers, combined over the block's waves in LDS and
+// leaves as ONE atomic row per block (same-address atomics from every post were the cost of the row-major
+// version).  Word rows are scattered with lane-dense atomics (each wave instruction covers 256 contiguous bytes)
+// staged through a wave-private LDS row.
+static constexpr int EMB_POSTS_PER_BLOCK = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
-    __shared__ float red[3][4][1024];
+    __shared__ __attribute__((aligned(16))) float red[3][4][1024];
+    float (*rowbuf)[1024] = red[0];          // wave-private staging rows while the posts are walked; reductions afterwards
+    __shared__ int wpid[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int nch = a.H >> 2, rows = a.posts * a.T;
+    const int nch = a.H >> 2;
+    const int tok = blockIdx.x, blk = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
     const float al = a.alpha == 0.f ? 1.f : a.alpha;
-    float dg[MAXC][4], db[MAXC][4], dt[MAXC][4], gam[MAXC][4];
+    float dg[MAXC][4], db[MAXC][4], dt[MAXC][4], gam[MAXC][4], pacc[MAXC][4];
 #pragma unroll
     for (int t = 0; t < MAXC; ++t) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dg[t][e] = 0.f; db[t][e] = 0.f; dt[t][e] = 0.f; gam[t][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { dg[t][e] = 0.f; db[t][e] = 0.f; dt[t][e] = 0.f; gam[t][e] = 0.f; pacc[t][e] = 0.f; }
         if (lane + 64 * t < nch) load4<float>(a.gamma + (lane + 64 * t) * 4, gam[t]);
     }
-    const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK;
-    for (int rr = w; rr < LN_ROWS_PER_BLOCK; rr += 4) {
-        const int row = r0 + rr;
-        if (row >= rows) break;
+    int pid0 = -1;
+    const int p0 = blockIdx.y * EMB_POSTS_PER_BLOCK + w * (EMB_POSTS_PER_BLOCK / 4);
+    for (int pp = 0; pp < EMB_POSTS_PER_BLOCK / 4; ++pp) {
+        const int post = p0 + pp;
+        if (post >= a.posts) break;
+        const int row = post * a.T + tok;
         const float rstd = a.rstd[row];
         float xh[MAXC][4], g[MAXC][4];
         float s1 = 0.f, s2 = 0.f;
@@ -328,19 +339,35 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
         const int64_t id = a.ids[row];
         const int pid = a.pos_ids[row];
         float* wrow = (id != a.pad_id) ? a.dword + (size_t)id * a.H : nullptr;
-        float* prow = (pid != a.pos_pad_id) ? a.dpos + (size_t)pid * a.H : nullptr;
+        const bool pos_on = pid != a.pos_pad_id;
+        if (pos_on && pid0 < 0) pid0 = pid;
+        const bool pos_reg = pos_on && pid == pid0;
+        float* prow = (pos_on && !pos_reg) ? a.dpos + (size_t)pid * a.H : nullptr;     // irregular slot: direct atomics
 #pragma unroll
         for (int t = 0; t < MAXC; ++t) {
             const int c = lane + 64 * t;
             if (c < nch) {
+                f32x4 ov;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float o = rstd * (g[t][e] - c1 - xh[t][e] * c2);
                     dt[t][e] += o;
-                    if (wrow) atomicAdd(wrow + c * 4 + e, o * al);
-                    if (prow) atomicAdd(prow + c * 4 + e, o * al);
+                    if (pos_reg) pacc[t][e] += o;
+                    ov[e] = o * al;
                 }
+                *reinterpret_cast<f32x4*>(&rowbuf[w][c * 4]) = ov;
             }
+        }
+        if (wrow || prow) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int c = lane; c < a.H; c += 64) {
+                const float o = rowbuf[w][c];
+                if (wrow) atomicAdd(wrow + c, o);
+                if (prow) atomicAdd(prow + c, o);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 #pragma unroll
@@ -351,19 +378,41 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
                 const int c = (lane + 64 * t) * 4 + e;
                 red[0][w][c] = dg[t][e]; red[1][w][c] = db[t][e]; red[2][w][c] = dt[t][e];
             }
+    if (lane == 0) wpid[w] = pid0;
     __syncthreads();
     for (int c = threadIdx.x; c < a.H; c += 256) {
         const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
         const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
         const float st = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
         if (a.partial) {
-            a.partial[(size_t)blockIdx.x * a.H + c] = sg;
-            a.partial[((size_t)gridDim.x + blockIdx.x) * a.H + c] = sb;
-            a.partial[((size_t)2 * gridDim.x + blockIdx.x) * a.H + c] = st;
+            a.partial[(size_t)blk * a.H + c] = sg;
+            a.partial[((size_t)nblk + blk) * a.H + c] = sb;
+            a.partial[((size_t)2 * nblk + blk) * a.H + c] = st;
         } else {
             atomicAdd(a.dgamma + c, sg * al);
             atomicAdd(a.dbeta + c, sb * al);
             atomicAdd(a.dtype + c, st * al);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t)
+        if (lane + 64 * t < nch)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rowbuf[w][(lane + 64 * t) * 4 + e] = pacc[t][e] * al;
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.H; c += 256) {
+        // position rows: waves that share an id leave as one atomic (the first such wave owns the sum)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pi = wpid[i];
+            if (pi < 0) continue;
+            bool owner = true;
+            for (int j = 0; j < i; ++j) owner = owner && wpid[j] != pi;
+            if (!owner) continue;
+            float sp = rowbuf[i][c];
+            for (int j = i + 1; j < 4; ++j) if (wpid[j] == pi) sp += rowbuf[j][c];
+            atomicAdd(a.dpos + (size_t)pi * a.H + c, sp);
         }
     }
 }
@@ -581,6 +630,7 @@ hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s) {
 size_t partial_floats_rows(int rows, int width, int nvec) {   // LN backward may use 3 vectors
     if (nvec < 3) nvec = 3;
     return (size_t)nvec * ((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK) * width; }
+size_t partial_floats_embed(int posts, int T, int width) { return (size_t)3 * T * ((posts + EMB_POSTS_PER_BLOCK - 1) / EMB_POSTS_PER_BLOCK) * width; }
 size_t partial_floats_colsum(int rows, int cols) { return (size_t)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS) * cols; }
 
 hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s) {
@@ -606,11 +656,12 @@ hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s) {
 }
 hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s) {
     if (a.posts <= 0) return hipSuccess;
-    const int grid = (a.posts * a.T + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
-    if (dtype == DT_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(embed_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    if (a.H % 4 || a.H > 1024) return hipErrorInvalidValue;
+    const dim3 grid(a.T, (a.posts + EMB_POSTS_PER_BLOCK - 1) / EMB_POSTS_PER_BLOCK);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(embed_bwd_kernel<f16_t>, grid, dim3(256), 0, s, a);
     if (a.partial) {
-        launch_reduce_partials(a.partial, grid, a.H, a.dgamma, s, a.alpha == 0.f ? 1.f : a.alpha, a.dbeta, a.dtype);
+        launch_reduce_partials(a.partial, (int)(grid.x * grid.y), a.H, a.dgamma, s, a.alpha == 0.f ? 1.f : a.alpha, a.dbeta, a.dtype);
     }
     return hipGetLastError();
 }
