@@ -113,6 +113,18 @@ int mmhip_stage_grad_range(mmhip_handle h, int stage, uint64_t* begin, uint64_t*
 int mmhip_adamw(float* p, float* g, float* m, float* v, uint64_t n, float lr, float beta1, float beta2, float eps,
                 float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
 
+/* Row-lazy form of the same update for the word-embedding table [rows, width] (69 % of Bernice's parameters; at most B*T
+ * of its rows receive a gradient per step).  `row_state` is a caller-owned byte per row, 4-byte aligned, allocated with
+ * rows rounded up to a multiple of 4 and zero-initialised together with the moments: bit0 = the row holds a gradient now
+ * (set by the backward pass once mmhip_set_row_state() registered the array, and by the caller for rows it adds itself,
+ * e.g. after a data-parallel row exchange), bit1 = the row's moments are non-zero.  Rows with state 0 only take the
+ * decoupled decay, which is bit-identical to what torch.optim.AdamW computes for g = m = v = 0 (models/mm_late.py:420-422
+ * runs the dense optimizer over nn.Embedding's dense gradient). */
+int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width, uint8_t* row_state, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+/* register (or with NULL remove) the word-table row flags the backward pass maintains */
+int mmhip_set_row_state(mmhip_handle h, uint8_t* row_state);
+
 /* ---- timing of the dominant kernel for bench.py: HIP events recorded around every MFMA NT-GEMM launch issued by the
  * handle on its stream while enabled; returns accumulated milliseconds, launches and algorithmic FLOPs since reset. */
 int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_t* launches, double* flops);

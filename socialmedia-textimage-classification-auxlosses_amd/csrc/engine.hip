@@ -54,6 +54,7 @@ struct mmhip_engine {
     size_t ids_all, mask_all, pos_ids, maskbias, x0, xhat_emb, rstd_emb;
     size_t v_patches, v_pe, v_x, v_ln, v_qkv, v_ctx, v_h, v_out;                             // ViT ping-pong
     size_t g_partial, g_partial_side;
+    uint8_t* word_row_state = nullptr;     // caller-owned row flags of the word table (mmhip_set_row_state)
     size_t g_set[2][6];      // double-buffered backward temporaries read by the side stream: dpre2, ddrop2, du, dpre1, ddrop1, dqkv
     size_t g_dx, g_dx2, g_dpre, g_ddrop, g_dpre1, g_ddrop1, g_dqkv, g_dctx, g_du;                               // backward temporaries
     // heads (fp32) ----------------------------------------------------------------------
@@ -666,6 +667,7 @@ int embed_backward(mmhip_engine& e, hipStream_t s) {
     b.drop = make_drop(c.p_hidden, e.seed, STREAM_EMBED, e.train_mode);
     b.partial = e.wsp<float>(e.g_partial);
     b.alpha = 1.0f / e.gscale();
+    b.row_state = e.word_row_state;
     CHECK_HIP(launch_embed_bwd(b, e.dt(), s));
     return 0;
 }
@@ -868,6 +870,26 @@ int mmhip_adamw(float* p, float* g, float* m, float* v, uint64_t n, float lr, fl
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
     a.zero_grad = zero_grad; a.grad_scale = grad_scale;
     CHECK_HIP(launch_adamw(a, (hipStream_t)stream));
+    return 0;
+}
+
+int mmhip_set_row_state(mmhip_handle h, uint8_t* row_state) {
+    if (!h) return MMHIP_E_INVALID;
+    if ((uintptr_t)row_state & 3) return MMHIP_E_INVALID;
+    h->word_row_state = row_state;
+    return 0;
+}
+
+int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width, uint8_t* row_state, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+    if (!p || !g || !m || !v || !row_state || step < 1 || rows < 0 || width <= 0 || width % 4) return MMHIP_E_INVALID;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MMHIP_E_INVALID;
+    AdamWArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = (size_t)rows * width; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)beta1, step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+    a.zero_grad = zero_grad; a.grad_scale = grad_scale;
+    CHECK_HIP(launch_adamw_rows(a, rows, width, row_state, (hipStream_t)stream));
     return 0;
 }
 

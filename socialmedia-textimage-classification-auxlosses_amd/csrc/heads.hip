@@ -393,6 +393,58 @@ hipError_t launch_bias_grad_f32(const float* d, int rows, int cols, int ld, floa
     hipLaunchKernelGGL(bias_grad_f32_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, d, rows, cols, ld, out, accumulate);
     return hipGetLastError();
 }
+// Row-lazy variant for embedding tables (the word table is 69 % of Bernice's parameters and <= B*T of its 250 002 rows see
+// a gradient per step).  One wave per row per iteration; the state byte is wave-uniform.
+//   state 0                : g = m = v = 0  ->  p *= (1 - lr*wd)   (exactly what the dense kernel computes; 8 B/param)
+//   ROW_HAS_GRAD           : full update, gradient cleared, state -> ROW_HAS_MOMENTS
+//   ROW_HAS_MOMENTS only   : full update with g = 0 (gradient neither read nor cleared)
+__global__ __launch_bounds__(256) void adamw_rows_kernel(AdamWArgs a, int rows, int width, uint8_t* __restrict__ state) {
+    const int lane = threadIdx.x & 63;
+    const int nch = width >> 2;
+    const float one_m_b1 = 1.f - a.beta1, one_m_b2 = 1.f - a.beta2;
+    const float decay = 1.f - a.lr * a.wd, step = a.lr / a.bc1;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const int st = state[row];
+        f32x4* __restrict__ p4 = reinterpret_cast<f32x4*>(a.p + (size_t)row * width);
+        if (st == 0) {
+            for (int c = lane; c < nch; c += 64) {
+                f32x4 p = p4[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[e] *= decay;
+                p4[c] = p;
+            }
+            continue;
+        }
+        f32x4* __restrict__ g4 = reinterpret_cast<f32x4*>(a.g + (size_t)row * width);
+        f32x4* __restrict__ m4 = reinterpret_cast<f32x4*>(a.m + (size_t)row * width);
+        f32x4* __restrict__ v4 = reinterpret_cast<f32x4*>(a.v + (size_t)row * width);
+        const bool has_g = st & ROW_HAS_GRAD;
+        for (int c = lane; c < nch; c += 64) {
+            f32x4 p = p4[c], m = m4[c], v = v4[c];
+            f32x4 g = has_g ? g4[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ge = g[e] * a.grad_scale;
+                p[e] *= decay;
+                m[e] = m[e] + one_m_b1 * (ge - m[e]);
+                v[e] = v[e] * a.beta2 + one_m_b2 * ge * ge;
+                const float denom = sqrtf(v[e]) / a.bc2_sqrt + a.eps;
+                p[e] -= step * (m[e] / denom);
+            }
+            p4[c] = p; m4[c] = m; v4[c] = v;
+            if (has_g && a.zero_grad) g4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int nst = ROW_HAS_MOMENTS | ((has_g && !a.zero_grad) ? ROW_HAS_GRAD : 0);
+        if (lane == 0 && nst != st) state[row] = (uint8_t)nst;
+    }
+}
+hipError_t launch_adamw_rows(const AdamWArgs& a, int rows, int width, uint8_t* row_state, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (width % 4 || !row_state) return hipErrorInvalidValue;
+    const int g = (rows + 3) / 4;
+    hipLaunchKernelGGL(adamw_rows_kernel, dim3(g > 16384 ? 16384 : g), dim3(256), 0, s, a, rows, width, row_state);
+    return hipGetLastError();
+}
 hipError_t launch_adamw(const AdamWArgs& a, hipStream_t s) {
     if (!a.n) return hipSuccess;
     size_t g = (a.n / 4 + 255) / 256;

@@ -111,8 +111,9 @@ struct EmbedBwdArgs {
     float* dword; float* dpos; float* dtype; float* dgamma; float* dbeta;
     int posts, T, H, pad_id, pos_pad_id;
     DropCfg drop;
-    float* partial;       // optional workspace of partial_floats_rows(posts*T, H, 3) floats
+    float* partial;       // optional workspace of partial_floats_embed(posts, T, H) floats
     float alpha;          // every parameter gradient is multiplied by alpha (0 is read as 1)
+    uint8_t* row_state;   // optional [vocab] row flags of the word table: bit0 is set on every row that receives a gradient
 };
 hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s);
 hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s);
@@ -188,5 +189,9 @@ struct AdamWArgs {
     float grad_scale;     // gradients are multiplied by this before use (1/world for DP averaging)
 };
 hipError_t launch_adamw(const AdamWArgs& a, hipStream_t s);
+// row-lazy AdamW over a [rows, width] table (a.p .. a.v, a.n = rows*width): rows whose state byte is 0 (no gradient now,
+// moments still exactly zero) only take the decoupled decay -- bit-identical to the dense update, a quarter of its traffic
+enum { ROW_HAS_GRAD = 1, ROW_HAS_MOMENTS = 2 };
+hipError_t launch_adamw_rows(const AdamWArgs& a, int rows, int width, uint8_t* row_state, hipStream_t s);
 
 }  // namespace mmhip

@@ -358,6 +358,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
                 *reinterpret_cast<f32x4*>(&rowbuf[w][c * 4]) = ov;
             }
         }
+        if (wrow && a.row_state && lane == 0)        // 32-bit atomic OR: neighbouring rows' flags share the word
+            atomicOr(reinterpret_cast<unsigned*>(a.row_state) + (id >> 2), 1u << (8 * (int)(id & 3)));
         if (wrow || prow) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();

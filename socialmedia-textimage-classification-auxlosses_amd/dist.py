@@ -43,10 +43,11 @@ def allreduce_range(flat_grad, begin, end, async_op=True):
     return td.all_reduce(flat_grad[begin:end], op=td.ReduceOp.SUM, async_op=async_op)
 
 
-def sparse_rows_exchange(table_grad, ids):
+def sparse_rows_exchange(table_grad, ids, row_state=None):
     """table_grad [V, H] holds this rank's gradient rows (non-zero only for rows in `ids`); afterwards it holds the sum
     over ranks.  Fixed-size payload (no host sync): rows are sent once per distinct id (first occurrence in sorted order),
-    the other slots carry zeros."""
+    the other slots carry zeros.  `row_state` (uint8 per row, include/mmhip.h: mmhip_adamw_rows) gets bit0 set on the
+    rows received from the other ranks."""
     W = world_size()
     if W == 1:
         return
@@ -63,6 +64,8 @@ def sparse_rows_exchange(table_grad, ids):
     for r in range(W):
         if r != me:
             table_grad.index_add_(0, ids_all[r], pay_all[r])
+            if row_state is not None:
+                row_state[ids_all[r]] = row_state[ids_all[r]] | 1
 
 
 def exchange_stage(model, stage, n_stage, use_itc, use_itm):
@@ -81,5 +84,5 @@ def exchange_stage(model, stage, n_stage, use_itc, use_itm):
         works.append(w)
     V, H = word["shape"]
     table = model._flat_grad[word["offset"]: word["offset"] + V * H].view(V, H)
-    sparse_rows_exchange(table, model._last["ids_all"])
+    sparse_rows_exchange(table, model._last["ids_all"], getattr(model, "_word_row_state", None))
     return works

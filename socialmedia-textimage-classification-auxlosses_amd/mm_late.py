@@ -183,6 +183,10 @@ class MM_Model(nn.Module):
                 self._infos.append(dict(name=pi.name.decode(), shape=tuple(pi.dims[: pi.ndim]), buffer=pi.buffer, group=pi.group,
                                         offset=int(pi.offset), numel=int(pi.numel)))
             self._register_parameters()
+            # word-table row flags shared by the backward pass and the row-lazy AdamW (include/mmhip.h: mmhip_adamw_rows)
+            self._word_info = next(i for i in self._train_params if i["name"].endswith("word_embeddings.weight"))
+            self._word_row_state = torch.zeros((self._word_info["shape"][0] + 3) // 4 * 4, dtype=torch.uint8, device=dev)
+        _lib.check(lib.mmhip_set_row_state(h, _lib.ptr(self._word_row_state)), "set_row_state")
         self._ws = None
         torch.cuda.empty_cache()
         self._ws = torch.empty(lib.mmhip_workspace_bytes(h), dtype=torch.uint8, device=dev)
@@ -449,12 +453,21 @@ class MMLate_Model(object):
         m, lib = self.model, _lib.lib()
         if self._opt is None:
             self._opt = (torch.zeros_like(m._flat_train), torch.zeros_like(m._flat_train))
+            m._word_row_state.bitwise_and_(1)                      # fresh moments: no row has any yet
         em, ev = self._opt
+        at = lambda t, el: C.c_void_p(t.data_ptr() + el * 4)
+        V, H = m._word_info["shape"]
+        w0 = m._word_info["offset"]                                 # the word table closes the trainable buffer
         for b, e in m.active_ranges(self.use_clip_loss, self.use_tim_loss):
-            off = b * 4
-            _lib.check(lib.mmhip_adamw(C.c_void_p(m._flat_train.data_ptr() + off), C.c_void_p(m._flat_grad.data_ptr() + off),
-                                       C.c_void_p(em.data_ptr() + off), C.c_void_p(ev.data_ptr() + off), e - b, lr, 0.9, 0.999, 1e-8,
-                                       weight_decay, step, 1.0 / self.world, 1, _lib.stream_ptr()), "adamw")
+            dense_end = min(e, w0)
+            if dense_end > b:
+                _lib.check(lib.mmhip_adamw(at(m._flat_train, b), at(m._flat_grad, b), at(em, b), at(ev, b), dense_end - b, lr, 0.9, 0.999,
+                                           1e-8, weight_decay, step, 1.0 / self.world, 1, _lib.stream_ptr()), "adamw")
+            if e > w0:
+                # rows without gradient and without moments only decay: same values as the dense update, 1/4 of its traffic
+                _lib.check(lib.mmhip_adamw_rows(at(m._flat_train, w0), at(m._flat_grad, w0), at(em, w0), at(ev, w0), V, H,
+                                                _lib.ptr(m._word_row_state), lr, 0.9, 0.999, 1e-8, weight_decay, step,
+                                                1.0 / self.world, 1, _lib.stream_ptr()), "adamw_rows")
 
     @staticmethod
     def _unpack(batch):

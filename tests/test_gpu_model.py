@@ -185,6 +185,85 @@ def test_adamw_matches_golden_and_skips_inactive():
         assert g.abs().max().item() == 0.0
 
 
+def test_adamw_rows_bit_identical_to_dense():
+    """row-lazy AdamW over an embedding table (rows without gradient and moments only decay) == the dense kernel, bit for
+    bit, over steps with changing touched-row sets; flags follow the protocol of include/mmhip.h"""
+    from smtc_amd import _lib
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    V, H = 1003, 768
+    p_d = torch.randn(V, H, generator=gen).to(dev)
+    p_r = p_d.clone()
+    m_d, v_d, m_r, v_r = (torch.zeros(V, H, device=dev) for _ in range(4))
+    state = torch.zeros((V + 3) // 4 * 4, dtype=torch.uint8, device=dev)
+    g_r = torch.zeros(V, H, device=dev)
+    lib = _lib.lib()
+    for step in range(1, 6):
+        rows = torch.randperm(V, generator=gen)[: 40 + 10 * step].to(dev)
+        g = torch.zeros(V, H, device=dev)
+        g[rows] = torch.randn(len(rows), H, generator=gen).to(dev)
+        g_r += g
+        state[rows] = state[rows] | 1
+        g_d = g.clone()
+        _lib.check(lib.mmhip_adamw(_lib.ptr(p_d), _lib.ptr(g_d), _lib.ptr(m_d), _lib.ptr(v_d), p_d.numel(), 1e-3, 0.9, 0.999, 1e-8, 0.01, step, 0.5, 1,
+                                   _lib.stream_ptr()))
+        _lib.check(lib.mmhip_adamw_rows(_lib.ptr(p_r), _lib.ptr(g_r), _lib.ptr(m_r), _lib.ptr(v_r), V, H, _lib.ptr(state), 1e-3, 0.9, 0.999, 1e-8,
+                                        0.01, step, 0.5, 1, _lib.stream_ptr()))
+        assert torch.equal(p_d, p_r) and torch.equal(m_d, m_r) and torch.equal(v_d, v_r), step
+        assert g_r.abs().max().item() == 0.0
+        st = state[:V].cpu()
+        assert int((st & 1).sum()) == 0 and int((st == 2).sum()) == int((m_d.abs().sum(1) > 0).sum())
+    # zero_grad = 0 keeps gradient and flag
+    rows = torch.arange(7, device=dev)
+    g_r[rows] = 1.0
+    state[rows] = state[rows] | 1
+    _lib.check(lib.mmhip_adamw_rows(_lib.ptr(p_r), _lib.ptr(g_r), _lib.ptr(m_r), _lib.ptr(v_r), V, H, _lib.ptr(state), 1e-3, 0.9, 0.999, 1e-8, 0.01, 6,
+                                    1.0, 0, _lib.stream_ptr()))
+    assert g_r[:7].min().item() == 1.0 and int((state[:7] & 1).sum()) == 7
+    assert lib.mmhip_adamw_rows(_lib.ptr(p_r), _lib.ptr(g_r), _lib.ptr(m_r), _lib.ptr(v_r), V, 770, _lib.ptr(state), 1e-3, 0.9, 0.999, 1e-8, 0.01, 1,
+                                1.0, 1, _lib.stream_ptr()) < 0
+
+
+def test_trainer_word_table_equals_dense_adamw():
+    """MMLate_Model.train_step (row-lazy word table) == the same steps with one dense AdamW over the whole buffer"""
+    import types
+    from smtc_amd import _lib
+    cfgd = types.SimpleNamespace(batch_size=4, num_labels=3, use_clip_loss=False, beta_itc=0.1, use_tim_loss=False, beta_itm=0.1,
+                                 max_length=32, dropout=0.05)
+    arch = dict(layers_txt=1, layers_img=1, vocab=3000, max_pos=130)
+    ocfg = O.OracleConfig(layers_txt=1, layers_img=1, vocab=3000, max_pos=130, num_labels=3)
+    a = MMLate_Model(cfgd, "bernice", "vit", "attention", arch=arch, seed=3)
+    b = MMLate_Model(cfgd, "bernice", "vit", "attention", arch=arch, seed=3)
+
+    def dense(self, lr, wd, step):
+        m = self.model
+        if self._opt is None:
+            self._opt = (torch.zeros_like(m._flat_train), torch.zeros_like(m._flat_train))
+        at = lambda tns, el: C.c_void_p(tns.data_ptr() + el * 4)
+        for bb, ee in m.active_ranges(False, False):
+            _lib.check(_lib.lib().mmhip_adamw(at(m._flat_train, bb), at(m._flat_grad, bb), at(self._opt[0], bb), at(self._opt[1], bb), ee - bb, lr,
+                                              0.9, 0.999, 1e-8, wd, step, 1.0, 1, _lib.stream_ptr()))
+    import ctypes as C
+    b._adamw = types.MethodType(dense, b)
+    for step in range(1, 5):
+        ids, mask, pixels, onehot = O.synthetic_batch(ocfg, 4, 32, 100 + step, True)
+        for tr in (a, b):
+            tr.model._calls = step               # same dropout stream in both trainers
+            tr.train_step(ids.cuda(), mask.cuda(), pixels, onehot, None, 1e-3, 0.01, step)
+    # the backward's fp32 atomics are not run-to-run bit-stable, so touched values are compared closely, not bitwise
+    assert (a.model._flat_train - b.model._flat_train).abs().max().item() < 2e-5
+    assert (a._opt[0] - b._opt[0]).abs().max().item() < 1e-5 and (a._opt[1] - b._opt[1]).abs().max().item() < 1e-5
+    assert a.model._flat_grad.abs().max().item() == 0.0 and b.model._flat_grad.abs().max().item() == 0.0
+    st = a.model._word_row_state[:3000]
+    touched = int((st == 2).sum())
+    assert 0 < touched < 3000 and int((st & 1).sum()) == 0
+    w = a.model._word_info
+    ta = a.model._flat_train[w["offset"]: w["offset"] + w["numel"]].view(w["shape"])
+    tb = b.model._flat_train[w["offset"]: w["offset"] + w["numel"]].view(w["shape"])
+    assert torch.equal(ta[st == 0], tb[st == 0])            # decay-only rows: bit-identical to the dense update
+    assert a._opt[0][w["offset"]: w["offset"] + w["numel"]].view(w["shape"])[st == 0].abs().max().item() == 0.0
+
+
 def test_trainer_step_and_itm_sampling():
     """fused MMLate_Model.train_step: loss goes down on a fixed batch; parameters outside the active set stay untouched;
     prepare_itm_inputs reproduces the reference's numpy RNG stream (tests/golden/itm_sampling.npz)"""
