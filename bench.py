@@ -103,6 +103,7 @@ def main():
     for _ in range(args.steps):
         step_no += 1
         loss, _ = trainer.train_step(ids, mask, pixels, onehot, None, lr, wd, step_no)
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3        # host time to enqueue a step (no sync inside the loop)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -160,7 +161,7 @@ def main():
                    "step": "full train step: fwd + loss + bwd + grad exchange + AdamW + weight refresh",
                    "posts_per_gpu": B, "text_tokens": T, "image": a["image"], "vocab": a["vocab"], "parallelism": f"dp{world}",
                    "weights": "random-init at true shapes"},
-        "fwd_bwd_ms": round(fb_ms, 3), "fwd_bwd_posts_per_s": round(world * B / (fb_ms * 1e-3), 1),
+        "host_enqueue_ms_per_step": round(host_ms, 3), "fwd_bwd_ms": round(fb_ms, 3), "fwd_bwd_posts_per_s": round(world * B / (fb_ms * 1e-3), 1),
         "model_tflops": round(posts_s * GF_PER_POST[mode] / 1e3, 1),
         "model_frac_of_peak": round(posts_s / world * GF_PER_POST[mode] / 1e3 / PEAK_TFLOPS, 4),
         "final_loss": round(final_loss, 5), "roofline": roofline,

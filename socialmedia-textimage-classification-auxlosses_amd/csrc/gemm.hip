@@ -196,24 +196,26 @@ void gemm_nt_kernel(GemmNTArgs a) {
     }
     // the staging region is wave-private and LDS operations of one wave execute in order: no barrier inside the loop
 #pragma unroll
-    for (int ch = 0; ch < C::TM / 32; ++ch) {
+    for (int ch = 0; ch < (C::FM + 1) / 2; ++ch) {     // FM odd (160-row tiles): the last chunk holds one 16-row fragment
         // compiler-level ordering only (other lanes of this wave read what this lane writes): keep chunk ch's reads
         // above chunk ch+1's writes and the writes above the reads; no instruction is emitted
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < 2; ++ii) {
+            if (ch * 2 + ii >= C::FM) break;
 #pragma unroll
             for (int j = 0; j < C::FN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ep[(ii * 16 + (lane >> 4) * 4 + r) * C::EP_LD + j * 16 + (lane & 15)] = acc[ch * 2 + ii][j][r];
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int row = p * RPP + lane / LPR;
             const int m = m0 + wm * C::TM + ch * 32 + row;
-            if (!ep_lane || row >= 32 || m >= a.M) continue;
+            if (!ep_lane || row >= 32 || ch * 32 + row >= C::TM || m >= a.M) continue;
             f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + row * C::EP_LD + c8), v1 = *reinterpret_cast<const f32x4*>(ep + row * C::EP_LD + c8 + 4);
             float v[8];
 #pragma unroll
@@ -550,7 +552,8 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if ((t >= 1 && t <= 5) && a.N % 128) t = 0;
     if ((t == 8 || t == 9) && a.N % 128) t = 0;
     if (t == 10 && a.N % 96) t = 0;
-    if (t >= 1 && t <= 10) return t;
+    if (t == 11 && a.N % 128) t = 0;
+    if (t >= 1 && t <= 11) return t;
     if (a.N % 128 && a.N % 192 == 0 && a.N % 256) { /* only the 192-wide tiles divide N */ }
     // Measured inside the training step (bench.py with MMHIP_NT_TILE forced, profiles/r01_tile_sweep.txt): 128x128 at two
     // blocks per CU is as fast as any other tile for every shape of this model; the isolated micro-benchmark gains of the
@@ -569,6 +572,16 @@ static int choose_nt_tile(const GemmNTArgs& a) {
         const long c96 = a.N % 96 == 0 ? ((tm * (a.N / 96) + 511) / 512) * 224 : (1L << 60);
         if (c96 < c128) return 10;
     }
+    if (rule == 7 || rule == 8) {
+        // 160-row tiles where they save a round of the 512 block slots (M = 12608 x N = 768: 474 tiles instead of 594)
+        if (a.N % 128 == 0) {
+            const long n128 = a.N / 128;
+            const long c128 = (((long)((a.M + 127) / 128) * n128 + 511) / 512) * 128;
+            const long c160 = (((long)((a.M + 159) / 160) * n128 + 511) / 512) * 160;
+            if (c160 < c128 && (rule == 8 || a.K < 2048)) return 11;
+        }
+        if (a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9;
+    }
     if (a.N % 128 == 0) return 1;
     if (a.N % 192 == 0) return 6;
     return 10;
@@ -577,6 +590,7 @@ static int choose_nt_tile(const GemmNTArgs& a) {
 template <typename T>
 static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
     switch (choose_nt_tile(a)) {
+        case 11: launch_nt_t<T, 160, 128, 2, 2, 2>(a, s); break;      // 474 tiles for M = 12608 (ViT), N = 768: one round of 512 slots
         case 10: launch_nt_t<T, 128, 96, 2, 2, 2>(a, s); break;       // 512 / 1536 tiles for N = 768 / 2304 at M = 8192: whole rounds
         case 9: launch_nt_t<T, 256, 128, 4, 2, 3, 4>(a, s); break;    // 8 consumers + 4 loaders, 3-stage ring
         case 8: launch_nt_t<T, 128, 128, 2, 2, 4, 4>(a, s); break;    // 4 consumers + 4 loaders, 4-stage ring

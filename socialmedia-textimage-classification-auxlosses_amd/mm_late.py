@@ -394,19 +394,26 @@ class MMLate_Model(object):
     # choice(list(others)) per swapped row; sources are read from the original ids, so swaps do not chain)
     def prepare_itm_inputs(self, ids, mask):
         B = ids.shape[0]
-        src, labels = list(range(B)), []
+        src, labels = list(range(B)), [1] * B
         if B > 1:
+            # choice(2) / choice(B-1) consume the legacy RandomState stream exactly like choice([True, False]) /
+            # choice(list(set(range(B)) - {idx})) (one bounded integer each; index 0 is True; the others-list is
+            # ascending), pinned by tests/golden/itm_sampling.npz
+            choice = np.random.choice
             for idx in range(B):
-                if np.random.choice([True, False]):
-                    labels.append(0)
-                    src[idx] = int(np.random.choice(list(set(range(B)) - {idx})))
-                else:
-                    labels.append(1)
-        else:
-            labels.append(1)
-        sel = torch.tensor(src, dtype=torch.int64, device=ids.device)
-        lbl = torch.tensor(labels, dtype=torch.long, device=self.device)
-        return ids.index_select(0, sel).to(self.device), mask.index_select(0, sel).to(self.device), lbl
+                if choice(2) == 0:
+                    labels[idx] = 0
+                    j = int(choice(B - 1))
+                    src[idx] = j if j < idx else j + 1
+        # pinned staging + asynchronous copies: a pageable host-to-device copy would wait for the previous step's kernels
+        # on this stream and stop the host from running ahead of the GPU
+        host = torch.tensor([src, labels], dtype=torch.int64)
+        if ids.is_cuda or self.device.type == "cuda":
+            host = host.pin_memory()
+        dev_pair = host.to(self.device, non_blocking=True)
+        lbl = dev_pair[1]
+        sel = dev_pair[0] if ids.is_cuda else host[0]
+        return (ids.index_select(0, sel).to(self.device, non_blocking=True), mask.index_select(0, sel).to(self.device, non_blocking=True), lbl)
 
     def loss_weights(self):
         """reference :473-487 -> (w_cls, w_itc, w_itm)"""
@@ -421,7 +428,8 @@ class MMLate_Model(object):
         if self.use_tim_loss and tim is None:
             tim = self.prepare_itm_inputs(ids, mask)
         tim_ids, tim_mask, lbl_tim = tim if tim is not None else (None, None, None)
-        m.train()
+        if not m.training:
+            m.train()                              # walks ~370 submodules (1.3 ms of host time): only on a mode change
         m._engine_forward(ids, mask, pixel_values, tim_ids, tim_mask)
         w_cls, w_itc, w_itm = self.loss_weights()
         onehot = onehot.to(self.device, torch.int64).contiguous()
