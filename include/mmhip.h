@@ -129,6 +129,25 @@ int mmhip_set_row_state(mmhip_handle h, uint8_t* row_state);
  * handle on its stream while enabled; returns accumulated milliseconds, launches and algorithmic FLOPs since reset. */
 int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_t* launches, double* flops);
 
+/* ---- input pipeline, image leg: decoded RGB bytes -> pixel_values [n,3,S,S] fp32.
+ * Replaces the ViT feature extractor call made per item inside the reference's Dataset.__getitem__
+ * (models/datasets.py:160-181: Image.open().convert("RGB") -> processor(images=...)): PIL Image.resize((S,S), BILINEAR)
+ * (Pillow's two-pass 22-bit fixed-point resampler, 8-bit intermediate), rescale 1/255, normalize -- bit-identical.
+ *   1. mmhip_image_plan_words / _build: HOST ONLY (no GPU call): per image the resampling windows and integer weights,
+ *      computed in double with Pillow's operation order, written into a caller-owned int32 plan (pin it and copy it to
+ *      the device asynchronously).  offsets[i] = byte offset of image i (uint8, HWC, RGB, rows packed) in `images`; offsets are
+ *      multiples of 16 and `images` is allocated with 16 spare bytes at the end (rows are staged in 16-byte chunks).
+ *   2. mmhip_image_preprocess: two kernel launches on `stream` for the whole batch.  `lut` = float[3][256] on the device:
+ *      channel value -> normalized float (the caller builds it with the reference's float64/float32 arithmetic, so the
+ *      device does integer work only); `tmp` = device scratch of mmhip_image_plan_tmp_bytes(plan) bytes;
+ *      out_u8 (optional, [n,S,S,3]) receives the resized bytes. */
+uint64_t mmhip_image_plan_words(int n, const int32_t* heights, const int32_t* widths, int out_size);   /* 0 = invalid sizes */
+int mmhip_image_plan_build(int n, const uint64_t* offsets, const int32_t* heights, const int32_t* widths, int out_size,
+                           int32_t* plan, uint64_t capacity_words);
+uint64_t mmhip_image_plan_tmp_bytes(const int32_t* plan_host);
+int mmhip_image_preprocess(const uint8_t* images, const int32_t* plan_host, const int32_t* plan_dev, const float* lut,
+                           float* out_f32, uint8_t* out_u8, uint8_t* tmp, void* stream);
+
 /* ---- operator-level entry points (parity tests; the engine calls the same launchers).  dtype = MMHIP_BF16 | MMHIP_F16.
  * 16-bit matrices are row-major with explicit leading dimensions (elements). */
 /* C[M,N] = epilogue(A[M,K] . B[N,K]^T): + bias[N] (fp32, may be NULL); act: 0 none, 1 exact-erf GELU, 2 tanh;

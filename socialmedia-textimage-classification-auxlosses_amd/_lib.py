@@ -54,6 +54,10 @@ _SIGS = {
     "mmhip_adamw": (I, [P, P, P, P, U64, F, F, F, F, F, I, F, I, P]),
     "mmhip_adamw_rows": (I, [P, P, P, P, I, I, P, F, F, F, F, F, I, F, I, P]),
     "mmhip_set_row_state": (I, [P, P]),
+    "mmhip_image_plan_words": (U64, [I, P, P, I]),
+    "mmhip_image_plan_build": (I, [I, P, P, P, I, P, U64]),
+    "mmhip_image_plan_tmp_bytes": (U64, [P]),
+    "mmhip_image_preprocess": (I, [P, P, P, P, P, P, P, P]),
     "mmhip_gemm_timing": (I, [P, I, I, C.POINTER(C.c_double), C.POINTER(U64), C.POINTER(C.c_double)]),
     "mmhip_op_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, P, I, F, U64, U32, P, I, I, I, P]),
     "mmhip_op_gemm_tn": (I, [I, P, I, P, I, P, I, I, I, I, I, I, P]),

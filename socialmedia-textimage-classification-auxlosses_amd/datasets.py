@@ -37,26 +37,40 @@ def prepare_data(data, num_labels, testing=False, nsamples=-1, seed=30):
 class MM_Dataset(torch.utils.data.Dataset):
     """item layout of reference models/datasets.py:125-190"""
 
-    def __init__(self, tweet_ids, texts, labels, tokenizer, max_length, img_file_fmt, image=224):
+    def __init__(self, tweet_ids, texts, labels, tokenizer, max_length, img_file_fmt, image=224, raw_images=False):
         self.ids, self.texts, self.labels = tweet_ids, texts, labels
         self.tok, self.max_length, self.fmt, self.image = tokenizer, max_length, img_file_fmt, image
+        self.raw_images = raw_images        # True: yield the decoded RGB bytes; resize + normalize run on the GPU per batch
+        self._lut = None
 
     def __len__(self):
         return len(self.ids)
 
-    def _pixels(self, tid):
+    def _open(self, tid):
         from PIL import Image
         path = self.fmt.format(tid)
         if not os.path.exists(path):
             path = path.replace(".jpg", ".png")               # reference :164-167 jpg -> png fallback
-        img = Image.open(path).convert("RGB").resize((self.image, self.image), Image.BILINEAR)
-        x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
-        return ((x - 0.5) / 0.5).unsqueeze(0)
+        return Image.open(path).convert("RGB")
+
+    def _pixels(self, tid):
+        """host form of the ViT feature extractor defaults (PIL BILINEAR resize, float64 rescale -> float32, normalize)"""
+        from PIL import Image
+        img = self._open(tid).resize((self.image, self.image), Image.BILINEAR)
+        if self._lut is None:
+            x = (np.arange(256).astype(np.float64) * (1 / 255)).astype(np.float32)
+            self._lut = (x - np.float32(0.5)) / np.float32(0.5)
+        return torch.from_numpy(self._lut[np.asarray(img)]).permute(2, 0, 1).contiguous().unsqueeze(0)
 
     def __getitem__(self, i):
         enc = self.tok(normalize_tweet(self.texts[i]), padding="max_length", truncation=True, max_length=self.max_length, return_tensors="pt")
-        return {"input_ids": enc["input_ids"], "attention_mask": enc["attention_mask"], "pixel_values": self._pixels(self.ids[i]),
-                "labels": torch.from_numpy(self.labels[i]), "data_id": torch.tensor(int(self.ids[i]))}
+        item = {"input_ids": enc["input_ids"], "attention_mask": enc["attention_mask"], "labels": torch.from_numpy(self.labels[i]),
+                "data_id": torch.tensor(int(self.ids[i]))}
+        if self.raw_images:
+            item["image"] = np.asarray(self._open(self.ids[i]))
+        else:
+            item["pixel_values"] = self._pixels(self.ids[i])
+        return item
 
 
 def loaders_from_data_key(cfg, args, trainer):
@@ -66,6 +80,14 @@ def loaders_from_data_key(cfg, args, trainer):
         raise FileNotFoundError(f"tokenizer directory {tdir!r} (config.MODEL_DIR_DICT) not found: use --synthetic, or place the model there")
     tok = AutoTokenizer.from_pretrained(tdir)
     tr, ytr, va, yva, te, yte, w = prepare_data(cfg.data, cfg.num_labels, args.testing, args.nsamples, args.seed)
-    mk = lambda df, y: MM_Dataset(df.tweet_id.values, df.text.values, y, tok, cfg.max_length, cfg.img_fmt, trainer.model.arch["image"])
-    dl = lambda ds, sh: torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh)
+    # image resize + normalize run on the GPU per batch (image_processing.py) unless --cpu_preprocess asks for the host form
+    gpu = not getattr(args, "cpu_preprocess", False) and trainer.device.type == "cuda"
+    size = trainer.model.arch["image"]
+    mk = lambda df, y: MM_Dataset(df.tweet_id.values, df.text.values, y, tok, cfg.max_length, cfg.img_fmt, size, raw_images=gpu)
+    kw = dict(num_workers=int(getattr(args, "num_workers", 0) or 0))
+    if gpu:
+        from .image_processing import GpuImageProcessor, RawImageCollate
+        trainer.image_processor = GpuImageProcessor(size=size, device=trainer.device)
+        kw["collate_fn"] = RawImageCollate(trainer.image_processor)
+    dl = lambda ds, sh: torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh, **kw)
     return dl(mk(tr, ytr), True), dl(mk(va, yva), False), dl(mk(te, yte), False), w

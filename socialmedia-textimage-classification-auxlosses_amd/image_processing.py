@@ -1,0 +1,167 @@
+"""GPU image processor: the image half of the reference's dual-encoder processor call (models/datasets.py:172-181,
+`processor(text=..., images=image, ...)` -> `pixel_values`), i.e. the ViT feature extractor with its defaults
+(resize 224x224 PIL-BILINEAR, rescale 1/255, normalize mean = std = 0.5), computed for a whole batch by two HIP kernel
+launches (csrc/image.hip) instead of per item on the host.  Bit-identical to PIL + the HF arithmetic (tests/test_image_*).
+
+    proc = GpuImageProcessor()                       # same attribute names as ViTImageProcessor
+    pixel_values = proc(list_of_PIL_or_uint8_HWC)["pixel_values"]      # [n, 3, 224, 224] fp32 on the GPU
+
+There is no CPU fallback: without libmmhip.so / a GPU this raises."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _as_rgb_u8(img):
+    """PIL image (any mode -> RGB, as the reference's .convert("RGB")) or uint8 array [h, w, 3] -> contiguous uint8 HWC"""
+    if hasattr(img, "convert"):
+        img = np.asarray(img.convert("RGB"))
+    a = np.ascontiguousarray(img)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError(f"expected a PIL image or a uint8 [h, w, 3] array, got {a.dtype} {a.shape}")
+    return a
+
+
+class GpuImageProcessor:
+    model_input_names = ["pixel_values"]
+
+    def __init__(self, size=224, rescale_factor=1 / 255, image_mean=(0.5, 0.5, 0.5), image_std=(0.5, 0.5, 0.5), device=None):
+        self.size = {"height": int(size), "width": int(size)}
+        self.rescale_factor, self.image_mean, self.image_std = rescale_factor, list(image_mean), list(image_std)
+        self.do_resize = self.do_rescale = self.do_normalize = True
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self._lut = None
+
+    def lut(self):
+        """float32 [3, 256]: byte -> ((float32)(byte * rescale_factor, float64)) - mean) / std in float32 -- the arithmetic
+        of transformers image_transforms.rescale / normalize, evaluated once on the host"""
+        if self._lut is None:
+            x = (np.arange(256).astype(np.float64) * self.rescale_factor).astype(np.float32)
+            m, s = np.asarray(self.image_mean, dtype=np.float32), np.asarray(self.image_std, dtype=np.float32)
+            self._lut = torch.from_numpy(((x[None, :] - m[:, None]) / s[:, None]).astype(np.float32)).to(self.device)
+            torch.cuda.synchronize(self.device)          # built once; later used from any stream
+        return self._lut
+
+    # ---- host half: pack the decoded images and build the resampling plan (no GPU call)
+    def pack(self, images, pin=True):
+        """-> (packed uint8 [total + 16], plan int32 [words], n).  Host work only (no kernel launch): usable as / inside a
+        DataLoader collate_fn; pass pin=False inside worker processes."""
+        lib = _lib.lib()
+        arrs = [_as_rgb_u8(im) for im in images]
+        n, S = len(arrs), self.size["height"]
+        hs = np.asarray([a.shape[0] for a in arrs], dtype=np.int32)
+        ws = np.asarray([a.shape[1] for a in arrs], dtype=np.int32)
+        sizes = (hs.astype(np.int64) * ws * 3 + 15) // 16 * 16
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64) if n else np.zeros(0, dtype=np.uint64)
+        total = int(sizes.sum())
+        # +16: the row-staging kernel reads whole 16-byte chunks; pinned directly when a GPU is present (one host copy)
+        packed = torch.empty(total + 16, dtype=torch.uint8, pin_memory=pin and torch.cuda.is_available())
+        pk = packed.numpy()
+        for a, o in zip(arrs, offs):
+            pk[int(o): int(o) + a.size] = a.reshape(-1)
+        words = int(lib.mmhip_image_plan_words(n, hs.ctypes.data_as(C.c_void_p), ws.ctypes.data_as(C.c_void_p), S))
+        if words == 0:
+            raise _lib.MMHipError("image plan: invalid image sizes")
+        plan = torch.empty(words, dtype=torch.int32)
+        _lib.check(lib.mmhip_image_plan_build(n, offs.ctypes.data_as(C.c_void_p), hs.ctypes.data_as(C.c_void_p), ws.ctypes.data_as(C.c_void_p),
+                                              S, C.c_void_p(plan.data_ptr()), words), "image_plan_build")
+        return packed, plan, n
+
+    # ---- device half
+    def run(self, packed, plan, n, return_u8=False):
+        lib = _lib.lib()
+        S = self.size["height"]
+        if not torch.cuda.is_available():
+            raise _lib.MMHipError("GpuImageProcessor needs a GPU (no CPU fallback)")
+        if n == 0:
+            out = torch.empty(0, 3, S, S, dtype=torch.float32, device=self.device)
+            return (out, torch.empty(0, S, S, 3, dtype=torch.uint8, device=self.device)) if return_u8 else out
+        pin = lambda t: t if t.is_pinned() else t.pin_memory()
+        packed_h, plan_h = pin(packed), pin(plan)
+        packed_d = packed_h.to(self.device, non_blocking=True)
+        plan_d = plan_h.to(self.device, non_blocking=True)
+        tmp = torch.empty(max(int(lib.mmhip_image_plan_tmp_bytes(C.c_void_p(plan_h.data_ptr()))), 16), dtype=torch.uint8, device=self.device)
+        out = torch.empty(n, 3, S, S, dtype=torch.float32, device=self.device)
+        u8 = torch.empty(n, S, S, 3, dtype=torch.uint8, device=self.device) if return_u8 else None
+        _lib.check(lib.mmhip_image_preprocess(_lib.ptr(packed_d), C.c_void_p(plan_h.data_ptr()), _lib.ptr(plan_d), _lib.ptr(self.lut()),
+                                              _lib.ptr(out), _lib.ptr(u8), _lib.ptr(tmp), _lib.stream_ptr()), "image_preprocess")
+        # the pinned staging buffers must outlive the asynchronous copies: tie them to the output
+        out._mmhip_keep = (packed_h, plan_h, packed_d, plan_d, tmp)
+        return (out, u8) if return_u8 else out
+
+    def __call__(self, images, return_tensors="pt", **_):
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        packed, plan, n = self.pack(images)
+        return {"pixel_values": self.run(packed, plan, n)}
+
+
+class RawImageCollate:
+    """collate_fn for datasets that yield decoded images (`image`: PIL / uint8 HWC) instead of `pixel_values`: stacks the
+    other fields and does the host half of the GPU processor (packing + plan) inside the DataLoader worker."""
+
+    def __init__(self, processor):
+        self.proc = processor
+
+    def __call__(self, items):
+        from torch.utils.data import default_collate
+        packed, plan, n = self.proc.pack([it["image"] for it in items])
+        batch = default_collate([{k: v for k, v in it.items() if k != "image"} for it in items])
+        batch["image_packed"], batch["image_plan"], batch["image_count"] = packed, plan, n
+        return batch
+
+
+class DevicePrefetcher:
+    """Keeps `depth` batches in flight to the GPU: pinned staging + non-blocking copies on a side stream, so the training
+    stream never waits on a pageable host-to-device copy (a 38 MB pixel batch otherwise serialises with the step).
+    Batches with `image_packed` / `image_plan` (RawImageCollate) are turned into `pixel_values` on the GPU here."""
+
+    def __init__(self, loader, device, processor=None, depth=2):
+        self.loader, self.device, self.proc, self.depth = loader, torch.device(device), processor, max(1, depth)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch):
+        out = {}
+        with torch.cuda.stream(self.stream):
+            if "image_packed" in batch:
+                if self.proc is None:
+                    raise ValueError("raw-image batches need a GpuImageProcessor")
+                out["pixel_values"] = self.proc.run(batch["image_packed"], batch["image_plan"], int(batch["image_count"]))
+            for k, v in batch.items():
+                if k in ("image_packed", "image_plan", "image_count"):
+                    continue
+                if torch.is_tensor(v) and k != "data_id":
+                    h = v if v.is_pinned() else v.pin_memory()
+                    out[k] = h.to(self.device, non_blocking=True)
+                    out[k]._mmhip_keep = h
+                else:
+                    out[k] = v
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return out, ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        queue = []
+        try:
+            while len(queue) < self.depth:
+                queue.append(self._stage(next(it)))
+        except StopIteration:
+            pass
+        while queue:
+            batch, ev = queue.pop(0)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for v in batch.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(torch.cuda.current_stream(self.device))
+            yield batch
+            try:
+                queue.append(self._stage(next(it)))
+            except StopIteration:
+                pass

@@ -382,6 +382,7 @@ class MMLate_Model(object):
         self.device = self.model.device_
         self._opt = None
         self.world = mmdist.world_size()
+        self.image_processor = None          # GpuImageProcessor when the loaders yield raw images (datasets.py)
 
     # ---- checkpoints (reference :343-345, :529-531): plain state_dict with the reference's keys
     def load_saved_model(self, model_path):
@@ -487,6 +488,13 @@ class MMLate_Model(object):
             px = px.squeeze(1)
         return ids, mask, px
 
+    def _device_batches(self, dataloader):
+        """batches staged to the GPU ahead of use (pinned, side stream); raw-image batches become pixel_values there"""
+        if self.device.type != "cuda":
+            return dataloader
+        from .image_processing import DevicePrefetcher
+        return DevicePrefetcher(dataloader, self.device, self.image_processor)
+
     def train(self, dataloader, val_dataloader, epochs, loss_fn=None, lr=1e-5, weight_decay=0.00025, tim_loss_fn=None,
               iadds_loss_fn=None, te_dataloader=None, model_path=None, val_filename=None, te_filename=None, class_weight=None,
               log_every=50):
@@ -499,7 +507,7 @@ class MMLate_Model(object):
         for epoch in range(epochs):
             if mmdist.rank() == 0:
                 print("Epoch:", epoch + 1)
-            for it, batch in enumerate(dataloader):
+            for it, batch in enumerate(self._device_batches(dataloader)):
                 ids, mask, px = self._unpack(batch)
                 step += 1
                 loss, ncorr = self.train_step(ids.to(self.device), mask.to(self.device), px, batch["labels"], class_weight, lr, weight_decay, step)
@@ -529,7 +537,7 @@ class MMLate_Model(object):
         w_cls, w_itc, w_itm = self.loss_weights()
         cw = None if class_weight is None else class_weight.to(self.device, torch.float32).contiguous()
         with torch.no_grad():
-            for batch in dataloader:
+            for batch in self._device_batches(dataloader):
                 ids, mask, px = self._unpack(batch)
                 ids, mask = ids.to(self.device), mask.to(self.device)
                 tim = self.prepare_itm_inputs(ids, mask) if self.use_tim_loss else None

@@ -1,6 +1,6 @@
 """Command line of the late-fusion runs -- same flags, defaults, file names and CSV layouts as the reference's
 models/run_mm_late.py:20-191.  Additive flags: --batch_size, --synthetic/--n_synthetic (no dataset on disk),
---dtype, --results_dir.  Data parallel: launch with `python -m torch.distributed.run --nproc-per-node N ...`.
+--dtype, --results_dir, --cpu_preprocess, --num_workers.  Data parallel: launch with `python -m torch.distributed.run --nproc-per-node N ...`.
 
     python -m smtc_amd.run_mm_late --txt_model_name bernice --img_model_name vit --fusion_name attention --task 2 --testing
 """
@@ -61,6 +61,8 @@ def build_parser():
     p.add_argument("--dtype", choices=["bf16", "f16"], default="bf16")
     p.add_argument("--results_dir", type=str, default=None, help="default ../results/mm_late/ as in the reference")
     p.add_argument("--arch_layers", type=int, default=None, help="(testing) override encoder depth")
+    p.add_argument("--cpu_preprocess", action="store_true", help="resize / normalize images on the host (PIL) instead of the GPU kernels")
+    p.add_argument("--num_workers", type=int, default=0, help="DataLoader workers (reference: 0)")
     return p
 
 

@@ -1,0 +1,104 @@
+"""GPU image processor (csrc/image.hip through the C ABI) against Pillow / the oracle / the HF golden vectors: bit-exact."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "image_golden.npz")
+
+
+def _proc(size=224):
+    from smtc_amd.image_processing import GpuImageProcessor
+    return GpuImageProcessor(size=size, device="cuda:0")
+
+
+def test_batch_of_ragged_images_equals_pillow():
+    from PIL import Image
+    from oracle import image_oracle as IO
+    rng = np.random.default_rng(3)
+    sizes = [(224, 224), (37, 53), (500, 375), (375, 500), (1, 1), (2, 900), (900, 2), (224, 500), (500, 224), (225, 223), (300, 3), (301, 3),
+             (1500, 11), (448, 448), (1, 224), (224, 1), (768, 1024), (1080, 1920)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    p = _proc()
+    packed, plan, n = p.pack(imgs)
+    out, u8 = p.run(packed, plan, n, return_u8=True)
+    torch.cuda.synchronize()
+    lut = IO.normalize_lut()
+    for i, img in enumerate(imgs):
+        ref = np.asarray(Image.fromarray(img).resize((224, 224), Image.BILINEAR))
+        assert np.array_equal(u8[i].cpu().numpy(), ref), sizes[i]
+        pv = np.stack([lut[c][ref[:, :, c]] for c in range(3)])
+        assert np.array_equal(out[i].cpu().numpy(), pv), sizes[i]
+
+
+def test_hf_processor_golden():
+    z = np.load(GOLD)
+    n = int(z["n"])
+    imgs = [z[f"img{i}"] for i in range(n)]
+    pv = _proc()(imgs)["pixel_values"].cpu().numpy()
+    for i in range(n):
+        assert hashlib.sha256(np.ascontiguousarray(pv[i]).tobytes()).digest() == z[f"sha224_{i}"].tobytes(), i
+    pv32 = _proc(32)(imgs)["pixel_values"].cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(pv32[i], z[f"pv32_{i}"]), i
+
+
+def test_pil_inputs_modes_and_errors():
+    from PIL import Image
+    from smtc_amd import _lib
+    rng = np.random.default_rng(5)
+    g = Image.fromarray(rng.integers(0, 256, (50, 70), dtype=np.uint8), mode="L")           # grey -> RGB like .convert("RGB")
+    rgba = Image.fromarray(rng.integers(0, 256, (40, 30, 4), dtype=np.uint8), mode="RGBA")
+    p = _proc()
+    pv = p([g, rgba])["pixel_values"]
+    from oracle import image_oracle as IO
+    for i, im in enumerate((g, rgba)):
+        assert np.array_equal(pv[i].cpu().numpy(), IO.preprocess(np.asarray(im.convert("RGB"))))
+    with pytest.raises(ValueError):
+        p([np.zeros((4, 4), dtype=np.uint8)])
+    with pytest.raises(ValueError):
+        p([np.zeros((4, 4, 3), dtype=np.float32)])
+    assert p([])["pixel_values"].shape == (0, 3, 224, 224)
+    # a plan that was never built is rejected before any launch
+    bogus = torch.zeros(64, dtype=torch.int32)
+    with pytest.raises(_lib.MMHipError):
+        p.run(torch.zeros(16, dtype=torch.uint8), bogus, 1)
+
+
+def test_full_batch_properties_and_prefetcher():
+    """B = 64 photo-sized images: (a) equals Pillow per image, (b) order of the batch does not matter, (c) the prefetcher +
+    raw-image collate deliver the same tensors as the host form of the pipeline"""
+    from PIL import Image
+    from smtc_amd.image_processing import DevicePrefetcher, RawImageCollate
+    rng = np.random.default_rng(11)
+    sizes = [(int(rng.integers(200, 1100)), int(rng.integers(200, 1400))) for _ in range(64)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    p = _proc()
+    pv = p(imgs)["pixel_values"]
+    perm = rng.permutation(64)
+    pv2 = p([imgs[j] for j in perm])["pixel_values"]
+    assert torch.equal(pv[perm], pv2)
+    x = (np.arange(256).astype(np.float64) * (1 / 255)).astype(np.float32)
+    lut = (x - np.float32(0.5)) / np.float32(0.5)
+    for i in (0, 17, 63):
+        ref = np.asarray(Image.fromarray(imgs[i]).resize((224, 224), Image.BILINEAR))
+        assert np.array_equal(pv[i].cpu().numpy(), lut[ref].transpose(2, 0, 1))
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 64
+
+        def __getitem__(self, i):
+            return {"image": imgs[i], "input_ids": torch.full((1, 8), i), "labels": torch.tensor([1, 0]), "data_id": torch.tensor(i)}
+    loader = torch.utils.data.DataLoader(DS(), batch_size=16, shuffle=False, collate_fn=RawImageCollate(p))
+    got = []
+    for b in DevicePrefetcher(loader, "cuda:0", p, depth=2):
+        assert b["pixel_values"].is_cuda and b["input_ids"].is_cuda and not b["data_id"].is_cuda
+        assert int(b["input_ids"][0, 0, 0]) == int(b["data_id"][0])
+        got.append(b["pixel_values"].clone())
+    assert torch.equal(torch.cat(got), pv)
