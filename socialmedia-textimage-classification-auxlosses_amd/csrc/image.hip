@@ -10,7 +10,7 @@
 //   * rescale + normalize are a 256-entry float table per channel that the caller builds with the reference's float64 /
 //     float32 arithmetic (smtc_amd/image_processing.py), so no floating-point operation happens on the device at all.
 // Pass order: horizontal then vertical; images with height > 100 * width take the vertical pass first -- the behaviour of
-// the installed Pillow (12.2.0), observed and pinned by tests/test_image_cpu.py.
+// the installed Pillow (12.2.0), observed and pinned by tests/test_pipeline_cpu.py.
 //
 // HBM-bound byte work: one thread per output pixel (3 channels), taps read as bytes through L1/L2 (neighbouring threads
 // share their windows); algorithmic bytes per image = h*w*3 read + 3*S*S*4 written (+ the 8-bit intermediate).

@@ -2,7 +2,6 @@
 models/utils.py:133-200 (prepare_data): tweet normalisation, tokenisation to max_length=128 with padding='max_length',
 image -> 224x224, rescale 1/255, mean = std = 0.5 (the ViT image processor's defaults), one-hot int64 labels."""
 import os
-import re
 
 import numpy as np
 import torch
@@ -10,15 +9,54 @@ import torch
 from .config import MODEL_DIR_DICT
 from .utils import balanced_class_weights
 
-_URL = re.compile(r"(https?://\S+|www\.\S+)")
-_USER = re.compile(r"@\w+")
+_SPECIAL_PUNCTS = {"\u2019": "'", "\u2026": "..."}
+_CONTRACTIONS = (("cannot ", "can not "), ("n't ", " n't "), ("n 't ", " n't "), ("ca n't", "can't"), ("ai n't", "ain't"))
+_CLITICS = (("'m ", " 'm "), ("'re ", " 're "), ("'s ", " 's "), ("'ll ", " 'll "), ("'d ", " 'd "), ("'ve ", " 've "))
+_CLOCK = ((" p . m .", "  p.m."), (" p . m ", " p.m "), (" a . m .", " a.m."), (" a . m ", " a.m "))
+_tokenizer = None
+_demojize = False
+
+
+def _tweet_tokenizer():
+    """the NLTK-derived tweet tokenizer the reference vendors (text_processing.py:250-): transformers ships the same class
+    with BERTweet (tokenization_bertweet.TweetTokenizer); equality of the two is part of tests/golden/text_golden.json"""
+    global _tokenizer, _demojize
+    if _tokenizer is None:
+        from transformers.models.bertweet.tokenization_bertweet import TweetTokenizer
+        _tokenizer = TweetTokenizer()
+        try:
+            from emoji import demojize                      # optional in the reference too (text_processing.py:186-196)
+            _demojize = demojize
+        except ImportError:
+            _demojize = None
+    return _tokenizer
+
+
+def _normalize_token(token):
+    """reference text_processing.py:231-248"""
+    low = token.lower()
+    if token.startswith("@"):
+        return "@USER"
+    if low.startswith("http") or low.startswith("www"):
+        return "HTTPURL"
+    if len(token) == 1:
+        if token in _SPECIAL_PUNCTS:
+            return _SPECIAL_PUNCTS[token]
+        return _demojize(token) if _demojize else token
+    return token
 
 
 def normalize_tweet(text):
-    """reference preprocessing/text_processing.py:180-248 (core rules): @user -> @USER, URLs -> HTTPURL"""
-    text = _URL.sub("HTTPURL", str(text))
-    text = _USER.sub("@USER", text)
-    return " ".join(text.split())
+    """reference preprocessing/text_processing.py:198-228 (`Tweet_Preprocessing.normalizeTweet`): typographic quote /
+    ellipsis folding, tweet tokenisation, @USER / HTTPURL, contraction and clock-time re-spacing, whitespace squeeze"""
+    text = str(text)
+    for k, v in _SPECIAL_PUNCTS.items():
+        text = text.replace(k, v)
+    out = " ".join(_normalize_token(t) for t in _tweet_tokenizer().tokenize(text))
+    for table in (_CONTRACTIONS, _CLITICS, _CLOCK):
+        for a, b in table:
+            out = out.replace(a, b)
+    return " ".join(out.split())
 
 
 def prepare_data(data, num_labels, testing=False, nsamples=-1, seed=30):
