@@ -128,8 +128,7 @@ def main(argv=None):
             stem = names["preds"][: -len("preds.csv")]
             pd.DataFrame({"data_id": pred["data_id"].tolist(), "label": pred["labels"].tolist(),
                           "prediction": pred["predictions"].tolist()}).to_csv(stem + "preds_lm.csv", index=False)
-            m = compute_metrics(pred, cfg.num_labels)
-            pd.DataFrame({"metric": list(m), "value": list(m.values())}).to_csv(stem + "metrics_lm.csv", index=False)
+            pd.DataFrame(compute_metrics(pred, cfg.num_labels)).to_csv(stem + "metrics_lm.csv", index=False)      # columns metric, result
     if mmdist.world_size() > 1:
         torch.distributed.destroy_process_group()
 

@@ -23,36 +23,50 @@ def get_optimizer_params(named_parameters, weight_decay, lr, verbose=False):
     return [params]
 
 
-def _prf(pred, target, num_classes):
-    """per-class precision / recall / f1 and supports (torchmetrics Multiclass* semantics, zero_division -> 0)"""
-    p, r, f, sup = (np.zeros(num_classes) for _ in range(4))
+def _stats(pred, target, num_classes):
+    tp, fp, fn = (np.zeros(num_classes) for _ in range(3))
     for c in range(num_classes):
-        tp = float(np.sum((pred == c) & (target == c)))
-        fp = float(np.sum((pred == c) & (target != c)))
-        fn = float(np.sum((pred != c) & (target == c)))
-        p[c] = tp / (tp + fp) if tp + fp > 0 else 0.0
-        r[c] = tp / (tp + fn) if tp + fn > 0 else 0.0
-        f[c] = 2 * p[c] * r[c] / (p[c] + r[c]) if p[c] + r[c] > 0 else 0.0
-        sup[c] = tp + fn
-    return p, r, f, sup
+        tp[c] = np.sum((pred == c) & (target == c))
+        fp[c] = np.sum((pred == c) & (target != c))
+        fn[c] = np.sum((pred != c) & (target == c))
+    return tp, fp, fn
 
 
-def compute_metrics(res, num_classes, multi_label=False):
-    """reference models/utils.py:294-325: weighted / macro F1, precision, recall + loss, in metric_names order."""
-    pred, target = np.asarray(res["predictions"]), np.asarray(res["labels"])
-    p, r, f, sup = _prf(pred, target, num_classes)
-    w = sup / max(sup.sum(), 1.0)
-    return {"f1_weighted": float((f * w).sum()), "f1_macro": float(f.mean()), "precision_weighted": float((p * w).sum()),
-            "precision_macro": float(p.mean()), "recall_weighted": float((r * w).sum()), "recall_macro": float(r.mean()),
-            "loss": float(res["loss"])}
+def _safe_div(a, b):
+    return np.divide(a, b, out=np.zeros_like(a, dtype=np.float64), where=b != 0)
 
 
-def agg_metrics_val(res_list, metric_names, num_classes):
-    """reference models/utils.py:327-335: column `metric` + one column `epoch-N` per evaluated epoch."""
-    out = {"metric": list(metric_names)}
-    for res in res_list:
-        m = compute_metrics(res, num_classes)
-        out["epoch-{}".format(res["epoch"])] = [m[k] for k in metric_names]
+def _reduce(score, average, tp, fp, fn):
+    """torchmetrics 0.11 (`timrel-env.yml:120`) `_adjust_weights_safe_divide`, multiclass: 'weighted' weighs by support
+    tp + fn; 'macro' averages over the classes that occur in predictions or labels (a class absent from both is left out)"""
+    w = tp + fn if average == "weighted" else ((tp + fp + fn) != 0).astype(np.float64)
+    return float(np.sum(_safe_div(w * score, np.full_like(score, w.sum()))))
+
+
+def compute_metrics(res, num_classes, multi_label=False, multilabel=None):
+    """reference models/utils.py:294-325 without torchmetrics: {"metric": [...], "result": [...]} with weighted / macro F1,
+    precision, recall (torchmetrics 0.11 multiclass definitions, zero division -> 0) and the loss, in that order.
+    (`multilabel=` is what the reference's load branch passes, run_mm_late.py:177 -- a TypeError there; both are taken.)"""
+    if multi_label or multilabel:
+        raise NotImplementedError("no task of the reference enables the multilabel branch (config.py:10)")
+    pred, target = np.asarray(res["predictions"]).reshape(-1), np.asarray(res["labels"]).reshape(-1)
+    tp, fp, fn = _stats(pred, target, num_classes)
+    prec, rec, f1 = _safe_div(tp, tp + fp), _safe_div(tp, tp + fn), _safe_div(2 * tp, 2 * tp + fp + fn)
+    results = {}
+    for name, score in (("f1", f1), ("precision", prec), ("recall", rec)):
+        for avg in ("weighted", "macro"):
+            results[f"{name}_{avg}"] = _reduce(score, avg, tp, fp, fn)
+    results["loss"] = res["loss"]
+    return {"metric": list(results), "result": list(results.values())}
+
+
+def agg_metrics_val(res_val, metric_names, num_labels):
+    """reference models/utils.py:327-335: column `metric` + one column `epoch-N` (1-based) per evaluated epoch"""
+    out = {"metric": metric_names}
+    for predictions in res_val:
+        m = compute_metrics(predictions, num_labels)
+        d = dict(zip(m["metric"], m["result"]))
+        out["epoch-" + str(predictions["epoch"] + 1)] = [d[k] for k in metric_names]
     return out
 
 

@@ -31,9 +31,9 @@ def test_cli_train_save_load(tmp_path):
     for suffix in ("net.pth", "metrics_val.csv", "metrics_test.csv", "preds.csv"):
         assert os.path.exists(stem + suffix), suffix
     mv = pd.read_csv(stem + "metrics_val.csv")
-    assert list(mv.columns) == ["metric", "epoch-0"]
+    assert list(mv.columns) == ["metric", "epoch-1"]
     assert list(mv.metric) == ["f1_weighted", "f1_macro", "precision_weighted", "precision_macro", "recall_weighted", "recall_macro", "loss"]
-    assert np.isfinite(mv["epoch-0"]).all()
+    assert np.isfinite(mv["epoch-1"]).all()
     assert list(pd.read_csv(stem + "preds.csv").columns) == ["data_id", "label", "prediction"]
     sd = torch.load(stem + "net.pth", map_location="cpu")
     assert "dual_encoder.text_model.encoder.layer.0.attention.self.query.weight" in sd and "linear_fusion.weight" in sd
@@ -119,6 +119,6 @@ def test_cli_config0_real_pipeline(tmp_path):
     out = os.path.join(os.path.dirname(run_dir), "results", "mm_late", "testing")
     stem = os.path.join(out, "bernice-vit-attention_task2_seed30_itc0.1_")
     mv = pd.read_csv(stem + "metrics_val.csv")
-    assert list(mv.columns) == ["metric", "epoch-0"] and np.isfinite(mv["epoch-0"]).all()
+    assert list(mv.columns) == ["metric", "epoch-1"] and np.isfinite(mv["epoch-1"]).all()
     preds = pd.read_csv(stem + "preds.csv")
     assert set(preds.prediction.unique()) <= {0, 1, 2, 3} and preds.data_id.between(1000, 1063).all()
