@@ -85,29 +85,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
         if (lane + 64 * t < nch) load4<float>(a.gamma + (lane + 64 * t) * 4, gam[t]);
     }
     const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK;
-    for (int rr = w; rr < LN_ROWS_PER_BLOCK; rr += 4) {
-        const int row = r0 + rr;
+    // all of this wave's rows are requested before the first one is used: 2 blocks per CU hold only 8 waves, so the
+    // bytes in flight per wave, not the wave count, must cover the HBM latency (24 -> 96 KB in flight per CU)
+    constexpr int RPW = LN_ROWS_PER_BLOCK / 4;
+    typedef typename Vec<T>::v4 v4;
+    v4 xraw[RPW][MAXC], dyraw[RPW][MAXC], rraw[RPW][MAXC];
+    float mean_r[RPW], rstd_r[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int row = r0 + w + 4 * i;
+        const bool live = row < a.rows;
+        mean_r[i] = live ? a.mean[row] : 0.f;
+        rstd_r[i] = live ? a.rstd[row] : 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            if (live && c < nch) {
+                xraw[i][t] = *reinterpret_cast<const v4*>((const T*)a.x + (size_t)row * a.width + c * 4);
+                dyraw[i][t] = *reinterpret_cast<const v4*>((const T*)a.dy + (size_t)row * a.width + c * 4);
+                if (a.dres) rraw[i][t] = *reinterpret_cast<const v4*>((const T*)a.dres + (size_t)row * a.width + c * 4);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int row = r0 + w + 4 * i;
         if (row >= a.rows) break;
-        const T* x = (const T*)a.x + (size_t)row * a.width;
-        const T* dy = (const T*)a.dy + (size_t)row * a.width;
-        const float mean = a.mean[row], rstd = a.rstd[row];
+        const float mean = mean_r[i], rstd = rstd_r[i];
         float xh[MAXC][4], g[MAXC][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int t = 0; t < MAXC; ++t) {
             const int c = lane + 64 * t;
             if (c < nch) {
-                float xv[4], dv[4];
-                load4<T>(x + c * 4, xv);
-                load4<T>(dy + c * 4, dv);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    xh[t][e] = (xv[e] - mean) * rstd;
-                    g[t][e] = dv[e] * gam[t][e];
+                    const float xv = to_f<T>(xraw[i][t][e]), dv = to_f<T>(dyraw[i][t][e]);
+                    xh[t][e] = (xv - mean) * rstd;
+                    g[t][e] = dv * gam[t][e];
                     s1 += g[t][e];
                     s2 += g[t][e] * xh[t][e];
-                    dg[t][e] += dv[e] * xh[t][e];
-                    db[t][e] += dv[e];
+                    dg[t][e] += dv * xh[t][e];
+                    db[t][e] += dv;
                 }
             }
         }
@@ -121,10 +140,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rstd * (g[t][e] - c1 - xh[t][e] * c2);
                 if (a.dres) {
-                    float r[4];
-                    load4<T>((const T*)a.dres + (size_t)row * a.width + c * 4, r);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += r[e];
+                    for (int e = 0; e < 4; ++e) o[e] += to_f<T>(rraw[i][t][e]);
                 }
                 store4<T>(dx + c * 4, o);
                 if (dropping) {

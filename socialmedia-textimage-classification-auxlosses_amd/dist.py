@@ -36,6 +36,11 @@ def init_from_env(backend=None):
     td.init_process_group(backend=backend)
 
 
+def force_exchange():
+    """MMHIP_FORCE_EXCHANGE=1: run the collectives even at world size 1 (exercises the RCCL call pattern on a one-GPU box)"""
+    return os.environ.get("MMHIP_FORCE_EXCHANGE", "0") == "1" and td.is_available() and td.is_initialized()
+
+
 def allreduce_range(flat_grad, begin, end, async_op=True):
     """sum-all-reduce flat_grad[begin:end] in place; returns the Work handle (or None)"""
     if end <= begin:
@@ -49,7 +54,7 @@ def sparse_rows_exchange(table_grad, ids, row_state=None):
     the other slots carry zeros.  `row_state` (uint8 per row, include/mmhip.h: mmhip_adamw_rows) gets bit0 set on the
     rows received from the other ranks."""
     W = world_size()
-    if W == 1:
+    if W == 1 and not force_exchange():
         return
     ids = ids.reshape(-1).to(table_grad.device)
     sorted_ids, _ = torch.sort(ids)

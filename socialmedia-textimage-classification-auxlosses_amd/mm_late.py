@@ -441,16 +441,17 @@ class MMLate_Model(object):
                                   _lib.ptr(ncorr), s), "loss")
         _lib.check(lib.mmhip_backward_begin(m._handle, None, None, None, None, s), "backward_begin")
         works = []
+        exchange = self.world > 1 or mmdist.force_exchange()
         n_stage = len(m._stage_ranges)
         for st in range(n_stage):
             _lib.check(lib.mmhip_backward_stage(m._handle, st, s), "backward_stage")
-            if self.world > 1 and st >= 1:
+            if exchange and st >= 1:
                 # stage st-1's parameter gradients may still be running on the engine's side stream: join them into this
                 # stream, then hand the range to RCCL (which orders itself after this stream) while stage st+1 computes
                 _lib.check(lib.mmhip_backward_join_stage(m._handle, st - 1, s), "backward_join_stage")
                 works += mmdist.exchange_stage(m, st - 1, n_stage, self.use_clip_loss, self.use_tim_loss)
         _lib.check(lib.mmhip_backward_finish(m._handle, s), "backward_finish")
-        if self.world > 1:
+        if exchange:
             works += mmdist.exchange_stage(m, n_stage - 1, n_stage, self.use_clip_loss, self.use_tim_loss)
         for w in works:
             w.wait()

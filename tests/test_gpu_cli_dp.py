@@ -122,3 +122,42 @@ def test_cli_config0_real_pipeline(tmp_path):
     assert list(mv.columns) == ["metric", "epoch-1"] and np.isfinite(mv["epoch-1"]).all()
     preds = pd.read_csv(stem + "preds.csv")
     assert set(preds.prediction.unique()) <= {0, 1, 2, 3} and preds.data_id.between(1000, 1063).all()
+
+
+RCCL_SCRIPT = r'''
+import os, sys, types, numpy as np, torch
+sys.path.insert(0, os.environ["ROOT"])
+import smtc_amd
+from smtc_amd import dist as mmdist
+from smtc_amd.mm_late import MMLate_Model
+from smtc_amd.synthetic import synthetic_batch
+torch.cuda.set_device(0)
+torch.distributed.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:" + os.environ["PORT"], rank=0, world_size=1)
+cfg = types.SimpleNamespace(batch_size=4, num_labels=3, use_clip_loss=True, beta_itc=0.1, use_tim_loss=True, beta_itm=0.1, max_length=64, dropout=0.05)
+arch = dict(layers_txt=2, layers_img=1, vocab=300, max_pos=130)
+ids, mask, px, oh = synthetic_batch(300, 3, 4, 64, 77, pad=True)
+out = []
+for force in ("1", "0"):
+    os.environ["MMHIP_FORCE_EXCHANGE"] = force
+    tr = MMLate_Model(cfg, "bernice", "vit", "attention", arch=arch, seed=5)
+    np.random.seed(30)
+    for step in (1, 2, 3):
+        loss, _ = tr.train_step(ids.cuda(), mask.cuda(), px, oh, None, 1e-3, 0.00025, step)
+    torch.cuda.synchronize()
+    out.append((tr.model._flat_train.clone(), loss.clone(), tr.model._word_row_state.clone()))
+err = (out[0][0] - out[1][0]).abs().max().item()
+print("RCCL_ERR", err, float(out[0][1][0]), float(out[1][1][0]), bool(torch.equal(out[0][2], out[1][2])), torch.distributed.get_backend())
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_rccl_call_pattern_at_world_size_one(tmp_path):
+    """the staged all-reduce / row-sparse all_gather exchange issued through RCCL itself (backend "nccl", one rank, exchange
+    forced): same parameters as the run without any collective -- the one-GPU box cannot host two RCCL ranks, so this pins
+    the backend's call pattern (slices of the flat gradient, async work handles, int64 / fp32 all_gather) and
+    tests/test_dist_cpu.py + the gloo test above pin the arithmetic across ranks"""
+    script = tmp_path / "rccl.py"
+    script.write_text(RCCL_SCRIPT)
+    r = run([sys.executable, str(script)], env={"ROOT": ROOT, "PORT": str(29900 + os.getpid() % 90), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_ERR")][0].split()
+    assert float(line[1]) < 2e-5 and line[4] == "True" and line[5] == "nccl", line
