@@ -48,14 +48,13 @@ def allreduce_range(flat_grad, begin, end, async_op=True):
     return td.all_reduce(flat_grad[begin:end], op=td.ReduceOp.SUM, async_op=async_op)
 
 
-def sparse_rows_exchange(table_grad, ids, row_state=None):
-    """table_grad [V, H] holds this rank's gradient rows (non-zero only for rows in `ids`); afterwards it holds the sum
-    over ranks.  Fixed-size payload (no host sync): rows are sent once per distinct id (first occurrence in sorted order),
-    the other slots carry zeros.  `row_state` (uint8 per row, include/mmhip.h: mmhip_adamw_rows) gets bit0 set on the
-    rows received from the other ranks."""
+def sparse_rows_exchange_begin(table_grad, ids):
+    """table_grad [V, H] holds this rank's gradient rows (non-zero only for rows in `ids`).  Starts the exchange (two
+    asynchronous all_gathers of a fixed-size payload -- no host sync: rows are sent once per distinct id, first occurrence
+    in sorted order, the other slots carry zeros) and returns the state `sparse_rows_exchange_finish` needs, or None."""
     W = world_size()
     if W == 1 and not force_exchange():
-        return
+        return None
     ids = ids.reshape(-1).to(table_grad.device)
     sorted_ids, _ = torch.sort(ids)
     first = torch.ones_like(sorted_ids, dtype=torch.bool)
@@ -63,18 +62,35 @@ def sparse_rows_exchange(table_grad, ids, row_state=None):
     payload = table_grad.index_select(0, sorted_ids) * first.unsqueeze(1).to(table_grad.dtype)
     ids_all = [torch.empty_like(sorted_ids) for _ in range(W)]
     pay_all = [torch.empty_like(payload) for _ in range(W)]
-    td.all_gather(ids_all, sorted_ids)
-    td.all_gather(pay_all, payload)
+    works = [td.all_gather(ids_all, sorted_ids, async_op=True), td.all_gather(pay_all, payload, async_op=True)]
+    return ids_all, pay_all, works, (sorted_ids, payload)
+
+
+def sparse_rows_exchange_finish(state, table_grad, row_state=None):
+    """adds the other ranks' rows: afterwards table_grad holds the sum over ranks.  `row_state` (uint8 per row,
+    include/mmhip.h: mmhip_adamw_rows) gets bit0 set on the rows received."""
+    if state is None:
+        return
+    ids_all, pay_all, works, _keep = state
+    for w in works:
+        w.wait()
     me = rank()
-    for r in range(W):
+    for r in range(len(ids_all)):
         if r != me:
             table_grad.index_add_(0, ids_all[r], pay_all[r])
             if row_state is not None:
                 row_state[ids_all[r]] = row_state[ids_all[r]] | 1
 
 
-def exchange_stage(model, stage, n_stage, use_itc, use_itm):
-    """called right after backward stage `stage` was enqueued; returns async Work handles to wait on before AdamW"""
+def sparse_rows_exchange(table_grad, ids, row_state=None):
+    """begin + finish in one call"""
+    sparse_rows_exchange_finish(sparse_rows_exchange_begin(table_grad, ids), table_grad, row_state)
+
+
+def exchange_stage(model, stage, n_stage, use_itc, use_itm, finishers=None):
+    """called right after backward stage `stage` was enqueued; returns async Work handles to wait on before AdamW.  With a
+    `finishers` list the word-table exchange of the last stage is only started here: the caller runs the appended callable
+    after the dense AdamW, so the all_gather travels while the dense parameters are being updated."""
     works = []
     b, e = model._stage_ranges[stage]
     if stage < n_stage - 1:
@@ -89,5 +105,10 @@ def exchange_stage(model, stage, n_stage, use_itc, use_itm):
         works.append(w)
     V, H = word["shape"]
     table = model._flat_grad[word["offset"]: word["offset"] + V * H].view(V, H)
-    sparse_rows_exchange(table, model._last["ids_all"], getattr(model, "_word_row_state", None))
+    state = sparse_rows_exchange_begin(table, model._last["ids_all"])
+    finish = lambda: sparse_rows_exchange_finish(state, table, getattr(model, "_word_row_state", None))
+    if finishers is None:
+        finish()
+    else:
+        finishers.append(finish)
     return works

@@ -451,15 +451,19 @@ class MMLate_Model(object):
                 _lib.check(lib.mmhip_backward_join_stage(m._handle, st - 1, s), "backward_join_stage")
                 works += mmdist.exchange_stage(m, st - 1, n_stage, self.use_clip_loss, self.use_tim_loss)
         _lib.check(lib.mmhip_backward_finish(m._handle, s), "backward_finish")
+        finishers = []
         if exchange:
-            works += mmdist.exchange_stage(m, n_stage - 1, n_stage, self.use_clip_loss, self.use_tim_loss)
+            works += mmdist.exchange_stage(m, n_stage - 1, n_stage, self.use_clip_loss, self.use_tim_loss, finishers)
         for w in works:
             w.wait()
-        self._adamw(lr, weight_decay, step)
-        m._refresh_weights(2)
+        self._adamw(lr, weight_decay, step, rows=False)        # dense ranges first: the word-table rows are still travelling
+        m._refresh_weights(2)                                  # 16-bit GEMM operand copies (no word-table dependence)
+        for f in finishers:
+            f()
+        self._adamw(lr, weight_decay, step, dense=False)
         return loss, ncorr
 
-    def _adamw(self, lr, weight_decay, step):
+    def _adamw(self, lr, weight_decay, step, dense=True, rows=True):
         m, lib = self.model, _lib.lib()
         if self._opt is None:
             self._opt = (torch.zeros_like(m._flat_train), torch.zeros_like(m._flat_train))
@@ -470,10 +474,10 @@ class MMLate_Model(object):
         w0 = m._word_info["offset"]                                 # the word table closes the trainable buffer
         for b, e in m.active_ranges(self.use_clip_loss, self.use_tim_loss):
             dense_end = min(e, w0)
-            if dense_end > b:
+            if dense and dense_end > b:
                 _lib.check(lib.mmhip_adamw(at(m._flat_train, b), at(m._flat_grad, b), at(em, b), at(ev, b), dense_end - b, lr, 0.9, 0.999,
                                            1e-8, weight_decay, step, 1.0 / self.world, 1, _lib.stream_ptr()), "adamw")
-            if e > w0:
+            if rows and e > w0:
                 # rows without gradient and without moments only decay: same values as the dense update, 1/4 of its traffic
                 _lib.check(lib.mmhip_adamw_rows(at(m._flat_train, w0), at(m._flat_grad, w0), at(em, w0), at(ev, w0), V, H,
                                                 _lib.ptr(m._word_row_state), lr, 0.9, 0.999, 1e-8, weight_decay, step,
