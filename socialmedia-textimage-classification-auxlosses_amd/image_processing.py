@@ -119,15 +119,36 @@ class DevicePrefetcher:
     stream never waits on a pageable host-to-device copy (a 38 MB pixel batch otherwise serialises with the step).
     Batches with `image_packed` / `image_plan` (RawImageCollate) are turned into `pixel_values` on the GPU here."""
 
-    def __init__(self, loader, device, processor=None, depth=2):
+    def __init__(self, loader, device, processor=None, depth=2, trim_padding=True):
         self.loader, self.device, self.proc, self.depth = loader, torch.device(device), processor, max(1, depth)
         self.stream = torch.cuda.Stream(device=self.device)
+        self.trim_padding = trim_padding
+
+    @staticmethod
+    def trim(batch):
+        """drop the token columns no post of the batch uses (right padding beyond the longest post, kept to a multiple of
+        32): masked keys weigh exp(-inf) = 0 and rows past a post's end are never read by the heads, so
+        outputs and gradients are unchanged while the text tower shrinks with the batch's longest post"""
+        m = batch.get("attention_mask")
+        if m is None or m.is_cuda:
+            return batch
+        T = m.shape[-1]
+        used = m.reshape(-1, T).ne(0).any(dim=0).nonzero()
+        t_eff = min(T, max(32, (int(used.max()) + 1 + 31) // 32 * 32)) if used.numel() else min(T, 32)
+        if t_eff < T:
+            batch = dict(batch)
+            for k in ("input_ids", "attention_mask", "token_type_ids"):
+                if k in batch and torch.is_tensor(batch[k]) and batch[k].shape[-1] == T:
+                    batch[k] = batch[k][..., :t_eff].contiguous()
+        return batch
 
     def __len__(self):
         return len(self.loader)
 
     def _stage(self, batch):
         out = {}
+        if self.trim_padding:
+            batch = self.trim(batch)
         with torch.cuda.stream(self.stream):
             if "image_packed" in batch:
                 if self.proc is None:

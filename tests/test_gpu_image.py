@@ -102,3 +102,33 @@ def test_full_batch_properties_and_prefetcher():
         assert int(b["input_ids"][0, 0, 0]) == int(b["data_id"][0])
         got.append(b["pixel_values"].clone())
     assert torch.equal(torch.cat(got), pv)
+
+
+def test_trimmed_padding_gives_the_same_outputs_and_gradients():
+    """DevicePrefetcher.trim: a batch whose longest post has 41 tokens runs with T = 64 instead of 128 -- same logits,
+    features, loss and (dropout off) the same gradients"""
+    from smtc_amd.image_processing import DevicePrefetcher
+    from smtc_amd.mm_late import MM_Model
+    from oracle import mm_oracle as O
+    arch = dict(layers_txt=2, layers_img=1, vocab=500, max_pos=130, p_hidden=0.0, p_attn=0.0)
+    cfg = O.OracleConfig(layers_txt=2, layers_img=1, vocab=500, max_pos=130, num_labels=3)
+    model = MM_Model(3, "bernice", "vit", 0.0, "attention", arch=arch, max_posts=8, max_text_len=128, seed=2)
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, 8, 128, 9, True)
+    lens = [41, 7, 33, 12, 40, 3, 25, 18]
+    for b, n in enumerate(lens):
+        mask[b, n:] = 0
+        ids[b, n:] = 1                                     # XLM-R pad id
+    full = {"input_ids": ids.unsqueeze(1), "attention_mask": mask.unsqueeze(1), "labels": onehot}
+    trimmed = DevicePrefetcher.trim(full)
+    assert trimmed["input_ids"].shape[-1] == 64 and trimmed["attention_mask"].shape[-1] == 64 and full["input_ids"].shape[-1] == 128
+    res = []
+    for bt in (full, trimmed):
+        model.train()
+        model._flat_grad.zero_()
+        out = model(bt["input_ids"].squeeze(1), bt["attention_mask"].squeeze(1), pixels)
+        loss = O.cls_loss(out[0], onehot.to(out[0].device).float(), None) + 0.1 * out[1].float().pow(2).mean()
+        loss.backward()
+        res.append((out[0].detach().clone(), out[4].detach().clone(), model._flat_grad.clone()))
+    assert torch.allclose(res[0][0], res[1][0], atol=1e-6) and torch.allclose(res[0][1], res[1][1], atol=1e-6)
+    rel = (res[0][2] - res[1][2]).norm() / res[0][2].norm()
+    assert rel < 1e-5, rel
