@@ -92,6 +92,11 @@ def make_loaders(args, cfg, trainer):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    for flag in ("eval_txt_test", "use_saved_features"):
+        if getattr(args, flag):
+            # text-only test split (models/mm_late.py:372-376) and pre-extracted processor outputs (models/datasets.py:155-158):
+            # outside the hot path (DESIGN.md "Out of scope"); refused rather than silently ignored
+            raise NotImplementedError(f"--{flag} is not part of this build")
     torch.manual_seed(args.seed)                      # models/run_mm_late.py:48-49
     np.random.seed(args.seed)
     mmdist.init_from_env()
