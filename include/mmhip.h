@@ -157,9 +157,10 @@ int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, 
                      const float* bias, int act, void* aux_pre, int ldaux, const void* mul_gelu_grad_of, int ldmul,
                      float p_drop, uint64_t seed, uint32_t stream_id, const void* residual, int ldres, int out_f32,
                      int force_slow, void* stream);
-/* C[Nn,Nc] (fp32) (+)= A[M,Nn]^T . B[M,Nc] */
+/* C[Nn,Nc] (fp32) (+)= A[M,Nn]^T . B[M,Nc];  colsum (may be NULL): fp32 [Nn] (+)= sum_m A[m][n], the bias gradient that goes
+ * with a weight gradient, from the same operand tiles */
 int mmhip_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int Nn, int Nc,
-                     int accumulate, int force_slow, void* stream);
+                     int accumulate, int force_slow, float* colsum, void* stream);
 int mmhip_op_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                            int rows, int width, float eps, void* stream);
 int mmhip_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmmhip.so")
+LIB_PATH = os.environ.get("MMHIP_LIB_PATH") or os.path.join(HERE, "libmmhip.so")      # override: A/B of two builds on one box
 
 BF16, F16, F32 = 0, 1, 2
 TXT_BERT, TXT_XLMR = 0, 1
@@ -60,7 +60,7 @@ _SIGS = {
     "mmhip_image_preprocess": (I, [P, P, P, P, P, P, P, P]),
     "mmhip_gemm_timing": (I, [P, I, I, C.POINTER(C.c_double), C.POINTER(U64), C.POINTER(C.c_double)]),
     "mmhip_op_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, P, I, F, U64, U32, P, I, I, I, P]),
-    "mmhip_op_gemm_tn": (I, [I, P, I, P, I, P, I, I, I, I, I, I, P]),
+    "mmhip_op_gemm_tn": (I, [I, P, I, P, I, P, I, I, I, I, I, I, P, P]),
     "mmhip_op_layernorm_fwd": (I, [I, P, P, P, P, P, P, I, I, F, P]),
     "mmhip_op_layernorm_bwd": (I, [I, P, P, P, P, P, P, P, P, P, I, I, P]),
     "mmhip_op_attn_fwd": (I, [I, P, P, P, P, I, I, I, F, U64, U32, P]),

@@ -107,9 +107,9 @@ int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, 
 }
 
 int mmhip_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int Nn, int Nc,
-                     int accumulate, int force_slow, void* stream) {
+                     int accumulate, int force_slow, float* colsum, void* stream) {
     if (!A || !B || !C || M < 1 || Nn < 1 || Nc < 1 || (dtype != MMHIP_BF16 && dtype != MMHIP_F16)) return MMHIP_E_INVALID;
-    GemmTNProblem p{A, B, C, M, Nn, Nc, lda, ldb, ldc, 0};
+    GemmTNProblem p{A, B, C, M, Nn, Nc, lda, ldb, ldc, 0, colsum};
     CHECK_HIP(launch_gemm_tn(&p, 1, accumulate, dtype, force_slow, (hipStream_t)stream));
     return 0;
 }

@@ -584,7 +584,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     // gradient of the Linear that fed the LN
     const DropCfg d_ffn = make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr);
     LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mr, H,
-                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ffn.thresh16 ? ddrop2 : nullptr, Gd + o.fc2_b, d_ffn, rmul};
+                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ffn.thresh16 ? ddrop2 : nullptr, nullptr, d_ffn, rmul};
     CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
     const char* df = d_ffn.thresh16 ? ddrop2 : dpre2;
     // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
@@ -593,7 +593,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
     LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mr, H,
-                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ao.thresh16 ? ddrop1 : nullptr, Gd + o.ao_b, d_ao, rmul};
+                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ao.thresh16 ? ddrop1 : nullptr, nullptr, d_ao, rmul};
     CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
     const char* dout = d_ao.thresh16 ? ddrop1 : dpre1;
     if (compact) {
@@ -614,15 +614,13 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     ab.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
     ab.q_tiles = compact ? 1 : 0;
     CHECK_HIP(launch_attn_bwd(ab, dt, s));
-    // ---- parameter gradients of the layer: off the critical path -> side stream (bias column sums + all four weight
-    // gradients in one grouped launch, no split-K, plain stores)
+    // ---- parameter gradients of the layer: off the critical path -> side stream: all four weight gradients AND their bias
+    // gradients in one grouped launch, no split-K, plain stores
     hipStream_t ps = s;
-    float* partial = e.wsp<float>(e.g_partial);
     if (side) {
         CHECK_HIP(hipEventRecord(e.ev_ready[set], s));
         CHECK_HIP(hipStreamWaitEvent(e.side, e.ev_ready[set], 0));
         ps = e.side;
-        partial = e.wsp<float>(e.g_partial_side);
     }
     if (compact) {
         // dx_in = dqkv . Wqkv, plus d pre1 on the CLS rows (the residual branch of the CLS rows)
@@ -633,13 +631,12 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
         g.residual(dpre1, H);
         if (int r = run_gemm(e, g, s)) return r;
     }
-    CHECK_HIP(launch_colsum(du, Mr, I, I, Gd + o.fc1_b, dt, ps, partial, 1.0f / e.gscale()));
-    CHECK_HIP(launch_colsum(dqkv, Mt, 3 * H, 3 * H, Gd + o.qkv_b, dt, ps, partial, 1.0f / e.gscale()));
     GemmTNProblem pr[4];
-    pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mr, H, I, H, I, I, 0};           // dW2[H,I]   = df^T h
-    pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mr, I, H, I, H, H, 0};          // dW1[I,H]   = du^T a1
-    pr[2] = GemmTNProblem{dqkv, x_in, Gd + o.qkv_w, Mt, 3 * H, H, 3 * H, H, H, 0};       // dWqkv[3H,H] = dqkv^T x_in
-    pr[3] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mr, H, H, H, rs, H, 0};       // dWo[H,H]   = dout^T ctx (CLS rows: stride T*H)
+    // each problem also yields its Linear's bias gradient (column sums of the dY operand) from the same tiles
+    pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mr, H, I, H, I, I, 0, Gd + o.fc2_b};           // dW2[H,I]   = df^T h
+    pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mr, I, H, I, H, H, 0, Gd + o.fc1_b};          // dW1[I,H]   = du^T a1
+    pr[2] = GemmTNProblem{dqkv, x_in, Gd + o.qkv_w, Mt, 3 * H, H, 3 * H, H, H, 0, Gd + o.qkv_b};       // dWqkv[3H,H] = dqkv^T x_in
+    pr[3] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mr, H, H, H, rs, H, 0, Gd + o.ao_b};        // dWo[H,H]   = dout^T ctx (CLS rows: stride T*H)
     CHECK_HIP(launch_gemm_tn(pr, 4, 0, dt, 0, ps, 1.0f / e.gscale()));
     if (side) {
         CHECK_HIP(hipEventRecord(e.ev_tn[set], e.side));

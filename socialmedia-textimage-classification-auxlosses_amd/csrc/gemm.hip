@@ -337,6 +337,15 @@ void gemm_tn_kernel(GemmTNGroup g) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // column sums of A (bias gradient): the waves of the first column tile multiply their A fragments by a B fragment of
+    // ones as well -- every column of that product is sum_m A[m][n]
+    const bool with_colsum = P.colsum != nullptr && c0 == 0 && wc_ == 0;
+    f32x4 accb[4];
+    v8 ones;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = from_f<T>(1.0f);
 
     // transposed-read addressing: lane = 16 g + 4 q + p; rows 8g+q (and +4), columns col16 + 4p..4p+3
     const int gq = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
@@ -362,6 +371,10 @@ void gemm_tn_kernel(GemmTNGroup g) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+            if (with_colsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = mfma16(af[i], ones, accb[i]);
+            }
         }
     };
     const int nsteps = P.M / 64;
@@ -430,6 +443,16 @@ void gemm_tn_kernel(GemmTNGroup g) {
                 if (g.accumulate == 1) atomicAdd(dst, acc[i][j][r] * g.alpha);
                 else *dst = acc[i][j][r] * g.alpha;
             }
+    if (with_colsum && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* dst = P.colsum + n0 + wn_ * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (g.accumulate == 1) atomicAdd(dst, accb[i][r] * g.alpha);
+                else *dst = accb[i][r] * g.alpha;
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ small fp32 GEMM
@@ -679,6 +702,11 @@ hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate,
             dim3 grid((P.Nc + 255) / 256, P.Nn);
             if (dtype == DT_BF16) hipLaunchKernelGGL(slow_tn_kernel<bf16_t>, grid, dim3(256), 0, s, P, accumulate, alpha);
             else hipLaunchKernelGGL(slow_tn_kernel<f16_t>, grid, dim3(256), 0, s, P, accumulate, alpha);
+            if (P.colsum) {       // generic shapes: the column sums take their own pass
+                if (accumulate != 1) { hipError_t e = hipMemsetAsync(P.colsum, 0, (size_t)P.Nn * 4, s); if (e != hipSuccess) return e; }
+                hipError_t e = launch_colsum(P.A, P.M, P.Nn, P.lda, P.colsum, dtype, s, nullptr, alpha);
+                if (e != hipSuccess) return e;
+            }
         }
     }
     flush();

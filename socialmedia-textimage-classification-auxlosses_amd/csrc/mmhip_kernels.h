@@ -34,6 +34,8 @@ static constexpr int GEMM_TN_MAX_GROUP = 8;
 struct GemmTNProblem {
     const void* A; const void* B; float* C;
     int M, Nn, Nc, lda, ldb, ldc, tile_start;
+    float* colsum;            // optional [Nn]: (+)= alpha * sum_m A[m][n] -- the bias gradient that goes with dW = dY^T X, taken
+                              // from the same operand tiles by one extra MFMA column (B = ones), no extra pass, no atomics
 };
 struct GemmTNGroup {
     GemmTNProblem p[GEMM_TN_MAX_GROUP];

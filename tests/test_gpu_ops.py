@@ -119,11 +119,15 @@ def test_gemm_tn(dt, M, Nn, Nc, slow):
     A = (torch.randn(M, Nn, generator=g) * 0.1).to(tdt).to(dev())
     B = (torch.randn(M, Nc, generator=g) * 0.5).to(tdt).to(dev())
     C_ = torch.full((Nn, Nc), 3.0, device=dev())
-    call("mmhip_op_gemm_tn", code, ptr(A), Nn, ptr(B), Nc, ptr(C_), Nc, M, Nn, Nc, 0, slow, stream())
+    cs = torch.full((Nn,), 7.0, device=dev())
+    call("mmhip_op_gemm_tn", code, ptr(A), Nn, ptr(B), Nc, ptr(C_), Nc, M, Nn, Nc, 0, slow, ptr(cs), stream())
     ref = A.float().t() @ B.float()
-    assert rel_err(C_, ref) < 3e-5
-    call("mmhip_op_gemm_tn", code, ptr(A), Nn, ptr(B), Nc, ptr(C_), Nc, M, Nn, Nc, 1, slow, stream())
-    assert rel_err(C_, 2 * ref) < 3e-5
+    ref_cs = A.float().sum(0)                      # the bias gradient that goes with dW: column sums of the dY operand
+    assert rel_err(C_, ref) < 3e-5 and rel_err(cs, ref_cs) < 3e-5
+    call("mmhip_op_gemm_tn", code, ptr(A), Nn, ptr(B), Nc, ptr(C_), Nc, M, Nn, Nc, 1, slow, ptr(cs), stream())
+    assert rel_err(C_, 2 * ref) < 3e-5 and rel_err(cs, 2 * ref_cs) < 3e-5
+    call("mmhip_op_gemm_tn", code, ptr(A), Nn, ptr(B), Nc, ptr(C_), Nc, M, Nn, Nc, 0, slow, None, stream())
+    assert rel_err(C_, ref) < 3e-5 and rel_err(cs, 2 * ref_cs) < 3e-5         # NULL: column sums untouched
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])

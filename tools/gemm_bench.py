@@ -58,7 +58,7 @@ def main():
         Cm = torch.empty(Nn, Nc, device=dev)
         cells = []
         for var in (1, 2, 3):
-            fn = lambda: lib.mmhip_op_gemm_tn(0, p(A), Nn, p(B), Nc, p(Cm), Nc, M, Nn, Nc, 0, var << 4, st())
+            fn = lambda: lib.mmhip_op_gemm_tn(0, p(A), Nn, p(B), Nc, p(Cm), Nc, M, Nn, Nc, 0, var << 4, None, st())
             us = time_it(fn)
             cells.append(f"{us:7.1f}us {2.0 * M * Nn * Nc / us / 1e6:6.0f}TF")
         print(f"{name:14s} M={M} {Nn}x{Nc}: " + " | ".join(cells) + "   (128x128 2-stage | 128x128 ring4 | 256x128 ring3)", flush=True)

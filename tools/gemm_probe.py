@@ -35,5 +35,5 @@ for name, M, Nn, Nc in [("dW fc1", 8192, 3072, 768), ("dW ao", 8192, 768, 768)]:
     Cm = torch.empty(Nn, Nc, device=dev)
     for var in (1, 3):
         for acc in (0, 2):
-            fn = lambda: lib.mmhip_op_gemm_tn(0, p(A), Nn, p(B), Nc, p(Cm), Nc, M, Nn, Nc, acc, var << 4, st())
+            fn = lambda: lib.mmhip_op_gemm_tn(0, p(A), Nn, p(B), Nc, p(Cm), Nc, M, Nn, Nc, acc, var << 4, None, st())
             print(f"  {name} variant {var} acc {acc}: {time_it(fn):7.1f} us", flush=True)

@@ -26,7 +26,7 @@ for name, M, Nn, Nc in [("dW fc1", 8192, 3072, 768), ("dW fc2", 8192, 768, 3072)
         Cm = torch.empty(Nn, Nc, device=dev)
         r = []
         for var in (1, 3):
-            fn = lambda: lib.mmhip_op_gemm_tn(0, p(A), lda, p(B), ldb, p(Cm), Nc, M, Nn, Nc, 0, var << 4, st())
+            fn = lambda: lib.mmhip_op_gemm_tn(0, p(A), lda, p(B), ldb, p(Cm), Nc, M, Nn, Nc, 0, var << 4, None, st())
             r.append(f"v{var} {time_it(fn):6.1f}us")
         print(f"  {name} pad {pad:3d}: " + "  ".join(r), flush=True)
 print("NT, pad on A and B leading dims (128x128)")

@@ -27,5 +27,5 @@ else:   # tn: M = reduction, N = Nn, K = Nc
     B = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
     Cm = torch.empty(N, K, device=dev)
     for _ in range(iters):
-        lib.mmhip_op_gemm_tn(0, p(A), N, p(B), K, p(Cm), K, M, N, K, 0, var << 4, st)
+        lib.mmhip_op_gemm_tn(0, p(A), N, p(B), K, p(Cm), K, M, N, K, 0, var << 4, None, st)
 torch.cuda.synchronize()
