@@ -54,6 +54,7 @@ struct mmhip_engine {
     size_t ids_all, mask_all, pos_ids, maskbias, x0, xhat_emb, rstd_emb;
     size_t v_patches, v_pe, v_x, v_ln, v_qkv, v_ctx, v_h, v_out;                             // ViT ping-pong
     size_t g_partial, g_partial_side;
+    size_t g_lnp[2][2];      // LN-backward partials per (layer parity, LN index): reduced on the side stream with the layer's dW
     uint8_t* word_row_state = nullptr;     // caller-owned row flags of the word table (mmhip_set_row_state)
     size_t g_set[2][6];      // double-buffered backward temporaries read by the side stream: dpre2, ddrop2, du, dpre1, ddrop1, dqkv
     size_t g_dx, g_dx2, g_dpre, g_ddrop, g_dpre1, g_ddrop1, g_dqkv, g_dctx, g_du;                               // backward temporaries
@@ -256,6 +257,8 @@ void build_workspace(mmhip_engine& e) {
         if (pe > pf) pf = pe;
         e.g_partial = w.take((pf > pc ? pf : pc) * 4);
         e.g_partial_side = w.take((pf > pc ? pf : pc) * 4);
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) e.g_lnp[i][j] = w.take(partial_floats_rows((int)Mt, (int)H, 2) * 4);
     }
     auto f = [&](size_t n) { return w.take(n * 4); };
     e.h_vpool = f(Bm * H); e.h_tpool = f(Bm * H); e.h_txt_e = f(Bm * E); e.h_img_e = f(Bm * E); e.h_txt_n = f(Bm * E); e.h_img_n = f(Bm * E);
@@ -583,8 +586,9 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     // ---- x' = LN2(pre2), pre2 = drop(fc2(h)) + a1.  LN backward also emits the dropout-backward copy and the bias
     // gradient of the Linear that fed the LN
     const DropCfg d_ffn = make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr);
+    // (the second stage of its dgamma / dbeta reduction is not on the dX chain: it runs with the layer's dW on the side stream)
     LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mr, H,
-                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ffn.thresh16 ? ddrop2 : nullptr, nullptr, d_ffn, rmul};
+                 e.wsp<float>(e.g_lnp[set][0]), 1.0f / e.gscale(), d_ffn.thresh16 ? ddrop2 : nullptr, nullptr, d_ffn, rmul, 1};
     CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
     const char* df = d_ffn.thresh16 ? ddrop2 : dpre2;
     // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
@@ -593,7 +597,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
     LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mr, H,
-                 e.wsp<float>(e.g_partial), 1.0f / e.gscale(), d_ao.thresh16 ? ddrop1 : nullptr, nullptr, d_ao, rmul};
+                 e.wsp<float>(e.g_lnp[set][1]), 1.0f / e.gscale(), d_ao.thresh16 ? ddrop1 : nullptr, nullptr, d_ao, rmul, 1};
     CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
     const char* dout = d_ao.thresh16 ? ddrop1 : dpre1;
     if (compact) {
@@ -632,6 +636,8 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
         if (int r = run_gemm(e, g, s)) return r;
     }
     GemmTNProblem pr[4];
+    CHECK_HIP(launch_layernorm_bwd_reduce(b2, ps));
+    CHECK_HIP(launch_layernorm_bwd_reduce(b1, ps));
     // each problem also yields its Linear's bias gradient (column sums of the dY operand) from the same tiles
     pr[0] = GemmTNProblem{df, e.ws + a.h, Gd + o.fc2_w, Mr, H, I, H, I, I, 0, Gd + o.fc2_b};           // dW2[H,I]   = df^T h
     pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mr, I, H, I, H, H, 0, Gd + o.fc1_b};          // dW1[I,H]   = du^T a1

@@ -92,7 +92,9 @@ struct LNBwdArgs {
     // colsum_out[c] += alpha * sum_rows (dx_drop or dx)[.][c]   -- the bias gradient of the Linear that produced the LN input
     void* dx_drop; float* colsum_out; DropCfg drop;
     int drop_row_mul;     // dropout index uses row * drop_row_mul (0 = 1)
+    int defer_reduce;     // 1: only write the per-block partials; the caller runs launch_layernorm_bwd_reduce later
 };
+hipError_t launch_layernorm_bwd_reduce(const LNBwdArgs& a, hipStream_t s);
 hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s);
 hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s);
 

@@ -658,10 +658,15 @@ hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s) {
     const int grid = (a.rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
     if (dtype == DT_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
-    if (a.partial) {
-        const float al = a.alpha == 0.f ? 1.f : a.alpha;
-        launch_reduce_partials(a.partial, grid, a.width, a.dgamma, s, al, a.dbeta, a.colsum_out);
-    }
+    if (a.partial && !a.defer_reduce) return launch_layernorm_bwd_reduce(a, s);
+    return hipGetLastError();
+}
+// second stage of the column reductions (dgamma, dbeta[, colsum]); with LNBwdArgs::defer_reduce the caller issues it itself,
+// on whichever stream it likes, once the first stage is ordered before it
+hipError_t launch_layernorm_bwd_reduce(const LNBwdArgs& a, hipStream_t s) {
+    if (a.rows <= 0 || !a.partial) return hipSuccess;
+    const int grid = (a.rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
+    launch_reduce_partials(a.partial, grid, a.width, a.dgamma, s, a.alpha == 0.f ? 1.f : a.alpha, a.dbeta, a.colsum_out);
     return hipGetLastError();
 }
 hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s) {
