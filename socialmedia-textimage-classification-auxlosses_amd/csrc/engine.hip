@@ -68,7 +68,8 @@ struct mmhip_engine {
     uint64_t seed = 0;
     const float *bd_out_cls = nullptr, *bd_logits = nullptr, *bd_out_tim = nullptr, *bd_feats = nullptr;
     // internal side stream (ViT forward beside the text forward; weight gradients beside the dX chain) -------------
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr;          // weight-gradient work of the backward
+    hipStream_t side_vit[2] = {nullptr, nullptr};     // image tower of the forward: [0] normal, [1] high priority
     hipEvent_t ev_fork = nullptr, ev_vit = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_tn[2] = {nullptr, nullptr};
     bool tn_pending[2] = {false, false};
     int cls_only = -1;         // -1 = read MMHIP_CLS_ONLY on first use; 1: the last text layer runs its post-attention part on CLS rows only
@@ -329,11 +330,19 @@ SmallGemmArgs small(const void* A, int lda, const float* W, int ldw, const float
 int side_init(mmhip_engine& e) {
     if (e.overlap < 0) { const char* v = getenv("MMHIP_OVERLAP"); e.overlap = v ? atoi(v) : 1; }
     if (!e.overlap || e.side) return 0;
-    {   // MMHIP_SIDE_PRIO: HIP priority of the side stream (lower = higher).  Measured: highest -0.1 ms/step on config 2,
-        // +0.3 ms on config 3; lowest +0.2 ms -- equal priority stays the default
+    {
+        // MMHIP_SIDE_PRIO: HIP priority of the backward's side stream (lower = higher; default: equal to the caller's).
         const char* v = getenv("MMHIP_SIDE_PRIO");
         if (v) CHECK_HIP(hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, atoi(v)));
         else CHECK_HIP(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
+        // The forward's two towers race for the CUs: whichever chain is longer should not be the one that waits.  The image
+        // tower gets the high-priority stream when it is the longer chain (plain batch: 34.9 vs 22.3 GF per post), the
+        // normal one when the text pass is doubled by the ITM posts.  Measured same-box: -0.17 ms/step on config 2; the
+        // same high priority on config 3 costs +0.38 ms.  MMHIP_VIT_PRIO=0/1 forces the choice.
+        int least = 0, greatest = 0;
+        CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        CHECK_HIP(hipStreamCreateWithFlags(&e.side_vit[0], hipStreamNonBlocking));
+        CHECK_HIP(hipStreamCreateWithPriority(&e.side_vit[1], hipStreamNonBlocking, greatest));
     }
     hipEvent_t* evs[6] = {&e.ev_fork, &e.ev_vit, &e.ev_ready[0], &e.ev_ready[1], &e.ev_tn[0], &e.ev_tn[1]};
     for (auto ev : evs) CHECK_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
@@ -713,6 +722,7 @@ void mmhip_destroy(mmhip_handle h) {
         for (hipEvent_t ev : {h->ev_fork, h->ev_vit, h->ev_ready[0], h->ev_ready[1], h->ev_tn[0], h->ev_tn[1]})
             if (ev) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(h->side);
+        for (auto sv : h->side_vit) if (sv) (void)hipStreamDestroy(sv);
     }
     for (auto& ev : h->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     delete h;
@@ -770,9 +780,14 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
     if (use_side(e)) {
         // the frozen image tower does not depend on the text tower: run it on the side stream, join before the heads
         CHECK_HIP(hipEventRecord(e.ev_fork, s));
-        CHECK_HIP(hipStreamWaitEvent(e.side, e.ev_fork, 0));
-        if (int r = vit_forward(e, pixels, e.side)) return r;
-        CHECK_HIP(hipEventRecord(e.ev_vit, e.side));
+        static int force = -2;
+        if (force == -2) { const char* v = getenv("MMHIP_VIT_PRIO"); force = v ? atoi(v) : -1; }
+        const int P = (e.cfg.image / e.cfg.patch) * (e.cfg.image / e.cfg.patch) + 1;
+        const bool vit_longer = (double)e.B * P * e.cfg.layers_img > (double)e.Bt * e.T * e.cfg.layers_txt;     // rows x layers of equal width
+        hipStream_t sv = e.side_vit[force >= 0 ? (force ? 1 : 0) : (vit_longer ? 1 : 0)];
+        CHECK_HIP(hipStreamWaitEvent(sv, e.ev_fork, 0));
+        if (int r = vit_forward(e, pixels, sv)) return r;
+        CHECK_HIP(hipEventRecord(e.ev_vit, sv));
         if (int r = text_forward(e, s)) return r;
         CHECK_HIP(hipStreamWaitEvent(s, e.ev_vit, 0));
     } else {
