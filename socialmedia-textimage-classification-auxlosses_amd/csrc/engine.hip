@@ -69,6 +69,7 @@ struct mmhip_engine {
     const float *bd_out_cls = nullptr, *bd_logits = nullptr, *bd_out_tim = nullptr, *bd_feats = nullptr;
     // internal side stream (ViT forward beside the text forward; weight gradients beside the dX chain) -------------
     hipStream_t side = nullptr;          // weight-gradient work of the backward
+    bool vit_is_long = false;            // the image tower is the longer forward chain of this call (set by mmhip_forward)
     hipStream_t side_vit[2] = {nullptr, nullptr};     // image tower of the forward: [0] normal, [1] high priority
     hipEvent_t ev_fork = nullptr, ev_vit = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_tn[2] = {nullptr, nullptr};
     bool tn_pending[2] = {false, false};
@@ -375,6 +376,12 @@ int vit_forward(mmhip_engine& e, const float* pixels, hipStream_t s) {
     }
     CHECK_HIP(launch_vit_assemble(e.ws + e.v_pe, F + e.v_cls, F + e.v_pos, e.ws + e.v_x, B, P, H, dt, s));
     char* x = e.ws + e.v_x;
+    // 768-wide outputs of M = B*197 rows: 160-row tiles (474 tiles = one round of the 512 block slots, instead of 594 of
+    // 128x128 or 300 one-per-CU 256x128) are faster when this tower runs alone (serial: -0.4 ms/step) but not beside the text
+    // tower (same-box, image tower on its high-priority stream: +0.2 ms/step) -- opt-in: MMHIP_VIT_TILE160=1
+    static int t160 = -2;
+    if (t160 == -2) { const char* v = getenv("MMHIP_VIT_TILE160"); t160 = v ? atoi(v) : 0; }
+    const int narrow_tile = (t160 > 0 && Mv > 8192 && (long)((Mv + 159) / 160) * (H / 128) <= 512) ? 11 : 0;
     for (int l = 0; l < c.layers_img; ++l) {
         const LayerOff& o = e.vit[l];
         const LayerW16& w = e.vit_w16[l];
@@ -386,11 +393,11 @@ int vit_forward(mmhip_engine& e, const float* pixels, hipStream_t s) {
         at.qkv = e.ws + e.v_qkv; at.ctx = e.ws + e.v_ctx; at.posts = B; at.S = P; at.heads = c.heads; at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
         at.scale = 1.0f / sqrtf((float)(H / c.heads));
         CHECK_HIP(launch_attn_fwd(at, dt, s));
-        { G g(e.ws + e.v_ctx, H, e.ws + w.ao, H, x, H, Mv, H, H); g.bias(F + o.ao_b).residual(x, H); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_ctx, H, e.ws + w.ao, H, x, H, Mv, H, H); g.bias(F + o.ao_b).residual(x, H); g.a.tile = narrow_tile; if (int r = run_gemm(e, g, s)) return r; }
         LNArgs ln2{x, e.ws + e.v_ln, F + o.ln2_w, F + o.ln2_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
         CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
         { G g(e.ws + e.v_ln, H, e.ws + w.fc1, H, e.ws + e.v_h, I, Mv, I, H); g.bias(F + o.fc1_b).gelu(); if (int r = run_gemm(e, g, s)) return r; }
-        { G g(e.ws + e.v_h, I, e.ws + w.fc2, I, x, H, Mv, H, I); g.bias(F + o.fc2_b).residual(x, H); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_h, I, e.ws + w.fc2, I, x, H, Mv, H, I); g.bias(F + o.fc2_b).residual(x, H); g.a.tile = narrow_tile; if (int r = run_gemm(e, g, s)) return r; }
     }
     LNArgs lnf{x, e.ws + e.v_out, F + e.v_ln_w, F + e.v_ln_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
     CHECK_HIP(launch_layernorm_fwd(lnf, dt, s));
@@ -784,6 +791,7 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
         if (force == -2) { const char* v = getenv("MMHIP_VIT_PRIO"); force = v ? atoi(v) : -1; }
         const int P = (e.cfg.image / e.cfg.patch) * (e.cfg.image / e.cfg.patch) + 1;
         const bool vit_longer = (double)e.B * P * e.cfg.layers_img > (double)e.Bt * e.T * e.cfg.layers_txt;     // rows x layers of equal width
+        e.vit_is_long = vit_longer;
         hipStream_t sv = e.side_vit[force >= 0 ? (force ? 1 : 0) : (vit_longer ? 1 : 0)];
         CHECK_HIP(hipStreamWaitEvent(sv, e.ev_fork, 0));
         if (int r = vit_forward(e, pixels, sv)) return r;
