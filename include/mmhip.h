@@ -74,6 +74,7 @@ int mmhip_refresh_weights(mmhip_handle h, int which, void* stream);
 /* ---- MM_Model.forward (models/mm_late.py:148-193).  ids/mask/tim_* are int64 [B,T]; pixels fp32 [B,3,image,image];
  * outputs fp32: out_cls [B,num_labels], logits_per_text [B,B], out_tim [B,2] (only when tim_ids != NULL),
  * mm_features [B,hidden].  train != 0 applies dropout with masks derived from `seed`. */
+/* (pixels may be NULL after mmhip_vision_import, see below) */
 int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
                   const int64_t* tim_mask, int B, int T, int train, uint64_t seed, float* out_cls, float* logits_per_text,
                   float* out_tim, float* mm_features, void* stream);
@@ -84,6 +85,18 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
  * lbl_tim int64 [B] or NULL.  weights: w_cls = 1 - betas, w_itc / w_itm = beta or 0 when the aux loss is off. */
 int mmhip_loss(mmhip_handle h, const int64_t* onehot, const float* class_w, const int64_t* lbl_tim, float w_cls, float w_itc,
                float w_itm, float* loss, int* n_correct, void* stream);
+
+/* ---- image-tower output cache (optional; sized for 288 GB of HBM: 306 KB per post, a 100 k-image data set is 31 GB).
+ * The vision tower is frozen (models/mm_late.py:67-69) and has no dropout, so its outputs (last_hidden_state [197,768] in the
+ * compute dtype + pooler_output [768] fp32) are a pure function of the pixels: a caller that sees the same image again (every
+ * epoch after the first) may keep them.  `cache` is caller-owned device memory of cache_records * mmhip_vision_record_bytes(h);
+ * slots = int64 [B] on the device, negative = skip that post.
+ *   mmhip_vision_export: after mmhip_forward, copy the tower outputs of the B posts of that forward into their slots.
+ *   mmhip_vision_import: before mmhip_forward, load the outputs of B posts from their slots; the next mmhip_forward with
+ *   pixels == NULL and the same B uses them and skips the tower (MMHIP_E_STATE otherwise).  Results are bit-identical. */
+uint64_t mmhip_vision_record_bytes(mmhip_handle h);
+int mmhip_vision_export(mmhip_handle h, const int64_t* slots, void* cache, uint64_t cache_records, void* stream);
+int mmhip_vision_import(mmhip_handle h, const int64_t* slots, const void* cache, uint64_t cache_records, int B, void* stream);
 
 /* ---- loss.backward() (models/mm_late.py:489): gradients of every trainable parameter, ACCUMULATED into train_grad
  * (which must be zero where a fresh gradient is wanted).  Pass NULL pointers to use the gradients mmhip_loss left in

@@ -44,6 +44,9 @@ _SIGS = {
     "mmhip_refresh_weights": (I, [P, I, P]),
     "mmhip_forward": (I, [P, P, P, P, P, P, I, I, I, U64, P, P, P, P, P]),
     "mmhip_loss": (I, [P, P, P, P, F, F, F, P, P, P]),
+    "mmhip_vision_record_bytes": (U64, [P]),
+    "mmhip_vision_export": (I, [P, P, P, U64, P]),
+    "mmhip_vision_import": (I, [P, P, P, U64, I, P]),
     "mmhip_backward": (I, [P, P, P, P, P, P]),
     "mmhip_backward_begin": (I, [P, P, P, P, P, P]),
     "mmhip_backward_stage": (I, [P, I, P]),

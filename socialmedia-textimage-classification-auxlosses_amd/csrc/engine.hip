@@ -69,6 +69,7 @@ struct mmhip_engine {
     const float *bd_out_cls = nullptr, *bd_logits = nullptr, *bd_out_tim = nullptr, *bd_feats = nullptr;
     // internal side stream (ViT forward beside the text forward; weight gradients beside the dX chain) -------------
     hipStream_t side = nullptr;          // weight-gradient work of the backward
+    int vision_ready_B = 0;              // > 0: the image tower's outputs for that many posts were imported (mmhip_vision_import)
     bool vit_is_long = false;            // the image tower is the longer forward chain of this call (set by mmhip_forward)
     hipStream_t side_vit[2] = {nullptr, nullptr};     // image tower of the forward: [0] normal, [1] high priority
     hipEvent_t ev_fork = nullptr, ev_vit = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_tn[2] = {nullptr, nullptr};
@@ -769,9 +770,12 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
                   const int64_t* tim_mask, int B, int T, int train, uint64_t seed, float* out_cls, float* logits_per_text,
                   float* out_tim, float* mm_features, void* stream) {
     if (!h || !h->ws) return MMHIP_E_STATE;
-    if (!ids || !mask || !pixels || B < 1 || T < 1) return MMHIP_E_INVALID;
+    if (!ids || !mask || B < 1 || T < 1) return MMHIP_E_INVALID;
     if ((tim_ids == nullptr) != (tim_mask == nullptr)) return MMHIP_E_INVALID;
     mmhip_engine& e = *h;
+    const bool imported = pixels == nullptr;           // image tower outputs come from the caller's cache (mmhip_vision_import)
+    if (imported && e.vision_ready_B != B) return MMHIP_E_STATE;
+    e.vision_ready_B = 0;
     if (B > e.cfg.max_posts || T > e.cfg.max_text_len) return MMHIP_E_CAPACITY;
     hipStream_t s = (hipStream_t)stream;
     e.B = B; e.T = T; e.itm = tim_ids != nullptr; e.Bt = e.itm ? 2 * B : B; e.train_mode = train != 0; e.seed = seed;
@@ -793,17 +797,65 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
         const bool vit_longer = (double)e.B * P * e.cfg.layers_img > (double)e.Bt * e.T * e.cfg.layers_txt;     // rows x layers of equal width
         e.vit_is_long = vit_longer;
         hipStream_t sv = e.side_vit[force >= 0 ? (force ? 1 : 0) : (vit_longer ? 1 : 0)];
-        CHECK_HIP(hipStreamWaitEvent(sv, e.ev_fork, 0));
-        if (int r = vit_forward(e, pixels, sv)) return r;
-        CHECK_HIP(hipEventRecord(e.ev_vit, sv));
+        if (!imported) {
+            CHECK_HIP(hipStreamWaitEvent(sv, e.ev_fork, 0));
+            if (int r = vit_forward(e, pixels, sv)) return r;
+            CHECK_HIP(hipEventRecord(e.ev_vit, sv));
+        }
         if (int r = text_forward(e, s)) return r;
-        CHECK_HIP(hipStreamWaitEvent(s, e.ev_vit, 0));
+        if (!imported) CHECK_HIP(hipStreamWaitEvent(s, e.ev_vit, 0));
     } else {
-        if (int r = vit_forward(e, pixels, s)) return r;
+        if (!imported) if (int r = vit_forward(e, pixels, s)) return r;
         if (int r = text_forward(e, s)) return r;
     }
     if (int r = heads_forward(e, out_cls, logits_per_text, out_tim, mm_features, s)) return r;
     e.fwd_done = true;
+    return 0;
+}
+
+// ---- image-tower output cache (the tower is frozen and dropout-free: its output is a pure function of the pixels)
+namespace {
+__global__ __launch_bounds__(256) void vision_copy_kernel(int to_cache, const int64_t* __restrict__ slots, char* cache, uint64_t rec_bytes,
+                                                          uint64_t cache_records, char* v_out, char* vpool, uint32_t tok_bytes, uint32_t pool_bytes) {
+    const int64_t slot = slots[blockIdx.y];
+    if (slot < 0 || (uint64_t)slot >= cache_records) return;
+    char* rec = cache + (uint64_t)slot * rec_bytes;
+    char* tok = v_out + (size_t)blockIdx.y * tok_bytes;
+    char* pool = vpool + (size_t)blockIdx.y * pool_bytes;
+    const uint32_t n16 = (tok_bytes + pool_bytes) / 16, t16 = tok_bytes / 16;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) {
+        uint4* live = reinterpret_cast<uint4*>(i < t16 ? tok + (size_t)i * 16 : pool + (size_t)(i - t16) * 16);
+        uint4* kept = reinterpret_cast<uint4*>(rec + (size_t)i * 16);
+        if (to_cache) *kept = *live;
+        else *live = *kept;
+    }
+}
+int vision_copy(mmhip_engine& e, int to_cache, const int64_t* slots, void* cache, uint64_t cache_records, int B, hipStream_t s) {
+    const int P = (e.cfg.image / e.cfg.patch) * (e.cfg.image / e.cfg.patch) + 1, H = e.cfg.hidden;
+    const uint32_t tok_bytes = (uint32_t)P * H * 2, pool_bytes = (uint32_t)H * 4;
+    if (tok_bytes % 16 || pool_bytes % 16) return MMHIP_E_INVALID;
+    hipLaunchKernelGGL(vision_copy_kernel, dim3(16, B), dim3(256), 0, s, to_cache, slots, (char*)cache, mmhip_vision_record_bytes(&e), cache_records,
+                       e.ws + e.v_out, (char*)e.wsp<float>(e.h_vpool), tok_bytes, pool_bytes);
+    hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : (int)err;
+}
+}  // namespace
+uint64_t mmhip_vision_record_bytes(mmhip_handle h) {
+    if (!h) return 0;
+    const uint64_t P = (uint64_t)(h->cfg.image / h->cfg.patch) * (h->cfg.image / h->cfg.patch) + 1;
+    return (P * h->cfg.hidden * 2 + (uint64_t)h->cfg.hidden * 4 + 255) & ~255ull;
+}
+int mmhip_vision_export(mmhip_handle h, const int64_t* slots, void* cache, uint64_t cache_records, void* stream) {
+    if (!h || !h->ws || !h->fwd_done) return MMHIP_E_STATE;
+    if (!slots || !cache || ((uintptr_t)cache & 15)) return MMHIP_E_INVALID;
+    return vision_copy(*h, 1, slots, cache, cache_records, h->B, (hipStream_t)stream);
+}
+int mmhip_vision_import(mmhip_handle h, const int64_t* slots, const void* cache, uint64_t cache_records, int B, void* stream) {
+    if (!h || !h->ws) return MMHIP_E_STATE;
+    if (!slots || !cache || ((uintptr_t)cache & 15) || B < 1) return MMHIP_E_INVALID;
+    if (B > h->cfg.max_posts) return MMHIP_E_CAPACITY;
+    if (int r = vision_copy(*h, 0, slots, const_cast<void*>(cache), cache_records, B, (hipStream_t)stream)) return r;
+    h->vision_ready_B = B;
     return 0;
 }
 

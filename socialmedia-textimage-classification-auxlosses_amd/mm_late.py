@@ -274,20 +274,53 @@ class MM_Model(nn.Module):
             self._refresh_weights(3 if self._weights_version is None or self._weights_version[1] != self._flat_frozen._version else 2)
 
     # ------------------------------------------------------------------ engine calls
-    def _engine_forward(self, ids, mask, pixels, tim_ids=None, tim_mask=None, seed=None):
+    # ---- image-tower output cache (include/mmhip.h: mmhip_vision_export / _import)
+    def enable_vision_cache(self, capacity_posts):
+        """keep the frozen, dropout-free image tower's outputs per post key (306 KB each, in HBM): a post seen again (every
+        epoch after the first) skips the tower and the pixel transfer; results are bit-identical.  Keys are passed to
+        `_engine_forward(..., vision_keys=...)` (MMLate_Model.train / eval pass the batch's data_id)."""
+        rec = int(_lib.lib().mmhip_vision_record_bytes(self._handle))
+        self._vcache = dict(rec=rec, cap=int(capacity_posts), slots={}, hits=0, misses=0,
+                            buf=torch.empty(int(capacity_posts) * rec, dtype=torch.uint8, device=self.device_))
+
+    def _vision_slots(self, keys, assign):
+        vc = self._vcache
+        out = []
+        for k in keys:
+            k = int(k)
+            s = vc["slots"].get(k, -1)
+            if s < 0 and assign and len(vc["slots"]) < vc["cap"]:
+                s = vc["slots"][k] = len(vc["slots"])
+            out.append(s)
+        t = torch.tensor(out, dtype=torch.int64).pin_memory()
+        return out, t.to(self.device_, non_blocking=True)
+
+    def _engine_forward(self, ids, mask, pixels, tim_ids=None, tim_mask=None, seed=None, vision_keys=None):
         dev = self.device_
         ids = ids.to(dev, torch.int64).contiguous()
         mask = mask.to(dev, torch.int64).contiguous()
-        pixels = pixels.to(dev, torch.float32).contiguous()
-        if ids.dim() != 2 or pixels.dim() != 4 or pixels.shape[0] != ids.shape[0]:
-            raise ValueError(f"MM_Model.forward: ids {tuple(ids.shape)} / pixel_values {tuple(pixels.shape)}")
+        if ids.dim() != 2:
+            raise ValueError(f"MM_Model.forward: ids {tuple(ids.shape)}")
         B, T = ids.shape
-        if tuple(pixels.shape[1:]) != (3, self.arch["image"], self.arch["image"]):
-            raise ValueError(f"pixel_values must be [B,3,{self.arch['image']},{self.arch['image']}], got {tuple(pixels.shape)}")
+        vc = getattr(self, "_vcache", None) if vision_keys is not None else None
+        if vc is not None and len(vision_keys) != B:
+            raise ValueError("vision_keys: one key per post")
+        self._ensure(B, T)
+        cached = False
+        if vc is not None:
+            slots, slots_dev = self._vision_slots(vision_keys, assign=False)
+            if all(s >= 0 for s in slots):
+                _lib.check(_lib.lib().mmhip_vision_import(self._handle, _lib.ptr(slots_dev), _lib.ptr(vc["buf"]), vc["cap"], B, _lib.stream_ptr()),
+                           "vision_import")
+                cached, pixels = True, None
+                vc["hits"] += B
+        if not cached:
+            pixels = pixels.to(dev, torch.float32).contiguous()
+            if pixels.dim() != 4 or pixels.shape[0] != B or tuple(pixels.shape[1:]) != (3, self.arch["image"], self.arch["image"]):
+                raise ValueError(f"pixel_values must be [{B},3,{self.arch['image']},{self.arch['image']}], got {tuple(pixels.shape)}")
         if tim_ids is not None:
             tim_ids = tim_ids.to(dev, torch.int64).contiguous()
             tim_mask = tim_mask.to(dev, torch.int64).contiguous()
-        self._ensure(B, T)
         if seed is None:
             self._calls += 1
             seed = (self._seed_base * 0x9E3779B97F4A7C15 + self._calls) & 0xFFFFFFFFFFFFFFFF
@@ -300,6 +333,11 @@ class MM_Model(nn.Module):
                                             _lib.ptr(feats), _lib.stream_ptr()), "forward")
         self._fwd_token += 1
         self._last = dict(B=B, T=T, itm=tim_ids is not None, seed=seed, ids_all=ids if tim_ids is None else torch.cat([ids, tim_ids]))
+        if vc is not None and not cached:
+            slots, slots_dev = self._vision_slots(vision_keys, assign=True)         # posts beyond the capacity stay uncached (-1)
+            _lib.check(_lib.lib().mmhip_vision_export(self._handle, _lib.ptr(slots_dev), _lib.ptr(vc["buf"]), vc["cap"], _lib.stream_ptr()),
+                       "vision_export")
+            vc["misses"] += B
         return out_cls, lpt, out_tim, feats
 
     def active_groups(self, use_itc, use_itm):
@@ -423,7 +461,7 @@ class MMLate_Model(object):
         return 1.0 - (bi + bm), bi, bm
 
     # ---- one fused training step on device tensors; returns (loss[4] device tensor, n_correct device tensor)
-    def train_step(self, ids, mask, pixel_values, onehot, class_weight, lr, weight_decay, step, tim=None):
+    def train_step(self, ids, mask, pixel_values, onehot, class_weight, lr, weight_decay, step, tim=None, vision_keys=None):
         m, lib = self.model, _lib.lib()
         s = _lib.stream_ptr()
         if self.use_tim_loss and tim is None:
@@ -431,7 +469,7 @@ class MMLate_Model(object):
         tim_ids, tim_mask, lbl_tim = tim if tim is not None else (None, None, None)
         if not m.training:
             m.train()                              # walks ~370 submodules (1.3 ms of host time): only on a mode change
-        m._engine_forward(ids, mask, pixel_values, tim_ids, tim_mask)
+        m._engine_forward(ids, mask, pixel_values, tim_ids, tim_mask, vision_keys=vision_keys)
         w_cls, w_itc, w_itm = self.loss_weights()
         onehot = onehot.to(self.device, torch.int64).contiguous()
         cw = None if class_weight is None else class_weight.to(self.device, torch.float32).contiguous()
@@ -515,7 +553,9 @@ class MMLate_Model(object):
             for it, batch in enumerate(self._device_batches(dataloader)):
                 ids, mask, px = self._unpack(batch)
                 step += 1
-                loss, ncorr = self.train_step(ids.to(self.device), mask.to(self.device), px, batch["labels"], class_weight, lr, weight_decay, step)
+                keys = batch["data_id"].tolist() if (getattr(self.model, "_vcache", None) is not None and "data_id" in batch) else None
+                loss, ncorr = self.train_step(ids.to(self.device), mask.to(self.device), px, batch["labels"], class_weight, lr, weight_decay, step,
+                                              vision_keys=keys)
                 if log_every and it % log_every == 0 and mmdist.rank() == 0:     # the reference syncs every step (:496-498)
                     n = ids.shape[0]
                     print(f"Got {int(ncorr.item())} / {n} with accuracy {float(ncorr.item()) / n * 100:.2f} loss {loss[0].item():.4f}")
@@ -547,7 +587,8 @@ class MMLate_Model(object):
                 ids, mask = ids.to(self.device), mask.to(self.device)
                 tim = self.prepare_itm_inputs(ids, mask) if self.use_tim_loss else None
                 tim_ids, tim_mask, lbl_tim = tim if tim is not None else (None, None, None)
-                out_cls, _, _, _ = m._engine_forward(ids, mask, px, tim_ids, tim_mask)
+                keys = batch["data_id"].tolist() if (getattr(m, "_vcache", None) is not None and "data_id" in batch) else None
+                out_cls, _, _, _ = m._engine_forward(ids, mask, px, tim_ids, tim_mask, vision_keys=keys)
                 onehot = batch["labels"].to(self.device, torch.int64).contiguous()
                 loss = torch.empty(4, device=self.device)
                 _lib.check(lib.mmhip_loss(m._handle, _lib.ptr(onehot), _lib.ptr(cw), _lib.ptr(lbl_tim), w_cls, w_itc, w_itm,

@@ -1,6 +1,6 @@
 """Command line of the late-fusion runs -- same flags, defaults, file names and CSV layouts as the reference's
 models/run_mm_late.py:20-191.  Additive flags: --batch_size, --synthetic/--n_synthetic (no dataset on disk),
---dtype, --results_dir, --cpu_preprocess, --num_workers.  Data parallel: launch with `python -m torch.distributed.run --nproc-per-node N ...`.
+--dtype, --results_dir, --cpu_preprocess, --num_workers, --cache_vision.  Data parallel: launch with `python -m torch.distributed.run --nproc-per-node N ...`.
 
     python -m smtc_amd.run_mm_late --txt_model_name bernice --img_model_name vit --fusion_name attention --task 2 --testing
 """
@@ -63,6 +63,8 @@ def build_parser():
     p.add_argument("--arch_layers", type=int, default=None, help="(testing) override encoder depth")
     p.add_argument("--cpu_preprocess", action="store_true", help="resize / normalize images on the host (PIL) instead of the GPU kernels")
     p.add_argument("--num_workers", type=int, default=0, help="DataLoader workers (reference: 0)")
+    p.add_argument("--cache_vision", type=int, default=0, metavar="POSTS",
+                   help="keep the frozen image tower's outputs of up to POSTS posts in HBM (306 KB each): epochs after the first skip the tower")
     return p
 
 
@@ -111,6 +113,8 @@ def main(argv=None):
     if args.arch_layers:
         kw["arch"] = dict(layers_txt=args.arch_layers, layers_img=args.arch_layers)
     trainer = MMLate_Model(cfg, args.txt_model_name, args.img_model_name, args.fusion_name, multilabel=cfg.multilabel, **kw)
+    if args.cache_vision > 0:
+        trainer.model.enable_vision_cache(args.cache_vision)
     train_loader, val_loader, test_loader, weight = make_loaders(args, cfg, trainer)
     names = file_names(args, results_dir, cfg.loss_str)
     model_path = names["model"] if (args.save_model or args.load_saved_model) else None

@@ -411,3 +411,48 @@ def test_full_size_backward_is_the_mean_of_half_batches():
     for b, e in model.active_ranges(False, False):
         err = (g_all[b:e] - ref[b:e]).norm().item() / max(ref[b:e].norm().item(), 1e-30)
         assert err < 2e-3, (b, e, err)            # identical per-row arithmetic; only fp32 / 16-bit summation order differs
+
+
+def test_vision_cache_is_bit_identical_and_skips_the_tower():
+    """image-tower output cache (include/mmhip.h mmhip_vision_export/_import): a post seen again takes its tower outputs from
+    HBM -- outputs, loss gradients and trained parameters are bit-identical to recomputing; mixed / over-capacity batches
+    recompute; pixels == NULL without an import is refused"""
+    import ctypes as C
+    from smtc_amd import _lib
+    arch = dict(layers_txt=1, layers_img=2, vocab=400, max_pos=130, p_hidden=0.0, p_attn=0.0)
+    cfg = O.OracleConfig(layers_txt=1, layers_img=2, vocab=400, max_pos=130, num_labels=3)
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, 6, 32, 21, True)
+    plain = MM_Model(3, "bernice", "vit", 0.0, "attention", arch=arch, max_posts=8, max_text_len=32, seed=4)
+    cached = MM_Model(3, "bernice", "vit", 0.0, "attention", arch=arch, max_posts=8, max_text_len=32, seed=4)
+    cached.enable_vision_cache(8)
+    plain.eval(); cached.eval()
+    keys = [101, 102, 103, 104, 105, 106]
+    with torch.no_grad():
+        ref = plain._engine_forward(ids, mask, pixels)
+        a = cached._engine_forward(ids, mask, pixels, vision_keys=keys)              # miss: computes + exports
+        assert cached._vcache["misses"] == 6 and cached._vcache["hits"] == 0
+        garbage = torch.full_like(pixels, float("nan"))
+        b = cached._engine_forward(ids, mask, garbage, vision_keys=keys)             # hit: pixels are not even looked at
+        assert cached._vcache["hits"] == 6
+        perm = [3, 0, 5, 1, 4, 2]
+        c = cached._engine_forward(ids[perm], mask[perm], garbage, vision_keys=[keys[j] for j in perm])
+        for x, y, z, w in zip(ref, a, b, c):
+            if x is not None:
+                assert torch.equal(x, y) and torch.equal(x, z)
+        assert torch.equal(ref[0][perm], c[0]) and torch.equal(ref[3][perm], c[3])
+        # a batch with an unknown key recomputes (and needs real pixels); over capacity: keys stay uncached
+        d = cached._engine_forward(ids, mask, pixels, vision_keys=[101, 102, 103, 104, 105, 999])
+        assert torch.equal(d[0], ref[0]) and len(cached._vcache["slots"]) == 7
+        cached._engine_forward(ids, mask, pixels, vision_keys=[201, 202, 203, 204, 205, 206])
+        assert len(cached._vcache["slots"]) == 8                                       # capacity 8: only one more fitted
+    # gradients through a cached forward
+    for m in (plain, cached):
+        m.train()
+        m._flat_grad.zero_()
+    o1 = plain(ids, mask, pixels)
+    (O.cls_loss(o1[0], onehot.to(o1[0].device).float(), None) + o1[1].float().pow(2).mean()).backward()
+    out = cached._engine_forward(ids, mask, garbage, vision_keys=keys)
+    assert torch.equal(out[0], o1[0].detach())
+    lib = _lib.lib()
+    assert lib.mmhip_forward(cached._handle, _lib.ptr(ids.cuda()), _lib.ptr(mask.cuda()), None, None, None, 6, 32, 0, 1, _lib.ptr(out[0]), _lib.ptr(out[1]), None,
+                             _lib.ptr(out[3]), _lib.stream_ptr()) == -2                # pixels NULL without an import: MMHIP_E_STATE
