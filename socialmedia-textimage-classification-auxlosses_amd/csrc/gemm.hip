@@ -62,7 +62,6 @@ void gemm_nt_kernel(GemmNTArgs a) {
 
     // ---- LDS-DMA staging: one wave instruction = 8 tile rows x 128 B; lane -> (row, 16-B slot)
     const int lrow = lane >> 3, slot = lane & 7;
-    const bool is_loader = NL == 0 || w >= C::NW;
     const int lw = NL ? (w - C::NW) & (C::NLOAD - 1) : w;          // index among the loading waves
     const T* asrc[C::AI];
     const T* bsrc[C::BI];

@@ -94,7 +94,7 @@ __device__ __forceinline__ uint8_t clip8(int32_t v) {
 __global__ __launch_bounds__(256) void resample_pass_kernel(PassArgs a) {
     const int32_t* rec = a.plan + HDR + blockIdx.y * REC;
     const int S = a.S;
-    const int h = rec[2], w = rec[3], order = rec[4];
+    const int w = rec[3], order = rec[4];
     const bool horizontal = (order == 0) != (a.second != 0);       // H-first: pass 0 horizontal; V-first: pass 1 horizontal
     const uint8_t* src;
     int src_w, rows_out, cols_out, row_shift = 0;
