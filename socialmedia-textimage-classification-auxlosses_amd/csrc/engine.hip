@@ -610,7 +610,13 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     const char* df = d_ffn.thresh16 ? ddrop2 : dpre2;
     // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
     { G g(df, H, e.ws + w.fc2T, H, du, I, Mr, I, H); g.mul_gelu_grad(e.ws + a.u, I); if (int r = run_gemm(e, g, s)) return r; }
-    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mr, H, I); g.residual(dpre2, H); if (int r = run_gemm(e, g, s)) return r; }
+    // the two long-K activation-gradient GEMMs of the layer (768 wide): one role-specialised 256x96 tile per CU when M gives
+    // exactly <= 256 of them -- in isolation 7 % faster than the 192 tiles of 256x128, in the step -0.05 ms (same-box A/B; the
+    // same tile in the FORWARD costs +0.3 ms: it leaves no CU to the image tower).  MMHIP_BWD_TILE12=0 turns it off.
+    static int bt12 = -1;
+    if (bt12 < 0) { const char* v = getenv("MMHIP_BWD_TILE12"); bt12 = v ? atoi(v) : 1; }
+    const int nt = (bt12 && Mr >= 4096 && Mr <= 8192 && H % 96 == 0) ? 12 : 0;
+    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mr, H, I); g.residual(dpre2, H); g.a.tile = nt; if (int r = run_gemm(e, g, s)) return r; }
     // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
     LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mr, H,
@@ -625,6 +631,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
         CHECK_HIP(hipMemsetAsync(dqkv, 0, (size_t)Mt * 3 * H * 2, s));      // dQ of the skipped query tiles is zero
     } else {
         G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H);
+        g.a.tile = (bt12 & 2) ? nt : 0;
         if (int r = run_gemm(e, g, s)) return r;
     }
     AttnBwdArgs ab;
@@ -650,6 +657,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     } else {
         G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H);
         g.residual(dpre1, H);
+        g.a.tile = nt;
         if (int r = run_gemm(e, g, s)) return r;
     }
     GemmTNProblem pr[4];

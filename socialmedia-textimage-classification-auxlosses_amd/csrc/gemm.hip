@@ -575,7 +575,8 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if ((t == 8 || t == 9) && a.N % 128) t = 0;
     if (t == 10 && a.N % 96) t = 0;
     if (t == 11 && a.N % 128) t = 0;
-    if (t >= 1 && t <= 11) return t;
+    if (t == 12 && a.N % 96) t = 0;
+    if (t >= 1 && t <= 12) return t;
     if (a.N % 128 && a.N % 192 == 0 && a.N % 256) { /* only the 192-wide tiles divide N */ }
     // Measured inside the training step (bench.py with MMHIP_NT_TILE forced, profiles/r01_tile_sweep.txt): 128x128 at two
     // blocks per CU is as fast as any other tile for every shape of this model; the isolated micro-benchmark gains of the
@@ -612,6 +613,7 @@ static int choose_nt_tile(const GemmNTArgs& a) {
 template <typename T>
 static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
     switch (choose_nt_tile(a)) {
+        case 12: launch_nt_t<T, 256, 96, 4, 2, 3, 4>(a, s); break;    // role-specialised, 256 tiles for 8192 x 768: one tile per CU
         case 11: launch_nt_t<T, 160, 128, 2, 2, 2>(a, s); break;      // 474 tiles for M = 12608 (ViT), N = 768: one round of 512 slots
         case 10: launch_nt_t<T, 128, 96, 2, 2, 2>(a, s); break;       // 512 / 1536 tiles for N = 768 / 2304 at M = 8192: whole rounds
         case 9: launch_nt_t<T, 256, 128, 4, 2, 3, 4>(a, s); break;    // 8 consumers + 4 loaders, 3-stage ring

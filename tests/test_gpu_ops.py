@@ -67,11 +67,12 @@ def _gemm_ref(A, B, bias, act, resid, mulg, keep, scale):
                                         (200, 128, 64, 128), (1000, 768, 768, 128), (8192, 2304, 768, 128), (2048, 768, 3072, 128),
                                         (300, 128, 128, 144), (8192, 3072, 768, 144), (1000, 768, 2304, 144),
                                         (200, 96, 64, 160), (8192, 768, 768, 160), (1000, 2304, 768, 160), (300, 480, 128, 0),
-                                        (200, 128, 64, 176), (12608, 768, 768, 176), (1000, 768, 3072, 176), (161, 256, 128, 176)])
+                                        (200, 128, 64, 176), (12608, 768, 768, 176), (1000, 768, 3072, 176), (161, 256, 128, 176),
+                                        (300, 96, 64, 192), (8192, 768, 3072, 192), (1000, 2304, 768, 192)])
 def test_gemm_nt_epilogues(dt, M, N, K, slow):
     """`slow`: bit 0 forces the generic kernel, bits 4.. pick the tile variant (16 = 128x128, 32 = 256x128, 48 = 256x256,
     64 = 128x128 4-stage ring, 80 = 256x128 3-stage ring, 96 = 128x192, 112 = 256x192,
-    128 / 144 = role-specialised 128x128 / 256x128: MFMA waves + LDS-DMA loader waves, 160 = 128x96, 176 = 160x128)"""
+    128 / 144 = role-specialised 128x128 / 256x128: MFMA waves + LDS-DMA loader waves, 160 = 128x96, 176 = 160x128, 192 = role-specialised 256x96)"""
     code, tdt = DT[dt]
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = (torch.randn(M, K, generator=g) * 0.5).to(tdt).to(dev())
