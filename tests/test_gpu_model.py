@@ -456,3 +456,53 @@ def test_vision_cache_is_bit_identical_and_skips_the_tower():
     lib = _lib.lib()
     assert lib.mmhip_forward(cached._handle, _lib.ptr(ids.cuda()), _lib.ptr(mask.cuda()), None, None, None, 6, 32, 0, 1, _lib.ptr(out[0]), _lib.ptr(out[1]), None,
                              _lib.ptr(out[3]), _lib.stream_ptr()) == -2                # pixels NULL without an import: MMHIP_E_STATE
+
+
+def test_loads_huggingface_directories_like_from_vision_text_pretrained(tmp_path, monkeypatch):
+    """MM_Model.__init__ with local HF model directories (the reference's from_vision_text_pretrained(img_dir, txt_dir),
+    models/mm_late.py:59-61): architecture comes from config.json, every tower weight from the checkpoint (transformers 5
+    ViT key names mapped back to the reference's 4.25.1 names), and the forward agrees with the installed transformers'
+    own ViTModel / XLMRobertaModel run on those very weights"""
+    import transformers
+    from smtc_amd import mm_late as ML
+    torch.manual_seed(7)
+    vcfg = transformers.ViTConfig(num_hidden_layers=2)
+    tcfg = transformers.XLMRobertaConfig(vocab_size=900, num_hidden_layers=2, max_position_embeddings=130, layer_norm_eps=1e-5, type_vocab_size=1,
+                                         pad_token_id=1, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    vit, txt = transformers.ViTModel(vcfg).eval(), transformers.XLMRobertaModel(tcfg).eval()
+    d_vit, d_txt = str(tmp_path / "vit"), str(tmp_path / "bernice")
+    vit.save_pretrained(d_vit)
+    txt.save_pretrained(d_txt)
+    monkeypatch.setitem(ML.MODEL_DIR_DICT, "vit", d_vit)
+    monkeypatch.setitem(ML.MODEL_DIR_DICT, "bernice", d_txt)
+    model = MM_Model(3, "bernice", "vit", 0.05, "attention", max_posts=4, max_text_len=32, seed=1, dtype="f16")
+    assert model.arch["layers_txt"] == 2 and model.arch["layers_img"] == 2 and model.arch["vocab"] == 900
+    sd = model.state_dict()
+    for k, v in txt.state_dict().items():
+        if k.endswith("position_ids") or k.endswith("token_type_ids"):
+            continue
+        assert torch.equal(sd["dual_encoder.text_model." + k].cpu(), v), k
+    n_vit = 0
+    for k, v in vit.state_dict().items():
+        rk = "dual_encoder.vision_model." + ML._vit_key_to_ref(k)
+        assert rk in sd, rk
+        assert torch.equal(sd[rk].cpu().reshape(v.shape), v), k
+        n_vit += 1
+    assert n_vit >= 2 * 16 + 6
+    # forward: towers of the installed transformers on the same weights (fp32, CPU) vs the engine (f16 operands)
+    cfg = O.OracleConfig(layers_txt=2, layers_img=2, vocab=900, max_pos=130, num_labels=3)
+    ids, mask, pixels, _ = O.synthetic_batch(cfg, 4, 32, 3, True)
+    model.eval()
+    with torch.no_grad():
+        out_cls, lpt, _, _, feats = model(ids, mask, pixels)
+        tv = vit(pixel_values=pixels)
+        tt = txt(input_ids=ids, attention_mask=mask)
+        P = {k: v.detach().float().cpu() for k, v in sd.items()}
+        txt_e = tt.pooler_output @ P["dual_encoder.text_projection.weight"].t()
+        img_e = tv.pooler_output @ P["dual_encoder.visual_projection.weight"].t()
+        txt_e, img_e = txt_e / txt_e.norm(dim=-1, keepdim=True), img_e / img_e.norm(dim=-1, keepdim=True)
+        ref_lpt = txt_e @ img_e.t() * P["dual_encoder.logit_scale"].exp()
+        ref = O.mm_forward(P, ids, mask, pixels, cfg)
+    assert (lpt.cpu() - ref_lpt).abs().max().item() / ref_lpt.abs().max().item() < 2e-3
+    assert (out_cls.cpu() - ref[0]).abs().max().item() / ref[0].abs().max().item() < 2e-3
+    assert (feats.cpu() - ref[4]).abs().max().item() / ref[4].abs().max().item() < 2e-3
