@@ -119,9 +119,15 @@ class DevicePrefetcher:
     stream never waits on a pageable host-to-device copy (a 38 MB pixel batch otherwise serialises with the step).
     Batches with `image_packed` / `image_plan` (RawImageCollate) are turned into `pixel_values` on the GPU here."""
 
+    _streams = {}        # one copy stream per device for every prefetcher: the caching allocator pools blocks per stream, and a
+                         # fresh stream per epoch strands the previous one's cached blocks (reserved memory grew 0.1-0.3 GiB per instance)
+
     def __init__(self, loader, device, processor=None, depth=2, trim_padding=True):
         self.loader, self.device, self.proc, self.depth = loader, torch.device(device), processor, max(1, depth)
-        self.stream = torch.cuda.Stream(device=self.device)
+        key = (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
+        if key not in DevicePrefetcher._streams:
+            DevicePrefetcher._streams[key] = torch.cuda.Stream(device=self.device)
+        self.stream = DevicePrefetcher._streams[key]
         self.trim_padding = trim_padding
 
     @staticmethod
