@@ -124,6 +124,9 @@ def main(argv=None):
         logger.info("Training")
         trainer.train(train_loader, val_loader, args.epochs, None, cfg.lr, cfg.weight_decay, te_dataloader=test_loader, model_path=model_path,
                       val_filename=names["val"], te_filename=names["test"], class_weight=weight)
+        vc = getattr(trainer.model, "_vcache", None)
+        if vc is not None:
+            logger.info("image-tower output cache: %d posts served from HBM, %d computed, %d cached", vc["hits"], vc["misses"], len(vc["slots"]))
         if args.save_preds and mmdist.rank() == 0:
             pred = trainer.eval(test_loader, class_weight=weight)
             pd.DataFrame({"data_id": pred["data_id"].tolist(), "label": pred["labels"].tolist(),
