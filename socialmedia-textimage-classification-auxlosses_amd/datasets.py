@@ -128,4 +128,12 @@ def loaders_from_data_key(cfg, args, trainer):
         trainer.image_processor = GpuImageProcessor(size=size, device=trainer.device)
         kw["collate_fn"] = RawImageCollate(trainer.image_processor)
     dl = lambda ds, sh: torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh, **kw)
-    return dl(mk(tr, ytr), True), dl(mk(va, yva), False), dl(mk(te, yte), False), w
+    train_ds = mk(tr, ytr)
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        # data parallel: every rank trains on its own shard (equal length on all ranks, so the per-stage all-reduces pair up);
+        # MMLate_Model.train calls sampler.set_epoch.  Validation / test stay whole on every rank (rank 0 writes the files).
+        sampler = torch.utils.data.distributed.DistributedSampler(train_ds, shuffle=True, seed=int(args.seed), drop_last=False)
+        train_loader = torch.utils.data.DataLoader(train_ds, batch_size=cfg.batch_size, sampler=sampler, **kw)
+    else:
+        train_loader = dl(train_ds, True)
+    return train_loader, dl(mk(va, yva), False), dl(mk(te, yte), False), w

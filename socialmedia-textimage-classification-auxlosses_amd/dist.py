@@ -30,7 +30,7 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("MMHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
     td.init_process_group(backend=backend)
@@ -48,15 +48,19 @@ def allreduce_range(flat_grad, begin, end, async_op=True):
     return td.all_reduce(flat_grad[begin:end], op=td.ReduceOp.SUM, async_op=async_op)
 
 
-def sparse_rows_exchange_begin(table_grad, ids):
+def sparse_rows_exchange_begin(table_grad, ids, capacity=None):
     """table_grad [V, H] holds this rank's gradient rows (non-zero only for rows in `ids`).  Starts the exchange (two
     asynchronous all_gathers of a fixed-size payload -- no host sync: rows are sent once per distinct id, first occurrence
-    in sorted order, the other slots carry zeros) and returns the state `sparse_rows_exchange_finish` needs, or None."""
+    in sorted order, the other slots carry zeros) and returns the state `sparse_rows_exchange_finish` needs, or None.
+    `capacity`: number of id slots every rank sends (ranks may hold different token counts -- the prefetcher trims each
+    rank's batch to its own longest post); the surplus slots repeat the last id and so carry zero rows."""
     W = world_size()
     if W == 1 and not force_exchange():
         return None
     ids = ids.reshape(-1).to(table_grad.device)
     sorted_ids, _ = torch.sort(ids)
+    if capacity is not None and capacity > sorted_ids.numel():
+        sorted_ids = torch.cat([sorted_ids, sorted_ids[-1:].expand(capacity - sorted_ids.numel())])
     first = torch.ones_like(sorted_ids, dtype=torch.bool)
     first[1:] = sorted_ids[1:] != sorted_ids[:-1]
     payload = table_grad.index_select(0, sorted_ids) * first.unsqueeze(1).to(table_grad.dtype)
@@ -105,7 +109,8 @@ def exchange_stage(model, stage, n_stage, use_itc, use_itm, finishers=None):
         works.append(w)
     V, H = word["shape"]
     table = model._flat_grad[word["offset"]: word["offset"] + V * H].view(V, H)
-    state = sparse_rows_exchange_begin(table, model._last["ids_all"])
+    cap_b, cap_t = model._capacity                              # the same on every rank (constructor arguments), unlike B*T of a trimmed batch
+    state = sparse_rows_exchange_begin(table, model._last["ids_all"], cap_b * cap_t * (2 if model._last["itm"] else 1))
     finish = lambda: sparse_rows_exchange_finish(state, table, getattr(model, "_word_row_state", None))
     if finishers is None:
         finish()

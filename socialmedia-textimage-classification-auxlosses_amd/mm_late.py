@@ -550,6 +550,8 @@ class MMLate_Model(object):
         for epoch in range(epochs):
             if mmdist.rank() == 0:
                 print("Epoch:", epoch + 1)
+            if hasattr(getattr(dataloader, "sampler", None), "set_epoch"):
+                dataloader.sampler.set_epoch(epoch)              # DistributedSampler: a new shuffle per epoch, same on all ranks
             for it, batch in enumerate(self._device_batches(dataloader)):
                 ids, mask, px = self._unpack(batch)
                 step += 1

@@ -99,9 +99,9 @@ def main(argv=None):
             # text-only test split (models/mm_late.py:372-376) and pre-extracted processor outputs (models/datasets.py:155-158):
             # outside the hot path (DESIGN.md "Out of scope"); refused rather than silently ignored
             raise NotImplementedError(f"--{flag} is not part of this build")
-    torch.manual_seed(args.seed)                      # models/run_mm_late.py:48-49
-    np.random.seed(args.seed)
     mmdist.init_from_env()
+    torch.manual_seed(args.seed)                      # models/run_mm_late.py:48-49 (same on every rank: identical initial weights)
+    np.random.seed(args.seed + mmdist.rank())         # ITM negative sampling draws from numpy: its own stream per rank
     results_dir = args.results_dir or results_dir_mm_late
     if args.testing:
         results_dir += "testing/"

@@ -171,3 +171,26 @@ def test_rccl_call_pattern_at_world_size_one(tmp_path):
     r = run([sys.executable, str(script)], env={"ROOT": ROOT, "PORT": str(29900 + os.getpid() % 90), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_ERR")][0].split()
     assert float(line[1]) < 2e-5 and line[4] == "True" and line[5] == "nccl", line
+
+
+def test_cli_two_ranks_shard_the_real_data(tmp_path):
+    """the CLI under data parallelism on real data keys: two ranks (gloo, sharing the one card) each train on their own shard of
+    the dummy task (DistributedSampler), exchange gradients, and end with identical parameters; rank 0 writes the files"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_dummy_task
+    run_dir = make_dummy_task.main(str(tmp_path), 64, 1)
+    port = str(29700 + os.getpid() % 200)
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   MMHIP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-m", "smtc_amd.run_mm_late", "--txt_model_name", "bernice", "--img_model_name", "vit",
+                                       "--fusion_name", "attention", "--task", "2", "--testing", "--use_clip_loss", "--use_tim_loss", "--epochs", "2",
+                                       "--batch_size", "8", "--save_model", "--results_dir", str(tmp_path) + f"/res{rank}/"],
+                                      cwd=run_dir, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][-3000:] + outs[1][-3000:]
+    stem = "testing/bernice-vit-attention_task2_seed30_itc0.1itm0.1_"
+    assert os.path.exists(str(tmp_path) + "/res0/" + stem + "net.pth") and not os.path.exists(str(tmp_path) + "/res1/" + stem + "net.pth")
+    mv = pd.read_csv(str(tmp_path) + "/res0/" + stem + "metrics_val.csv")
+    assert list(mv.columns) == ["metric", "epoch-1", "epoch-2"] and np.isfinite(mv.values[:, 1:].astype(float)).all()
