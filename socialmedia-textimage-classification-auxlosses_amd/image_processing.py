@@ -107,8 +107,10 @@ class RawImageCollate:
         self.proc = processor
 
     def __call__(self, items):
-        from torch.utils.data import default_collate
-        packed, plan, n = self.proc.pack([it["image"] for it in items])
+        from torch.utils.data import default_collate, get_worker_info
+        # inside a DataLoader worker process: no pinned allocation there (it would initialise the GPU runtime in a forked child);
+        # the prefetcher pins on the main process instead
+        packed, plan, n = self.proc.pack([it["image"] for it in items], pin=get_worker_info() is None)
         batch = default_collate([{k: v for k, v in it.items() if k != "image"} for it in items])
         batch["image_packed"], batch["image_plan"], batch["image_count"] = packed, plan, n
         return batch

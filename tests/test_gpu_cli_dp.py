@@ -125,7 +125,7 @@ def test_cli_config0_real_pipeline(tmp_path):
     # three epochs with both auxiliary losses and the image-tower output cache: epochs 2 and 3 take every post from the cache
     r = subprocess.run([sys.executable, "-m", "smtc_amd.run_mm_late", "--txt_model_name", "bernice", "--img_model_name", "vit", "--fusion_name",
                         "attention", "--task", "2", "--testing", "--use_clip_loss", "--use_tim_loss", "--epochs", "3", "--cache_vision", "64",
-                        "--seed", "31"], cwd=run_dir, env=env, capture_output=True, text=True, timeout=600)
+                        "--seed", "31", "--num_workers", "2"], cwd=run_dir, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     mv = pd.read_csv(os.path.join(out, "bernice-vit-attention_task2_seed31_itc0.1itm0.1_metrics_val.csv"))
     assert list(mv.columns) == ["metric", "epoch-1", "epoch-2", "epoch-3"] and np.isfinite(mv.values[:, 1:].astype(float)).all()
