@@ -32,7 +32,21 @@ def _worker(rank, world, port, q):
     part = ref_flat[8:24].clone()
     td.all_reduce(part)
     ref_flat[8:24] = part
-    q.put((rank, float((table - ref_table).abs().max()), float((flat - ref_flat).abs().max())))
+    # ranks with DIFFERENT token counts (each rank trims its batch to its own longest post): fixed number of id slots, the row
+    # flags of include/mmhip.h get bit0 on the rows that arrive from the other rank
+    n2 = 10 + 6 * rank
+    ids2 = torch.randint(0, V, (n2,), generator=g)
+    table2 = torch.zeros(V, H)
+    table2.index_add_(0, ids2, torch.randn(n2, H, generator=g))
+    ref2 = table2.clone()
+    td.all_reduce(ref2)
+    state = torch.zeros(V + 2, dtype=torch.uint8)
+    state[ids2] = 1
+    st = mmdist.sparse_rows_exchange_begin(table2, ids2, capacity=24)
+    mmdist.sparse_rows_exchange_finish(st, table2, state)
+    touched = (ref2.abs().sum(1) > 0)
+    ok_flags = bool(((state[:V] & 1).bool() | ~touched).all())
+    q.put((rank, float((table - ref_table).abs().max()), float(max((flat - ref_flat).abs().max(), (table2 - ref2).abs().max())) + (0.0 if ok_flags else 1.0)))
     td.destroy_process_group()
 
 
