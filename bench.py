@@ -145,7 +145,7 @@ def main():
     if os.path.exists(tfile) and not args.aux and B == 64 and world == 1:
         with open(tfile) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
-    roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (MFMA 16x16x32, LDS-DMA staged; 128x128x64 tiles, role-specialised 256x128 for N<=768 & K>=2048)", "achieved": round(achieved, 1),
+    roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (MFMA 16x16x32, LDS-DMA staged; 128x128x64 tiles, role-specialised 256x128 for N<=768 & K>=2048, 256x96 for the long-K dX GEMMs)", "achieved": round(achieved, 1),
                 "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_gemm_traffic.json)",
                 "algorithmic_flops_per_launch": round(gf.value / max(1, gl.value)),
                 "launches_per_step": int(gl.value // 2), "avg_launch_us": round(gms.value * 1e3 / max(1, gl.value), 2),
