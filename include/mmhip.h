@@ -25,7 +25,10 @@ extern "C" {
 #define MMHIP_E_STATE (-2)     /* call order (not bound, forward not run, ...) */
 #define MMHIP_E_CAPACITY (-3)  /* batch / sequence longer than the handle was created for, or workspace too small */
 
-enum { MMHIP_BF16 = 0, MMHIP_F16 = 1, MMHIP_F32 = 2 };
+/* MMHIP_BF16X3 (as mmhip_config.dtype): the strict-parity mode -- activations stay fp32 in HBM (same value as MMHIP_F32, the
+ * element type the op-level entry points then take) and every Linear runs as three bf16 MFMA products of hi/lo-split
+ * operands (csrc/x3.hip); ~1e-5 on the logits against the fp32 reference, where bf16 gives 5e-3..2e-2 and f16 1e-3..3e-3 */
+enum { MMHIP_BF16 = 0, MMHIP_F16 = 1, MMHIP_F32 = 2, MMHIP_BF16X3 = 2 };
 enum { MMHIP_TXT_BERT = 0, MMHIP_TXT_XLMR = 1 };
 enum { MMHIP_FUSION_CONCAT = 0, MMHIP_FUSION_ATTENTION = 1 };
 /* gradient groups: which parameters receive a gradient for a given flag set */
@@ -40,7 +43,7 @@ typedef struct mmhip_config {
     int image, patch, proj_dim, num_labels;
     int fusion;                          /* MMHIP_FUSION_*  (--fusion_name, models/run_mm_late.py:23) */
     float p_hidden, p_attn, p_head;      /* text hidden / attention-prob dropout, --dropout */
-    int dtype;                           /* MMHIP_BF16 | MMHIP_F16: storage + MFMA operand type of activations */
+    int dtype;                           /* MMHIP_BF16 | MMHIP_F16: storage + MFMA operand type of activations; MMHIP_BF16X3: parity mode */
     int max_posts, max_text_len;         /* capacity: B <= max_posts, T <= max_text_len (ITM doubles the text rows) */
     float loss_scale;                    /* gradient scale inside the 16-bit text tower; 0 = default (1 for bf16, 1024 for f16:
                                             f16 has 5 exponent bits, deep-layer activation gradients ~1e-6 would be subnormal).
@@ -98,8 +101,13 @@ uint64_t mmhip_vision_record_bytes(mmhip_handle h);
 int mmhip_vision_export(mmhip_handle h, const int64_t* slots, void* cache, uint64_t cache_records, void* stream);
 int mmhip_vision_import(mmhip_handle h, const int64_t* slots, const void* cache, uint64_t cache_records, int B, void* stream);
 
-/* ---- loss.backward() (models/mm_late.py:489): gradients of every trainable parameter, ACCUMULATED into train_grad
- * (which must be zero where a fresh gradient is wanted).  Pass NULL pointers to use the gradients mmhip_loss left in
+/* ---- loss.backward() (models/mm_late.py:489): gradients of every trainable parameter, written to train_grad.
+ * CONTRACT: train_grad must be ZERO on entry over the ranges that receive gradients, and holds exactly this call's
+ * gradient on exit.  (The head and embedding kernels add into it -- fp32 `+=` / row atomics, and they set bit0 of the
+ * word-table row flags -- while the text-layer weight / bias gradients are plain stores: calling backward twice without
+ * clearing in between is NOT gradient accumulation; a caller that wants micro-batches sums the flat buffers itself.)
+ * mmhip_adamw / mmhip_adamw_rows with zero_grad = 1 re-establish the entry condition (and clear bit0) as they consume the
+ * gradient; a caller that does not run them clears train_grad and bit0 of the row flags itself.  Pass NULL pointers to use the gradients mmhip_loss left in
  * the handle, or explicit fp32 output gradients (autograd binding).  Stages let a data-parallel caller start the
  * all-reduce of finished parameter ranges while later stages run: stage 0 = heads, 1..layers_txt = text layers
  * last -> first, layers_txt+1 = embeddings.  mmhip_backward runs all of them and the finish.
@@ -139,7 +147,9 @@ int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width
 int mmhip_set_row_state(mmhip_handle h, uint8_t* row_state);
 
 /* ---- timing of the dominant kernel for bench.py: HIP events recorded around every MFMA NT-GEMM launch issued by the
- * handle on its stream while enabled; returns accumulated milliseconds, launches and algorithmic FLOPs since reset. */
+ * handle, on the stream the launch goes to, while enabled; returns accumulated milliseconds, launches and algorithmic FLOPs
+ * since reset.  enable = 1: the engine keeps its internal side streams (the conditions of a normal step: a launch may share
+ * the chip with the other tower / the weight-gradient GEMM); enable = 2: side streams off, every kernel alone on the chip. */
 int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_t* launches, double* flops);
 
 /* ---- input pipeline, image leg: decoded RGB bytes -> pixel_values [n,3,S,S] fp32.

@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMHIP_LIB_PATH") or os.path.join(HERE, "libmmhip.so")      # override: A/B of two builds on one box
 
 BF16, F16, F32 = 0, 1, 2
+BF16X3 = 2          # as an engine dtype: the strict-parity mode (fp32 activations, bf16x3 matrix products; include/mmhip.h)
 TXT_BERT, TXT_XLMR = 0, 1
 FUSION_CONCAT, FUSION_ATTENTION = 0, 1
 G_NEVER, G_ITC, G_ITM, G_FUSION_ATT, G_ALWAYS, G_FROZEN = range(6)

@@ -344,6 +344,7 @@ static hipError_t launch_fwd_d(const AttnArgs& a, hipStream_t s) {
 }
 hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s) {
     if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1) return hipErrorInvalidValue;
+    if (dtype == DT_F32) return launch_attn_fwd_f32(a, s);
     return dtype == DT_BF16 ? launch_fwd_d<bf16_t>(a, s) : launch_fwd_d<f16_t>(a, s);
 }
 template <typename T, int NKT>
@@ -363,6 +364,7 @@ static hipError_t launch_bwd_d(const AttnBwdArgs& a, hipStream_t s) {
 }
 hipError_t launch_attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t s) {
     if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1) return hipErrorInvalidValue;
+    if (dtype == DT_F32) return launch_attn_bwd_f32(a, s);
     return dtype == DT_BF16 ? launch_bwd_d<bf16_t>(a, s) : launch_bwd_d<f16_t>(a, s);
 }
 

@@ -88,7 +88,7 @@ int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, 
                      const float* bias, int act, void* aux_pre, int ldaux, const void* mul_gelu_grad_of, int ldmul,
                      float p_drop, uint64_t seed, uint32_t stream_id, const void* residual, int ldres, int out_f32,
                      int force_slow, void* stream) {
-    if (!A || !B || !C || M < 0 || N < 1 || K < 1 || (dtype != MMHIP_BF16 && dtype != MMHIP_F16)) return MMHIP_E_INVALID;
+    if (!A || !B || !C || M < 0 || N < 1 || K < 1 || (dtype != MMHIP_BF16 && dtype != MMHIP_F16 && dtype != MMHIP_F32)) return MMHIP_E_INVALID;
     GemmNTArgs a;
     memset(&a, 0, sizeof(a));
     a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
@@ -108,7 +108,7 @@ int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, 
 
 int mmhip_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int Nn, int Nc,
                      int accumulate, int force_slow, float* colsum, void* stream) {
-    if (!A || !B || !C || M < 1 || Nn < 1 || Nc < 1 || (dtype != MMHIP_BF16 && dtype != MMHIP_F16)) return MMHIP_E_INVALID;
+    if (!A || !B || !C || M < 1 || Nn < 1 || Nc < 1 || (dtype != MMHIP_BF16 && dtype != MMHIP_F16 && dtype != MMHIP_F32)) return MMHIP_E_INVALID;
     GemmTNProblem p{A, B, C, M, Nn, Nc, lda, ldb, ldc, 0, colsum};
     CHECK_HIP(launch_gemm_tn(&p, 1, accumulate, dtype, force_slow, (hipStream_t)stream));
     return 0;

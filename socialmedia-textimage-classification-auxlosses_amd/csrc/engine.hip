@@ -78,7 +78,7 @@ struct mmhip_engine {
     bool cls_compact = false;  // state of the last forward
     int overlap = -1;          // -1 = read MMHIP_OVERLAP on first use
     // GEMM timing ----------------------------------------------------------------------
-    bool timing = false;
+    int timing = 0;            // 0 off, 1 = events around every NT GEMM with the side streams on, 2 = side streams off
     struct Ev { hipEvent_t a, b; double flops; };
     std::vector<Ev> evs; size_t ev_used = 0;
 
@@ -87,7 +87,7 @@ struct mmhip_engine {
     // f16 activations: gradients inside the text tower are carried multiplied by gscale() (range, not precision) and
     // every fp32 parameter gradient is written multiplied by 1 / gscale(); bf16 needs none
     float gscale() const { return cfg.loss_scale > 0.f ? cfg.loss_scale : (cfg.dtype == MMHIP_F16 ? 1024.f : 1.f); }
-    size_t esz() const { return 2; }
+    size_t esz() const { return cfg.dtype == MMHIP_BF16X3 ? 4 : 2; }
 };
 
 namespace {
@@ -226,34 +226,35 @@ void build_workspace(mmhip_engine& e) {
     const size_t H = c.hidden, I = c.inter, E = c.proj_dim, C = c.num_labels;
     const size_t Bm = c.max_posts, Tm = c.max_text_len, P = (c.image / c.patch) * (c.image / c.patch) + 1;
     const size_t Mt = 2 * Bm * Tm, Mv = Bm * P, Bt = 2 * Bm;
+    const size_t Z = e.esz();      // bytes per activation / GEMM-operand element: 2 (bf16, f16) or 4 (bf16x3 parity mode)
     Carver w;
     auto w16 = [&](std::vector<LayerW16>& v, int n, bool transposed) {
         v.resize(n);
         for (auto& L : v) {
-            L.qkv = w.take(3 * H * H * 2); L.ao = w.take(H * H * 2); L.fc1 = w.take(I * H * 2); L.fc2 = w.take(H * I * 2);
-            if (transposed) { L.qkvT = w.take(3 * H * H * 2); L.aoT = w.take(H * H * 2); L.fc1T = w.take(I * H * 2); L.fc2T = w.take(H * I * 2); }
+            L.qkv = w.take(3 * H * H * Z); L.ao = w.take(H * H * Z); L.fc1 = w.take(I * H * Z); L.fc2 = w.take(H * I * Z);
+            if (transposed) { L.qkvT = w.take(3 * H * H * Z); L.aoT = w.take(H * H * Z); L.fc1T = w.take(I * H * Z); L.fc2T = w.take(H * I * Z); }
         }
     };
     w16(e.vit_w16, c.layers_img, false);
     w16(e.txt_w16, c.layers_txt, true);
-    e.patch_w16 = w.take(H * 3 * c.patch * c.patch * 2);
+    e.patch_w16 = w.take(H * 3 * c.patch * c.patch * Z);
     e.ids_all = w.take(Bt * Tm * 8); e.mask_all = w.take(Bt * Tm * 8); e.pos_ids = w.take(Bt * Tm * 4); e.maskbias = w.take(Bt * Tm * 4);
-    e.x0 = w.take(Mt * H * 2); e.xhat_emb = w.take(Mt * H * 2); e.rstd_emb = w.take(Mt * 4);
+    e.x0 = w.take(Mt * H * Z); e.xhat_emb = w.take(Mt * H * Z); e.rstd_emb = w.take(Mt * 4);
     e.tact.resize(c.layers_txt);
     for (auto& a : e.tact) {
-        a.qkv = w.take(Mt * 3 * H * 2); a.ctx = w.take(Mt * H * 2); a.pre1 = w.take(Mt * H * 2); a.a1 = w.take(Mt * H * 2);
-        a.u = w.take(Mt * I * 2); a.h = w.take(Mt * I * 2); a.pre2 = w.take(Mt * H * 2); a.out = w.take(Mt * H * 2);
+        a.qkv = w.take(Mt * 3 * H * Z); a.ctx = w.take(Mt * H * Z); a.pre1 = w.take(Mt * H * Z); a.a1 = w.take(Mt * H * Z);
+        a.u = w.take(Mt * I * Z); a.h = w.take(Mt * I * Z); a.pre2 = w.take(Mt * H * Z); a.out = w.take(Mt * H * Z);
         a.mean1 = w.take(Mt * 4); a.rstd1 = w.take(Mt * 4); a.mean2 = w.take(Mt * 4); a.rstd2 = w.take(Mt * 4);
         a.lse = w.take(Bt * c.heads * Tm * 4);
     }
-    e.v_patches = w.take(Bm * (P - 1) * 3 * c.patch * c.patch * 2); e.v_pe = w.take(Bm * (P - 1) * H * 2);
-    e.v_x = w.take(Mv * H * 2); e.v_ln = w.take(Mv * H * 2); e.v_qkv = w.take(Mv * 3 * H * 2); e.v_ctx = w.take(Mv * H * 2);
-    e.v_h = w.take(Mv * I * 2); e.v_out = w.take(Mv * H * 2);
-    e.g_dx = w.take(Mt * H * 2); e.g_dx2 = w.take(Mt * H * 2); e.g_dpre = w.take(Mt * H * 2); e.g_ddrop = w.take(Mt * H * 2); e.g_dpre1 = w.take(Mt * H * 2); e.g_ddrop1 = w.take(Mt * H * 2);
-    e.g_dqkv = w.take(Mt * 3 * H * 2); e.g_dctx = w.take(Mt * H * 2); e.g_du = w.take(Mt * I * 2);
+    e.v_patches = w.take(Bm * (P - 1) * 3 * c.patch * c.patch * Z); e.v_pe = w.take(Bm * (P - 1) * H * Z);
+    e.v_x = w.take(Mv * H * Z); e.v_ln = w.take(Mv * H * Z); e.v_qkv = w.take(Mv * 3 * H * Z); e.v_ctx = w.take(Mv * H * Z);
+    e.v_h = w.take(Mv * I * Z); e.v_out = w.take(Mv * H * Z);
+    e.g_dx = w.take(Mt * H * Z); e.g_dx2 = w.take(Mt * H * Z); e.g_dpre = w.take(Mt * H * Z); e.g_ddrop = w.take(Mt * H * Z); e.g_dpre1 = w.take(Mt * H * Z); e.g_ddrop1 = w.take(Mt * H * Z);
+    e.g_dqkv = w.take(Mt * 3 * H * Z); e.g_dctx = w.take(Mt * H * Z); e.g_du = w.take(Mt * I * Z);
     e.g_set[0][0] = e.g_dpre; e.g_set[0][1] = e.g_ddrop; e.g_set[0][2] = e.g_du; e.g_set[0][3] = e.g_dpre1; e.g_set[0][4] = e.g_ddrop1; e.g_set[0][5] = e.g_dqkv;
-    e.g_set[1][0] = w.take(Mt * H * 2); e.g_set[1][1] = w.take(Mt * H * 2); e.g_set[1][2] = w.take(Mt * I * 2);
-    e.g_set[1][3] = w.take(Mt * H * 2); e.g_set[1][4] = w.take(Mt * H * 2); e.g_set[1][5] = w.take(Mt * 3 * H * 2);
+    e.g_set[1][0] = w.take(Mt * H * Z); e.g_set[1][1] = w.take(Mt * H * Z); e.g_set[1][2] = w.take(Mt * I * Z);
+    e.g_set[1][3] = w.take(Mt * H * Z); e.g_set[1][4] = w.take(Mt * H * Z); e.g_set[1][5] = w.take(Mt * 3 * H * Z);
     {
         size_t pf = partial_floats_rows((int)Mt, (int)H, 3), pc = partial_floats_colsum((int)Mt, (int)(3 * H > I ? 3 * H : I));
         const size_t pe = partial_floats_embed((int)Bt, (int)Tm, (int)H);
@@ -350,7 +351,7 @@ int side_init(mmhip_engine& e) {
     for (auto ev : evs) CHECK_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     return 0;
 }
-inline bool use_side(const mmhip_engine& e) { return e.overlap > 0 && e.side && !e.timing; }
+inline bool use_side(const mmhip_engine& e) { return e.overlap > 0 && e.side && e.timing != 2; }
 
 // ------------------------------------------------------------------------------------------------ weights
 int refresh_layer(mmhip_engine& e, const float* base, const LayerOff& o, const LayerW16& w, bool transposed, hipStream_t s) {
@@ -626,9 +627,9 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     if (compact) {
         // d ctx for the CLS rows only, spread into an otherwise-zero full tensor for the attention backward
         { G g(dout, H, e.ws + w.aoT, H, dx2, H, Mr, H, H); if (int r = run_gemm(e, g, s)) return r; }
-        CHECK_HIP(hipMemsetAsync(dctx, 0, (size_t)Mt * H * 2, s));
+        CHECK_HIP(hipMemsetAsync(dctx, 0, (size_t)Mt * H * e.esz(), s));
         CHECK_HIP(launch_scatter_rows16(dx2, dctx, Bt, (size_t)T * H, H, 0, dt, s));
-        CHECK_HIP(hipMemsetAsync(dqkv, 0, (size_t)Mt * 3 * H * 2, s));      // dQ of the skipped query tiles is zero
+        CHECK_HIP(hipMemsetAsync(dqkv, 0, (size_t)Mt * 3 * H * e.esz(), s));      // dQ of the skipped query tiles is zero
     } else {
         G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H);
         g.a.tile = (bt12 & 2) ? nt : 0;
@@ -719,7 +720,7 @@ int mmhip_create(const mmhip_config* cfg, mmhip_handle* out) {
     if (c.image % c.patch || c.patch % 8 || (3 * c.patch * c.patch) % 64) return MMHIP_E_INVALID;
     if ((c.image / c.patch) * (c.image / c.patch) + 1 > 224) return MMHIP_E_INVALID;
     if (c.max_text_len > 128 || c.max_text_len < 1 || c.max_posts < 1 || c.max_posts > 1024) return MMHIP_E_INVALID;
-    if (c.dtype != MMHIP_BF16 && c.dtype != MMHIP_F16) return MMHIP_E_INVALID;
+    if (c.dtype != MMHIP_BF16 && c.dtype != MMHIP_F16 && c.dtype != MMHIP_BF16X3) return MMHIP_E_INVALID;
     if (c.num_labels < 1 || c.num_labels > 64 || c.proj_dim < 1 || c.proj_dim > 1024) return MMHIP_E_INVALID;
     if (c.txt_kind == MMHIP_TXT_XLMR && c.max_pos < c.max_text_len + c.pad_id + 1) return MMHIP_E_INVALID;
     if (c.txt_kind == MMHIP_TXT_BERT && c.max_pos < c.max_text_len) return MMHIP_E_INVALID;
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(256) void vision_copy_kernel(int to_cache, const in
 }
 int vision_copy(mmhip_engine& e, int to_cache, const int64_t* slots, void* cache, uint64_t cache_records, int B, hipStream_t s) {
     const int P = (e.cfg.image / e.cfg.patch) * (e.cfg.image / e.cfg.patch) + 1, H = e.cfg.hidden;
-    const uint32_t tok_bytes = (uint32_t)P * H * 2, pool_bytes = (uint32_t)H * 4;
+    const uint32_t tok_bytes = (uint32_t)(P * H * e.esz()), pool_bytes = (uint32_t)H * 4;
     if (tok_bytes % 16 || pool_bytes % 16) return MMHIP_E_INVALID;
     hipLaunchKernelGGL(vision_copy_kernel, dim3(16, B), dim3(256), 0, s, to_cache, slots, (char*)cache, mmhip_vision_record_bytes(&e), cache_records,
                        e.ws + e.v_out, (char*)e.wsp<float>(e.h_vpool), tok_bytes, pool_bytes);
@@ -851,7 +852,7 @@ int vision_copy(mmhip_engine& e, int to_cache, const int64_t* slots, void* cache
 uint64_t mmhip_vision_record_bytes(mmhip_handle h) {
     if (!h) return 0;
     const uint64_t P = (uint64_t)(h->cfg.image / h->cfg.patch) * (h->cfg.image / h->cfg.patch) + 1;
-    return (P * h->cfg.hidden * 2 + (uint64_t)h->cfg.hidden * 4 + 255) & ~255ull;
+    return (P * h->cfg.hidden * h->esz() + (uint64_t)h->cfg.hidden * 4 + 255) & ~255ull;
 }
 int mmhip_vision_export(mmhip_handle h, const int64_t* slots, void* cache, uint64_t cache_records, void* stream) {
     if (!h || !h->ws || !h->fwd_done) return MMHIP_E_STATE;
@@ -1000,7 +1001,7 @@ int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_
         if (flops) *flops = tf;
     }
     if (reset) e.ev_used = 0;
-    e.timing = enable != 0;
+    e.timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return 0;
 }
 

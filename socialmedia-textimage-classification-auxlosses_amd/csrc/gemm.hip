@@ -9,6 +9,7 @@
 // LDS images are XOR-swizzled on the *source* address (the LDS-DMA destination is lane-linear) and on the read.
 #include "mmhip_common.h"
 #include <cstdlib>
+#include <type_traits>
 #include "mmhip_kernels.h"
 
 namespace mmhip {
@@ -576,6 +577,7 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if (t == 10 && a.N % 96) t = 0;
     if (t == 11 && a.N % 128) t = 0;
     if (t == 12 && a.N % 96) t = 0;
+    if (t >= 13 && t <= 16) return t;
     if (t >= 1 && t <= 12) return t;
     if (a.N % 128 && a.N % 192 == 0 && a.N % 256) { /* only the 192-wide tiles divide N */ }
     // Measured inside the training step (bench.py with MMHIP_NT_TILE forced, profiles/r01_tile_sweep.txt): 128x128 at two
@@ -612,7 +614,12 @@ static int choose_nt_tile(const GemmNTArgs& a) {
 
 template <typename T>
 static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
-    switch (choose_nt_tile(a)) {
+    const int tile = choose_nt_tile(a);
+    if (tile >= 13) {      // 13 / 14: deep-pipelined 256x256 / 256x128, one tile per workgroup; 15 / 16: the same, persistent
+        const int dt = sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16;
+        if (launch_gemm_nt8(a, dt, (tile == 13 || tile == 15) ? 256 : 128, tile >= 15, s)) return;
+    }
+    switch (tile >= 13 ? 1 : tile) {
         case 12: launch_nt_t<T, 256, 96, 4, 2, 3, 4>(a, s); break;    // role-specialised, 256 tiles for 8192 x 768: one tile per CU
         case 11: launch_nt_t<T, 160, 128, 2, 2, 2>(a, s); break;      // 474 tiles for M = 12608 (ViT), N = 768: one round of 512 slots
         case 10: launch_nt_t<T, 128, 96, 2, 2, 2>(a, s); break;       // 512 / 1536 tiles for N = 768 / 2304 at M = 8192: whole rounds
@@ -636,6 +643,7 @@ static bool debug_force_slow() {
 
 hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
+    if (dtype == DT_F32) return launch_gemm_nt_x3(a, s);
     if (nt_fast_ok(a) && !a.force_slow && !debug_force_slow()) {
         if (dtype == DT_BF16) launch_nt_d<bf16_t>(a, s);
         else launch_nt_d<f16_t>(a, s);
@@ -659,6 +667,7 @@ static void launch_tn_t(const GemmTNGroup& g, int tiles, hipStream_t s) {
 // 2 = 128x128 4-stage ring, 3 = 256x128 3-stage ring, 4 = role-specialised 256x128 (8 MFMA + 4 loader waves, 3-stage
 // ring), 5 = role-specialised 128x128 (4 + 4, 4-stage ring); env MMHIP_TN_TILE overrides
 hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha) {
+    if (dtype == DT_F32) return launch_gemm_tn_x3(probs, count, accumulate, s, alpha);
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_TN_TILE"); env = e ? atoi(e) : 0; }
     int variant = (force_slow >> 4) ? (force_slow >> 4) : (env ? env : 4);

@@ -355,14 +355,16 @@ hipError_t launch_fusion_attn_fwd(const FusionAttnArgs& a, int dtype, hipStream_
     if (a.Bt <= 0) return hipSuccess;
     if (a.P > 256 || a.H > 1024 || a.H % 4) return hipErrorInvalidValue;
     if (dtype == DT_BF16) hipLaunchKernelGGL(fusion_attn_fwd_kernel<bf16_t>, dim3(a.Bt), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(fusion_attn_fwd_kernel<f16_t>, dim3(a.Bt), dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(fusion_attn_fwd_kernel<f16_t>, dim3(a.Bt), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(fusion_attn_fwd_kernel<float>, dim3(a.Bt), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_fusion_attn_bwd(const FusionAttnBwdArgs& a, int dtype, hipStream_t s) {
     if (a.Bt <= 0) return hipSuccess;
     if (a.P > 256 || a.H > 1024 || a.H % 4) return hipErrorInvalidValue;
     if (dtype == DT_BF16) hipLaunchKernelGGL(fusion_attn_bwd_kernel<bf16_t>, dim3(a.Bt), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(fusion_attn_bwd_kernel<f16_t>, dim3(a.Bt), dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(fusion_attn_bwd_kernel<f16_t>, dim3(a.Bt), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(fusion_attn_bwd_kernel<float>, dim3(a.Bt), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_itc_fwd(const ItcArgs& a, hipStream_t s) {

@@ -25,6 +25,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 template <typename T> struct Vec;
 template <> struct Vec<bf16_t> { typedef bf16x8 v8; typedef bf16x4 v4; };
 template <> struct Vec<f16_t> { typedef f16x8 v8; typedef f16x4 v4; };
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+template <> struct Vec<float> { typedef f32x8 v8; typedef f32x4 v4; };      // parity mode (bf16x3): activations stay fp32
 
 template <typename T> __device__ __forceinline__ float to_f(T x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f(float x) { return (T)x; }
@@ -86,7 +88,7 @@ __device__ __forceinline__ void mm_keep2(uint32_t e_even, const DropCfg& d, bool
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, i.e. fp32 round-off level)
 __device__ __forceinline__ float mm_erf(float x) {
     float ax = fabsf(x);
-    float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);      // v_rcp_f32 (1 ulp), not the IEEE division sequence
     float y = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     float r = 1.0f - y * __expf(-ax * ax);
     return copysignf(r, x);

@@ -48,7 +48,12 @@ struct SmallGemmArgs {
     int sam, sak, sbk, sbn;   // element strides of A(m,k) and B(k,n); filled by the launch_small_* wrappers
 };
 hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s);
+// deep-pipelined 256 x bn tiles (gemm8.hip); false = shape rules not met, nothing launched
+bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hipStream_t s);
 hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha = 1.0f);
+// parity mode (fp32 activations, three bf16 MFMA products of split operands / fp32 attention): csrc/x3.hip
+hipError_t launch_gemm_nt_x3(const GemmNTArgs& a, hipStream_t s);
+hipError_t launch_gemm_tn_x3(const GemmTNProblem* probs, int count, int accumulate, hipStream_t s, float alpha);
 hipError_t launch_small_nt(const SmallGemmArgs& a, int a_dtype, hipStream_t s);   // out[M,N] = act(A[M,K] W[N,K]^T + b)
 hipError_t launch_small_nn(const SmallGemmArgs& a, hipStream_t s);                // out[M,N] = A[M,K] W[K,N]
 hipError_t launch_small_tn(const SmallGemmArgs& a, int b_dtype, int n_rows, hipStream_t s);  // out[n_rows,N] = A[M,n_rows]^T B[M,N]
@@ -73,6 +78,8 @@ struct AttnBwdArgs {
     int q_tiles;          // > 0: d ctx is zero outside the first q_tiles query tiles; dQ of the other tiles is NOT written
 };
 hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s);
+hipError_t launch_attn_fwd_f32(const AttnArgs& a, hipStream_t s);
+hipError_t launch_attn_bwd_f32(const AttnBwdArgs& a, hipStream_t s);
 hipError_t launch_attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t s);
 
 // ---------------------------------------------------------------- row ops (LayerNorm, embeddings, elementwise)

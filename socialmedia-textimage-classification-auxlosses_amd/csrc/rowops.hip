@@ -643,7 +643,8 @@ hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
     if (a.width % 4 || a.width > 1024 || a.ldx % 4 || a.ldy % 4) return hipErrorInvalidValue;
     if (dtype == DT_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(ln_fwd_kernel<f16_t>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(ln_fwd_kernel<f16_t>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 size_t partial_floats_rows(int rows, int width, int nvec) {   // LN backward may use 3 vectors
@@ -657,7 +658,8 @@ hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s) {
     if (a.width % 4 || a.width > 1024) return hipErrorInvalidValue;
     const int grid = (a.rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
     if (dtype == DT_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, a);
     if (a.partial && !a.defer_reduce) return launch_layernorm_bwd_reduce(a, s);
     return hipGetLastError();
 }
@@ -675,7 +677,8 @@ hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s) {
     hipLaunchKernelGGL(pos_ids_kernel, dim3(a.posts), dim3(64), 0, s, a.ids, a.mask, a.pos_ids, a.maskbias, a.T, a.xlmr, a.pad_id);
     const int grid = (a.posts * a.T + 3) / 4;
     if (dtype == DT_BF16) hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(embed_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(embed_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s) {
@@ -683,7 +686,8 @@ hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s) {
     if (a.H % 4 || a.H > 1024) return hipErrorInvalidValue;
     const dim3 grid(a.T, (a.posts + EMB_POSTS_PER_BLOCK - 1) / EMB_POSTS_PER_BLOCK);
     if (dtype == DT_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(embed_bwd_kernel<f16_t>, grid, dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(embed_bwd_kernel<f16_t>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), 0, s, a);
     if (a.partial) {
         launch_reduce_partials(a.partial, (int)(grid.x * grid.y), a.H, a.dgamma, s, a.alpha == 0.f ? 1.f : a.alpha, a.dbeta, a.dtype);
     }
@@ -694,14 +698,16 @@ hipError_t launch_patchify(const float* pixels, void* out, int B, int img, int p
     if (patch % 8 || img % patch) return hipErrorInvalidValue;
     const size_t total = (size_t)B * (img / patch) * (img / patch) * (3 * patch * patch / 8);
     if (dtype == DT_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(cap_grid(total)), dim3(256), 0, s, pixels, (bf16_t*)out, B, img, patch);
-    else hipLaunchKernelGGL(patchify_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, pixels, (f16_t*)out, B, img, patch);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(patchify_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, pixels, (f16_t*)out, B, img, patch);
+    else hipLaunchKernelGGL(patchify_kernel<float>, dim3(cap_grid(total)), dim3(256), 0, s, pixels, (float*)out, B, img, patch);
     return hipGetLastError();
 }
 hipError_t launch_vit_assemble(const void* patches, const float* cls, const float* pos, void* x, int B, int P, int H, int dtype, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     const size_t total = (size_t)B * P * (H / 4);
     if (dtype == DT_BF16) hipLaunchKernelGGL(vit_assemble_kernel<bf16_t>, dim3(cap_grid(total)), dim3(256), 0, s, (const bf16_t*)patches, cls, pos, (bf16_t*)x, B, P, H);
-    else hipLaunchKernelGGL(vit_assemble_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, (const f16_t*)patches, cls, pos, (f16_t*)x, B, P, H);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(vit_assemble_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, (const f16_t*)patches, cls, pos, (f16_t*)x, B, P, H);
+    else hipLaunchKernelGGL(vit_assemble_kernel<float>, dim3(cap_grid(total)), dim3(256), 0, s, (const float*)patches, cls, pos, (float*)x, B, P, H);
     return hipGetLastError();
 }
 hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s, float* partial, float alpha) {
@@ -709,21 +715,24 @@ hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, 
     if (cols % 4 || ld % 4) return hipErrorInvalidValue;
     dim3 grid((cols + 255) / 256, (rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
     if (dtype == DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, cols, ld, out, partial, alpha);
-    else hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, rows, cols, ld, out, partial, alpha);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, rows, cols, ld, out, partial, alpha);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, rows, cols, ld, out, partial, alpha);
     if (partial) launch_reduce_partials(partial, (int)grid.y, cols, out, s, alpha);
     return hipGetLastError();
 }
 hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s) {
     if (!n) return hipSuccess;
     if (dtype == DT_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(cap_grid(n / 4 + 1)), dim3(256), 0, s, src, (bf16_t*)dst, n);
-    else hipLaunchKernelGGL(cast_kernel<f16_t>, dim3(cap_grid(n / 4 + 1)), dim3(256), 0, s, src, (f16_t*)dst, n);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(cast_kernel<f16_t>, dim3(cap_grid(n / 4 + 1)), dim3(256), 0, s, src, (f16_t*)dst, n);
+    else hipLaunchKernelGGL(cast_kernel<float>, dim3(cap_grid(n / 4 + 1)), dim3(256), 0, s, src, (float*)dst, n);
     return hipGetLastError();
 }
 hipError_t launch_cast_transpose(const float* src, void* dst, int rows, int cols, int dtype, hipStream_t s) {
     if (rows <= 0 || cols <= 0) return hipSuccess;
     dim3 grid((cols + 63) / 64, (rows + 63) / 64);
     if (dtype == DT_BF16) hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, rows, cols);
-    else hipLaunchKernelGGL(cast_transpose_kernel<f16_t>, grid, dim3(256), 0, s, src, (f16_t*)dst, rows, cols);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(cast_transpose_kernel<f16_t>, grid, dim3(256), 0, s, src, (f16_t*)dst, rows, cols);
+    else hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, rows, cols);
     return hipGetLastError();
 }
 hipError_t launch_cast_group(const CastMat* mats, int count, int dtype, hipStream_t s) {
@@ -739,35 +748,40 @@ hipError_t launch_cast_group(const CastMat* mats, int count, int dtype, hipStrea
     }
     if (!tiles) return hipSuccess;
     if (dtype == DT_BF16) hipLaunchKernelGGL(cast_dual_kernel<bf16_t>, dim3(tiles), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(cast_dual_kernel<f16_t>, dim3(tiles), dim3(256), 0, s, g);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(cast_dual_kernel<f16_t>, dim3(tiles), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(cast_dual_kernel<float>, dim3(tiles), dim3(256), 0, s, g);
     return hipGetLastError();
 }
 hipError_t launch_scatter_rows16(const void* src, void* dst, int rows, size_t dst_stride, int H, int add, int dtype, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (H % 4 || dst_stride % 4) return hipErrorInvalidValue;
     if (dtype == DT_BF16) hipLaunchKernelGGL(scatter_rows16_kernel<bf16_t>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, rows, dst_stride, H, add);
-    else hipLaunchKernelGGL(scatter_rows16_kernel<f16_t>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const f16_t*)src, (f16_t*)dst, rows, dst_stride, H, add);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(scatter_rows16_kernel<f16_t>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const f16_t*)src, (f16_t*)dst, rows, dst_stride, H, add);
+    else hipLaunchKernelGGL(scatter_rows16_kernel<float>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const float*)src, (float*)dst, rows, dst_stride, H, add);
     return hipGetLastError();
 }
 hipError_t launch_dropout16(const void* src, void* dst, size_t n, const DropCfg& d, int dtype, hipStream_t s) {
     if (!n) return hipSuccess;
     if (n % 4) return hipErrorInvalidValue;
     if (dtype == DT_BF16) hipLaunchKernelGGL(dropout16_kernel<bf16_t>, dim3(cap_grid(n / 4)), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n, d);
-    else hipLaunchKernelGGL(dropout16_kernel<f16_t>, dim3(cap_grid(n / 4)), dim3(256), 0, s, (const f16_t*)src, (f16_t*)dst, n, d);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(dropout16_kernel<f16_t>, dim3(cap_grid(n / 4)), dim3(256), 0, s, (const f16_t*)src, (f16_t*)dst, n, d);
+    else hipLaunchKernelGGL(dropout16_kernel<float>, dim3(cap_grid(n / 4)), dim3(256), 0, s, (const float*)src, (float*)dst, n, d);
     return hipGetLastError();
 }
 hipError_t launch_gather_rows_f32(const void* src, size_t src_stride, float* out, int ldo, int rows, int H, int dtype, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (H % 4 || ldo % 4) return hipErrorInvalidValue;
     if (dtype == DT_BF16) hipLaunchKernelGGL(gather_rows_f32_kernel<bf16_t>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const bf16_t*)src, src_stride, out, ldo, rows, H);
-    else hipLaunchKernelGGL(gather_rows_f32_kernel<f16_t>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const f16_t*)src, src_stride, out, ldo, rows, H);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(gather_rows_f32_kernel<f16_t>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const f16_t*)src, src_stride, out, ldo, rows, H);
+    else hipLaunchKernelGGL(gather_rows_f32_kernel<float>, dim3(cap_grid((size_t)rows * H / 4)), dim3(256), 0, s, (const float*)src, src_stride, out, ldo, rows, H);
     return hipGetLastError();
 }
 hipError_t launch_scatter_cls_rows(const float* d, void* dx, int posts, int T, int H, int dtype, hipStream_t s, float scale) {
     if (posts <= 0) return hipSuccess;
     const size_t total = (size_t)posts * T * (H / 4);
     if (dtype == DT_BF16) hipLaunchKernelGGL(scatter_cls_kernel<bf16_t>, dim3(cap_grid(total)), dim3(256), 0, s, d, (bf16_t*)dx, posts, T, H, scale);
-    else hipLaunchKernelGGL(scatter_cls_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, d, (f16_t*)dx, posts, T, H, scale);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(scatter_cls_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, d, (f16_t*)dx, posts, T, H, scale);
+    else hipLaunchKernelGGL(scatter_cls_kernel<float>, dim3(cap_grid(total)), dim3(256), 0, s, d, (float*)dx, posts, T, H, scale);
     return hipGetLastError();
 }
 

@@ -71,19 +71,21 @@ def sparse_rows_exchange_begin(table_grad, ids, capacity=None):
 
 
 def sparse_rows_exchange_finish(state, table_grad, row_state=None):
-    """adds the other ranks' rows: afterwards table_grad holds the sum over ranks.  `row_state` (uint8 per row,
-    include/mmhip.h: mmhip_adamw_rows) gets bit0 set on the rows received."""
+    """afterwards table_grad holds the sum over ranks, BIT-IDENTICAL on every rank: the local rows named in this rank's id
+    list are cleared and every rank's payload -- the own one included -- is added in rank order 0..W-1, so each row is the
+    same fp32 sum ((0 + g_0) + g_1) + ... everywhere (with "own rows first" three or more ranks would round differently and
+    the replicas would drift apart; nothing re-synchronises parameters).  `row_state` (uint8 per row, include/mmhip.h:
+    mmhip_adamw_rows) gets bit0 set on the rows received."""
     if state is None:
         return
-    ids_all, pay_all, works, _keep = state
+    ids_all, pay_all, works, (own_ids, _own_payload) = state
     for w in works:
         w.wait()
-    me = rank()
+    table_grad.index_fill_(0, own_ids, 0.0)
     for r in range(len(ids_all)):
-        if r != me:
-            table_grad.index_add_(0, ids_all[r], pay_all[r])
-            if row_state is not None:
-                row_state[ids_all[r]] = row_state[ids_all[r]] | 1
+        table_grad.index_add_(0, ids_all[r], pay_all[r])
+        if row_state is not None:
+            row_state[ids_all[r]] = row_state[ids_all[r]] | 1
 
 
 def sparse_rows_exchange(table_grad, ids, row_state=None):
@@ -91,26 +93,64 @@ def sparse_rows_exchange(table_grad, ids, row_state=None):
     sparse_rows_exchange_finish(sparse_rows_exchange_begin(table_grad, ids), table_grad, row_state)
 
 
-def exchange_stage(model, stage, n_stage, use_itc, use_itm, finishers=None):
+BUCKET_BYTES = int(os.environ.get("MMHIP_BUCKET_MB", "48")) << 20
+
+
+class StageBuckets:
+    """merges the per-stage gradient ranges of one backward pass into all-reduces of >= BUCKET_BYTES: xGMI is
+    point-to-point, a ring all-reduce is bound per link, so a few large collectives beat fourteen 28 MB ones.  Stage ranges
+    are adjacent in address order (the flat layout follows the backward order), so a bucket is one slice."""
+
+    def __init__(self, flat_grad):
+        self.flat, self.begin, self.end, self.works, self.bytes = flat_grad, None, None, [], 0
+
+    def add(self, b, e, flush=False):
+        if e > b:
+            if self.begin is not None and b != self.end:
+                self.flush()                                   # not adjacent: close the open bucket first
+            if self.begin is None:
+                self.begin = b
+            self.end = e
+        if self.begin is not None and (flush or (self.end - self.begin) * 4 >= BUCKET_BYTES):
+            self.flush()
+
+    def flush(self):
+        if self.begin is not None and self.end > self.begin:
+            self.works.append(allreduce_range(self.flat, self.begin, self.end))
+            self.bytes += (self.end - self.begin) * 4
+        self.begin = self.end = None
+
+
+def exchange_stage(model, stage, n_stage, use_itc, use_itm, finishers=None, buckets=None):
     """called right after backward stage `stage` was enqueued; returns async Work handles to wait on before AdamW.  With a
     `finishers` list the word-table exchange of the last stage is only started here: the caller runs the appended callable
-    after the dense AdamW, so the all_gather travels while the dense parameters are being updated."""
+    after the dense AdamW, so the all_gather travels while the dense parameters are being updated.  With `buckets`
+    (StageBuckets) the dense ranges are merged into large all-reduces; its Work handles are in buckets.works."""
     works = []
     b, e = model._stage_ranges[stage]
     if stage < n_stage - 1:
+        if buckets is not None:
+            buckets.add(b, e)
+            return works
         w = allreduce_range(model._flat_grad, b, e)
         if w is not None:
             works.append(w)
         return works
     # embeddings: [LayerNorm, type, position] dense; word table sparse
     word = next(i for i in model._train_params if i["name"].endswith("word_embeddings.weight"))
-    w = allreduce_range(model._flat_grad, b, word["offset"])
-    if w is not None:
-        works.append(w)
+    if buckets is not None:
+        buckets.add(b, word["offset"], flush=True)
+    else:
+        w = allreduce_range(model._flat_grad, b, word["offset"])
+        if w is not None:
+            works.append(w)
     V, H = word["shape"]
     table = model._flat_grad[word["offset"]: word["offset"] + V * H].view(V, H)
     cap_b, cap_t = model._capacity                              # the same on every rank (constructor arguments), unlike B*T of a trimmed batch
-    state = sparse_rows_exchange_begin(table, model._last["ids_all"], cap_b * cap_t * (2 if model._last["itm"] else 1))
+    # every ITM row is a copy of a row of `ids` (reference models/mm_late.py:389-414): the distinct word rows of the 2B-post
+    # text pass are those of the B original posts, so the id list (and the payload) is B*T slots, not 2*B*T
+    state = sparse_rows_exchange_begin(table, model._last["ids"], cap_b * cap_t)
+    model._last["exchange_bytes"] = (buckets.bytes if buckets is not None else 0) + cap_b * cap_t * (H * 4 + 8)
     finish = lambda: sparse_rows_exchange_finish(state, table, getattr(model, "_word_row_state", None))
     if finishers is None:
         finish()

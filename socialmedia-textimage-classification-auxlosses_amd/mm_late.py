@@ -106,7 +106,7 @@ class MM_Model(nn.Module):
     """reference models/mm_late.py:50-193.
 
     MM_Model(num_labels, txt_model_name, img_model_name, dropout, fusion_name='concat'); keyword-only extras are
-    additive: `arch` overrides (layer counts, vocab ... for tests), `dtype` ('bf16' | 'f16'), `max_posts` /
+    additive: `arch` overrides (layer counts, vocab ... for tests), `dtype` ('bf16' | 'f16' | 'bf16x3' = strict-parity mode), `max_posts` /
     `max_text_len` (capacity the workspace is sized for), `device`, `seed`.
     Weights: loaded from the local directories of config.MODEL_DIR_DICT when they exist (HF layout), else random
     init at the architecture's true shapes (no network in this environment).
@@ -144,7 +144,7 @@ class MM_Model(nn.Module):
                             proj_dim=a["proj_dim"], num_labels=num_labels,
                             fusion=_lib.FUSION_ATTENTION if fusion_name == "attention" else _lib.FUSION_CONCAT,
                             p_hidden=a["p_hidden"], p_attn=a["p_attn"], p_head=float(dropout),
-                            dtype={"bf16": _lib.BF16, "f16": _lib.F16}[dtype])
+                            dtype={"bf16": _lib.BF16, "f16": _lib.F16, "bf16x3": _lib.BF16X3}[dtype])
         self._handle = None
         self._capacity = (0, 0)
         self._fwd_token = 0
@@ -332,7 +332,7 @@ class MM_Model(nn.Module):
                                             B, T, int(self.training), seed, _lib.ptr(out_cls), _lib.ptr(lpt), _lib.ptr(out_tim),
                                             _lib.ptr(feats), _lib.stream_ptr()), "forward")
         self._fwd_token += 1
-        self._last = dict(B=B, T=T, itm=tim_ids is not None, seed=seed, ids_all=ids if tim_ids is None else torch.cat([ids, tim_ids]))
+        self._last = dict(B=B, T=T, itm=tim_ids is not None, seed=seed, ids=ids)
         if vc is not None and not cached:
             slots, slots_dev = self._vision_slots(vision_keys, assign=True)         # posts beyond the capacity stay uncached (-1)
             _lib.check(_lib.lib().mmhip_vision_export(self._handle, _lib.ptr(slots_dev), _lib.ptr(vc["buf"]), vc["cap"], _lib.stream_ptr()),
@@ -378,6 +378,10 @@ class MM_Model(nn.Module):
                 out.append(self._flat_grad[inf["offset"]: inf["offset"] + inf["numel"]].view(inf["shape"]).clone())
             else:
                 out.append(None)
+        # leave the entry condition of include/mmhip.h's backward contract behind (the fused step relies on it): no stale
+        # gradients, no stale "row has a gradient" flags
+        self._flat_grad.zero_()
+        self._word_row_state.bitwise_and_(0xFE)
         return out
 
     # ------------------------------------------------------------------ reference interface
@@ -480,18 +484,21 @@ class MMLate_Model(object):
         _lib.check(lib.mmhip_backward_begin(m._handle, None, None, None, None, s), "backward_begin")
         works = []
         exchange = self.world > 1 or mmdist.force_exchange()
+        buckets = mmdist.StageBuckets(m._flat_grad) if exchange else None
         n_stage = len(m._stage_ranges)
         for st in range(n_stage):
             _lib.check(lib.mmhip_backward_stage(m._handle, st, s), "backward_stage")
             if exchange and st >= 1:
                 # stage st-1's parameter gradients may still be running on the engine's side stream: join them into this
-                # stream, then hand the range to RCCL (which orders itself after this stream) while stage st+1 computes
+                # stream, then hand the range to RCCL (which orders itself after this stream) while stage st+1 computes;
+                # ranges are merged into >= 48 MB buckets (dist.StageBuckets)
                 _lib.check(lib.mmhip_backward_join_stage(m._handle, st - 1, s), "backward_join_stage")
-                works += mmdist.exchange_stage(m, st - 1, n_stage, self.use_clip_loss, self.use_tim_loss)
+                works += mmdist.exchange_stage(m, st - 1, n_stage, self.use_clip_loss, self.use_tim_loss, buckets=buckets)
         _lib.check(lib.mmhip_backward_finish(m._handle, s), "backward_finish")
         finishers = []
         if exchange:
-            works += mmdist.exchange_stage(m, n_stage - 1, n_stage, self.use_clip_loss, self.use_tim_loss, finishers)
+            works += mmdist.exchange_stage(m, n_stage - 1, n_stage, self.use_clip_loss, self.use_tim_loss, finishers, buckets=buckets)
+            works += buckets.works
         for w in works:
             w.wait()
         self._adamw(lr, weight_decay, step, rows=False)        # dense ranges first: the word-table rows are still travelling

@@ -7,7 +7,7 @@ import torch
 import smtc_amd  # noqa: F401
 from smtc_amd import _lib
 
-DT = {"bf16": (_lib.BF16, torch.bfloat16), "f16": (_lib.F16, torch.float16)}
+DT = {"bf16": (_lib.BF16, torch.bfloat16), "f16": (_lib.F16, torch.float16), "x3": (_lib.F32, torch.float32)}
 
 
 def dev():

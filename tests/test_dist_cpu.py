@@ -1,4 +1,4 @@
-"""CPU, gloo, world_size 2: the data-parallel exchange primitives (dense range all-reduce, row-sparse embedding
+"""CPU, gloo, world_size 2 and 3: the data-parallel exchange primitives (dense range all-reduce, row-sparse embedding
 exchange) against the dense sum they must equal."""
 import os
 
@@ -44,17 +44,38 @@ def _worker(rank, world, port, q):
     state[ids2] = 1
     st = mmdist.sparse_rows_exchange_begin(table2, ids2, capacity=24)
     mmdist.sparse_rows_exchange_finish(st, table2, state)
+    # replicas must stay BIT-identical (nothing re-synchronises parameters): every rank's summed table equals rank 0's,
+    # which "own rows first, then the others" does not give for three or more ranks (fp32 sums do not associate)
+    same = True
+    for tab in (table, table2):
+        gathered = [torch.empty_like(tab) for _ in range(world)]
+        td.all_gather(gathered, tab)
+        same = same and all(torch.equal(gathered[0], g_) for g_ in gathered[1:])
+    # the merged stage buckets equal per-range all-reduces
+    flat2 = torch.randn(64, generator=torch.Generator().manual_seed(7 + rank))
+    ref3 = flat2.clone()
+    td.all_reduce(ref3)
+    old = mmdist.BUCKET_BYTES
+    mmdist.BUCKET_BYTES = 64                     # 16 floats per bucket
+    bk = mmdist.StageBuckets(flat2)
+    for b_, e_ in ((0, 8), (8, 20), (20, 20), (20, 30), (30, 64)):
+        bk.add(b_, e_, flush=(e_ == 64))
+    for w_ in bk.works:
+        w_.wait()
+    mmdist.BUCKET_BYTES = old
+    same = same and bool((flat2 - ref3).abs().max() < 1e-5) and bk.bytes == 64 * 4 and len(bk.works) == 2
     touched = (ref2.abs().sum(1) > 0)
     ok_flags = bool(((state[:V] & 1).bool() | ~touched).all())
-    q.put((rank, float((table - ref_table).abs().max()), float(max((flat - ref_flat).abs().max(), (table2 - ref2).abs().max())) + (0.0 if ok_flags else 1.0)))
+    q.put((rank, float((table - ref_table).abs().max()), float(max((flat - ref_flat).abs().max(), (table2 - ref2).abs().max())) + (0.0 if ok_flags else 1.0) + (0.0 if same else 2.0)))
     td.destroy_process_group()
 
 
-def test_exchange_equals_dense_allreduce():
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_equals_dense_allreduce(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + 7 * world) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

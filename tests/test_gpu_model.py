@@ -24,13 +24,15 @@ if torch.cuda.is_available():
     from gpu_util import rel_err
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TOL_OUT = {"bf16": 2.5e-2, "f16": 3e-3}
-TOL_LOSS = {"bf16": 1e-3, "f16": 1e-3}
+# "bf16x3" is the strict-parity mode (fp32 activations, every Linear as three bf16 MFMA products of hi/lo-split operands,
+# fp32 attention): the mode in which north_star's 1e-3 on the per-post outputs is asserted.
+TOL_OUT = {"bf16": 2.5e-2, "f16": 3e-3, "bf16x3": 1e-3}
+TOL_LOSS = {"bf16": 1e-3, "f16": 1e-3, "bf16x3": 1e-4}
 # gradients: relative L2 error of the compared slice / tensor.  Measured on MI355X: attention q/k weight gradients (a
 # difference of soft-max-weighted terms) are the noisiest at 9e-2 (bf16) / 1.4e-2 (f16): the 6.5x ratio between the two
 # dtypes is the mantissa ratio, i.e. rounding noise -- a logic error would not depend on the dtype.  fc_Q / fc_K (soft-max
 # over 197 near-uniform image-token scores: dS is a difference of nearly equal terms) reach 0.2 in bf16, 0.02 in f16.
-TOL_GRAD = {"bf16": 0.35, "f16": 0.05}
+TOL_GRAD = {"bf16": 0.35, "f16": 0.05, "bf16x3": 2e-2}
 
 
 def load(name):
@@ -55,7 +57,7 @@ def load_oracle_params(model, P):
     assert unexpected == [] and missing == ["dual_encoder.text_model.embeddings.position_ids"]
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "bf16x3"])
 @pytest.mark.parametrize("name,txt", [("fwd_small_xlmr", "bernice"), ("fwd_small_bert", "bert"), ("fwd_small_concat", "bernice"),
                                       ("fwd_full_xlmr", "bernice")])
 def test_forward_matches_reference_golden(name, txt, dtype):
@@ -74,7 +76,7 @@ def test_forward_matches_reference_golden(name, txt, dtype):
         assert e < TOL_OUT[dtype], (k, e)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "bf16x3"])
 @pytest.mark.parametrize("path", ["fused", "autograd"])
 def test_train_losses_and_grads_match_reference_golden(dtype, path):
     """train() mode, dropout p = 0: the three loss mixes and gradients of the watched parameters"""
@@ -136,7 +138,7 @@ def test_train_losses_and_grads_match_reference_golden(dtype, path):
             assert e < TOL_GRAD[dtype], (mix, k, e)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "bf16x3"])
 def test_dropout_train_step_matches_oracle_with_replayed_masks(dtype):
     """dropout ON: the oracle replays the kernels' counter-based masks (same hash), so loss and gradients must agree"""
     cfg = O.OracleConfig(layers_txt=2, layers_img=1, vocab=500, max_pos=130, num_labels=3)
