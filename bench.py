@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--aux", action="store_true", help="BASELINE config 3: ITC + ITM auxiliary losses")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "bf16x3"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--txt_model_name", default="bernice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,27 +129,54 @@ def main():
     torch.cuda.synchronize()
     fb_ms = (time.perf_counter() - t1) / nfb * 1e3
     m._flat_grad.zero_()
+    m._word_row_state.bitwise_and_(0xFE)        # include/mmhip.h backward contract: no stale row flags into the next fused step
 
-    # ---- roofline of the dominant kernel (MFMA NT GEMM): HIP events around every launch, on the launch stream
+    # ---- roofline of the dominant kernel (MFMA NT GEMM): HIP events around every launch, on the stream it is launched on.
+    # Two passes: side streams ON (the conditions of the timed step: a launch may share the chip with the other tower or with
+    # the weight-gradient GEMM -- this is `frac`) and side streams OFF (every kernel alone on the chip: `frac_serial`).
     import ctypes as Ct
-    _lib.check(lib.mmhip_gemm_timing(m._handle, 1, 1, None, None, None))
-    for _ in range(2):
-        step_no += 1
-        trainer.train_step(ids, mask, pixels, onehot, None, lr, wd, step_no)
-    gms, gl, gf = Ct.c_double(), Ct.c_uint64(), Ct.c_double()
-    _lib.check(lib.mmhip_gemm_timing(m._handle, 0, 1, Ct.byref(gms), Ct.byref(gl), Ct.byref(gf)))
-    achieved = gf.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
-    # HBM bytes per launch of that kernel: PMC passes of this very command (FETCH_SIZE x2 per the gfx950 correction and
-    # WRITE_SIZE, collected in separate rocprofv3 --pmc runs; profiles/README.md) -- bench.py cannot run the profiler itself
-    traffic, tfile = None, os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-    if os.path.exists(tfile) and not args.aux and B == 64 and world == 1:
-        with open(tfile) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
-    roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (MFMA 16x16x32, LDS-DMA staged; 128x128x64 tiles, role-specialised 256x128 for N<=768 & K>=2048, 256x96 for the long-K dX GEMMs)", "achieved": round(achieved, 1),
-                "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_gemm_traffic.json)",
-                "algorithmic_flops_per_launch": round(gf.value / max(1, gl.value)),
-                "launches_per_step": int(gl.value // 2), "avg_launch_us": round(gms.value * 1e3 / max(1, gl.value), 2),
-                "gemm_ms_per_step": round(gms.value / 2, 3)}
+
+    def gemm_pass(mode):
+        nonlocal step_no
+        _lib.check(lib.mmhip_gemm_timing(m._handle, mode, 1, None, None, None))
+        for _ in range(2):
+            step_no += 1
+            trainer.train_step(ids, mask, pixels, onehot, None, lr, wd, step_no)
+        gms, gl, gf = Ct.c_double(), Ct.c_uint64(), Ct.c_double()
+        _lib.check(lib.mmhip_gemm_timing(m._handle, 0, 1, Ct.byref(gms), Ct.byref(gl), Ct.byref(gf)))
+        tf = gf.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
+        return tf, gms.value, int(gl.value), gf.value
+
+    achieved, gms, gl, gf = gemm_pass(1)
+    serial_tf, gms_serial, _, _ = gemm_pass(2)
+    # HBM bytes per launch of that kernel come from PMC passes of this very command (FETCH_SIZE x2 per the gfx950 correction and
+    # WRITE_SIZE, separate rocprofv3 --pmc runs, tools/pmc_traffic.py): bench.py cannot run the profiler on itself, so the
+    # number is taken from the committed profile ONLY when that profile was collected on the kernel sources of this build
+    # (sha256 over csrc/*.hip, *.h); otherwise it is null
+    traffic, traffic_src = None, None
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "socialmedia-textimage-classification-auxlosses_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, fn), "rb") as f:
+                h.update(f.read())
+    src_hash = h.hexdigest()[:16]
+    for tfile in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_gemm_traffic.json")), reverse=True):
+        with open(os.path.join(ROOT, "profiles", tfile)) as f:
+            tj = json.load(f)
+        if tj.get("csrc_sha256_16") == src_hash and not args.aux and B == 64 and world == 1 and tj.get("dtype", "bf16") == args.dtype:
+            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/" + tfile
+            break
+    roofline = {"bound": "mfma", "kernel": "NT GEMM family (gemm_nt_kernel / gemm_nt8_kernel, MFMA 16x16x32, LDS-DMA staged)",
+                "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4),
+                "conditions": "HIP events around every NT launch on its own stream, side streams on (as in the timed step)",
+                "achieved_serial": round(serial_tf, 1), "frac_serial": round(serial_tf / PEAK_TFLOPS, 4),
+                "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                "csrc_sha256_16": src_hash,
+                "algorithmic_flops_per_launch": round(gf / max(1, gl)),
+                "launches_per_step": gl // 2, "avg_launch_us": round(gms * 1e3 / max(1, gl), 2),
+                "gemm_ms_per_step": round(gms / 2, 3), "gemm_ms_per_step_serial": round(gms_serial / 2, 3)}
     mode = "aux" if args.aux else "plain"
     out = {
         "metric": "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion, bs=64",

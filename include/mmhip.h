@@ -146,6 +146,20 @@ int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width
 /* register (or with NULL remove) the word-table row flags the backward pass maintains */
 int mmhip_set_row_state(mmhip_handle h, uint8_t* row_state);
 
+/* ---- one whole training step of MMLate_Model.train (models/mm_late.py:452-491: zero_grad, forward, loss mix, backward,
+ * optimizer.step) in ONE call: mmhip_forward(train) + mmhip_loss + mmhip_backward + AdamW over exactly the parameter ranges
+ * that receive a gradient for this flag set (torch.optim.AdamW skips `grad is None` tensors: never-used heads always; the ITC
+ * group unless use_itc; linear_tim unless use_itm; the fusion-attention group for 'concat') + mmhip_refresh_weights(train).
+ * adam_m / adam_v: the caller's moment buffers, laid out like the trainable flat buffer (zero before the first step; the
+ * word-table row flags of mmhip_set_row_state must then have bit1 clear).  loss[4] / n_correct as in mmhip_loss.  Everything
+ * is enqueued on `stream`; the host returns without waiting.  Single-rank form: a data-parallel caller that exchanges
+ * gradients between backward and the optimizer uses the staged calls above. */
+int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
+                     const int64_t* tim_mask, const int64_t* lbl_tim, const int64_t* onehot, const float* class_w, int B, int T,
+                     uint64_t seed, int use_itc, int use_itm, float w_cls, float w_itc, float w_itm, float* adam_m, float* adam_v,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, float* loss,
+                     int* n_correct, void* stream);
+
 /* ---- timing of the dominant kernel for bench.py: HIP events recorded around every MFMA NT-GEMM launch issued by the
  * handle, on the stream the launch goes to, while enabled; returns accumulated milliseconds, launches and algorithmic FLOPs
  * since reset.  enable = 1: the engine keeps its internal side streams (the conditions of a normal step: a launch may share

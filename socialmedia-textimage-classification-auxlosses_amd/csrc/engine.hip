@@ -985,6 +985,51 @@ int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width
     return 0;
 }
 
+// One fused training step, enqueued natively (no per-stage host round trips): forward (train mode) -> loss -> backward ->
+// AdamW over the ranges that receive gradients for this flag set (torch skips `grad is None` tensors) ->
+// 16-bit weight refresh.  Single-rank form of MMLate_Model.train_step; a data-parallel caller keeps the staged calls.
+int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
+                     const int64_t* tim_mask, const int64_t* lbl_tim, const int64_t* onehot, const float* class_w, int B, int T,
+                     uint64_t seed, int use_itc, int use_itm, float w_cls, float w_itc, float w_itm, float* adam_m, float* adam_v,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, float* loss,
+                     int* n_correct, void* stream) {
+    if (!h || !h->ws || !h->grad) return MMHIP_E_STATE;
+    if (!adam_m || !adam_v || !onehot || step < 1) return MMHIP_E_INVALID;
+    if (use_itm && (!tim_ids || !lbl_tim)) return MMHIP_E_INVALID;
+    mmhip_engine& e = *h;
+    if (int r = mmhip_forward(h, ids, mask, pixels, use_itm ? tim_ids : nullptr, use_itm ? tim_mask : nullptr, B, T, 1, seed, nullptr, nullptr,
+                              nullptr, nullptr, stream)) return r;
+    if (int r = mmhip_loss(h, onehot, class_w, use_itm ? lbl_tim : nullptr, w_cls, use_itc ? w_itc : 0.f, use_itm ? w_itm : 0.f, loss, n_correct, stream)) return r;
+    if (int r = mmhip_backward(h, nullptr, nullptr, nullptr, nullptr, stream)) return r;
+    // merged [begin, end) ranges of the active gradient groups, in address order
+    bool act[6] = {false, use_itc != 0, use_itm != 0, e.cfg.fusion == MMHIP_FUSION_ATTENTION, true, false};
+    const uint64_t w0 = e.t_word, V = (uint64_t)e.cfg.vocab, H = (uint64_t)e.cfg.hidden;
+    uint64_t rb = 0, re = 0;
+    bool open = false;
+    auto flush = [&]() -> int {
+        if (!open || re <= rb) return 0;
+        const uint64_t dense_end = re < w0 ? re : w0;
+        if (dense_end > rb)
+            if (int r = mmhip_adamw(e.train + rb, e.grad + rb, adam_m + rb, adam_v + rb, dense_end - rb, lr, beta1, beta2, eps, weight_decay, step,
+                                    grad_scale, 1, stream)) return r;
+        if (re > w0) {
+            if (!e.word_row_state) return MMHIP_E_STATE;
+            if (int r = mmhip_adamw_rows(e.train + w0, e.grad + w0, adam_m + w0, adam_v + w0, (int)V, (int)H, e.word_row_state, lr, beta1, beta2, eps,
+                                         weight_decay, step, grad_scale, 1, stream)) return r;
+        }
+        return 0;
+    };
+    for (const auto& p : e.params) {
+        if (p.buffer != 1 || !act[p.group]) continue;
+        const uint64_t b = p.offset, en = p.offset + ((p.numel + 3) & ~(uint64_t)3);
+        if (open && b == re) { re = en; continue; }
+        if (int r = flush()) return r;
+        rb = b; re = en; open = true;
+    }
+    if (int r = flush()) return r;
+    return mmhip_refresh_weights(h, 2, stream);
+}
+
 int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_t* launches, double* flops) {
     if (!h) return MMHIP_E_INVALID;
     mmhip_engine& e = *h;

@@ -473,17 +473,21 @@ class MMLate_Model(object):
         tim_ids, tim_mask, lbl_tim = tim if tim is not None else (None, None, None)
         if not m.training:
             m.train()                              # walks ~370 submodules (1.3 ms of host time): only on a mode change
-        m._engine_forward(ids, mask, pixel_values, tim_ids, tim_mask, vision_keys=vision_keys)
         w_cls, w_itc, w_itm = self.loss_weights()
         onehot = onehot.to(self.device, torch.int64).contiguous()
         cw = None if class_weight is None else class_weight.to(self.device, torch.float32).contiguous()
         loss = torch.empty(4, device=self.device)
         ncorr = torch.empty(1, dtype=torch.int32, device=self.device)
+        exchange = self.world > 1 or mmdist.force_exchange()
+        if not exchange and vision_keys is None and os.environ.get("MMHIP_NATIVE_STEP", "1") != "0":
+            # single rank: the whole step is one native call (include/mmhip.h: mmhip_train_step) -- the host enqueues ~250
+            # kernels from C++ instead of crossing ctypes ~40 times per step
+            return self._native_step(ids, mask, pixel_values, tim_ids, tim_mask, lbl_tim, onehot, cw, lr, weight_decay, step, loss, ncorr)
+        m._engine_forward(ids, mask, pixel_values, tim_ids, tim_mask, vision_keys=vision_keys)
         _lib.check(lib.mmhip_loss(m._handle, _lib.ptr(onehot), _lib.ptr(cw), _lib.ptr(lbl_tim), w_cls, w_itc, w_itm, _lib.ptr(loss),
                                   _lib.ptr(ncorr), s), "loss")
         _lib.check(lib.mmhip_backward_begin(m._handle, None, None, None, None, s), "backward_begin")
         works = []
-        exchange = self.world > 1 or mmdist.force_exchange()
         buckets = mmdist.StageBuckets(m._flat_grad) if exchange else None
         n_stage = len(m._stage_ranges)
         for st in range(n_stage):
@@ -508,12 +512,40 @@ class MMLate_Model(object):
         self._adamw(lr, weight_decay, step, dense=False)
         return loss, ncorr
 
-    def _adamw(self, lr, weight_decay, step, dense=True, rows=True):
-        m, lib = self.model, _lib.lib()
+    def _moments(self):
+        m = self.model
         if self._opt is None:
             self._opt = (torch.zeros_like(m._flat_train), torch.zeros_like(m._flat_train))
             m._word_row_state.bitwise_and_(1)                      # fresh moments: no row has any yet
-        em, ev = self._opt
+        return self._opt
+
+    def _native_step(self, ids, mask, pixels, tim_ids, tim_mask, lbl_tim, onehot, cw, lr, weight_decay, step, loss, ncorr):
+        m = self.model
+        dev = self.device
+        ids = ids.to(dev, torch.int64).contiguous()
+        mask = mask.to(dev, torch.int64).contiguous()
+        pixels = pixels.to(dev, torch.float32).contiguous()
+        B, T = ids.shape
+        if pixels.dim() != 4 or pixels.shape[0] != B or tuple(pixels.shape[1:]) != (3, m.arch["image"], m.arch["image"]):
+            raise ValueError(f"pixel_values must be [{B},3,{m.arch['image']},{m.arch['image']}], got {tuple(pixels.shape)}")
+        m._ensure(B, T)
+        em, ev = self._moments()
+        m._calls += 1
+        seed = (m._seed_base * 0x9E3779B97F4A7C15 + m._calls) & 0xFFFFFFFFFFFFFFFF
+        w_cls, w_itc, w_itm = self.loss_weights()
+        _lib.check(_lib.lib().mmhip_train_step(m._handle, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(pixels), _lib.ptr(tim_ids), _lib.ptr(tim_mask),
+                                               _lib.ptr(lbl_tim), _lib.ptr(onehot), _lib.ptr(cw), B, T, seed, int(bool(self.use_clip_loss)),
+                                               int(bool(self.use_tim_loss)), w_cls, w_itc, w_itm, _lib.ptr(em), _lib.ptr(ev), lr, 0.9, 0.999, 1e-8,
+                                               weight_decay, step, 1.0, _lib.ptr(loss), _lib.ptr(ncorr), _lib.stream_ptr()), "train_step")
+        m._fwd_token += 1
+        m._last = dict(B=B, T=T, itm=tim_ids is not None, seed=seed, ids=ids)
+        m._flat_train._version                                        # (read only; the refresh inside the call keeps the 16-bit copies current)
+        m._weights_version = (m._flat_train._version, m._flat_frozen._version)
+        return loss, ncorr
+
+    def _adamw(self, lr, weight_decay, step, dense=True, rows=True):
+        m, lib = self.model, _lib.lib()
+        em, ev = self._moments()
         at = lambda t, el: C.c_void_p(t.data_ptr() + el * 4)
         V, H = m._word_info["shape"]
         w0 = m._word_info["offset"]                                 # the word table closes the trainable buffer
