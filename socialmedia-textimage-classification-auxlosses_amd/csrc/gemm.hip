@@ -194,6 +194,25 @@ void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
+    // Every global LOAD of the epilogue is issued before its first STORE: vmcnt retires in issue order, so a load issued
+    // behind stores can only be consumed once those stores have completed -- one residual load per pass used to serialise
+    // the eight passes of a wave on HBM write latency.  `pre` = the residual rows (or, without a residual, the mul_in rows).
+    constexpr int NCH = (C::FM + 1) / 2;
+    const bool pre_res = (fl & GEMM_RESIDUAL) != 0, pre_mul = !pre_res && (fl & GEMM_MUL_GELU_GRAD);
+    v8 pre[NCH][PASSES];
+    if (pre_res || pre_mul) {
+        const T* pb = pre_res ? (const T*)a.residual : (const T*)a.mul_in;
+        const int pld = pre_res ? a.ldres : a.ldmul;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int row = p * RPP + lane / LPR;
+                const int m = m0 + wm * C::TM + ch * 32 + row;
+                if (!ep_lane || row >= 32 || ch * 32 + row >= C::TM || m >= a.M) continue;
+                pre[ch][p] = *reinterpret_cast<const v8*>(pb + (size_t)m * pld + n);
+            }
+    }
     // the staging region is wave-private and LDS operations of one wave execute in order: no barrier inside the loop
 #pragma unroll
     for (int ch = 0; ch < (C::FM + 1) / 2; ++ch) {     // FM odd (160-row tiles): the last chunk holds one 16-row fragment
@@ -235,7 +254,8 @@ void gemm_nt_kernel(GemmNTArgs a) {
                 for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
             }
             if (fl & GEMM_MUL_GELU_GRAD) {
-                v8 u = *reinterpret_cast<const v8*>((const T*)a.mul_in + (size_t)m * a.ldmul + n);
+                v8 u = pre[ch][p];
+                if (!pre_mul) u = *reinterpret_cast<const v8*>((const T*)a.mul_in + (size_t)m * a.ldmul + n);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= mm_gelu_grad(to_f<T>(u[e]));
             }
@@ -250,7 +270,7 @@ void gemm_nt_kernel(GemmNTArgs a) {
                 }
             }
             if (fl & GEMM_RESIDUAL) {
-                v8 r = *reinterpret_cast<const v8*>((const T*)a.residual + (size_t)m * a.ldres + n);
+                const v8 r = pre[ch][p];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += to_f<T>(r[e]);
             }
@@ -584,6 +604,24 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     // blocks per CU is as fast as any other tile for every shape of this model; the isolated micro-benchmark gains of the
     // 192-wide tiles (tools/gemm_bench.py) do not survive the cold caches between dependent kernels.  The wider tiles
     // stay selectable (a.tile / MMHIP_NT_TILE) and serve N that only 192 divides.
+    // round 2: the deep-pipelined persistent kernels (gemm8.hip) where they measure faster (tools/gemm8_bench.py on the model's
+    // shapes with the matching epilogue, profiles/r02_gemm8_microbench.txt).  One 256 x BN tile per CU and round: what decides
+    // is how full the last round of the 256 CUs is.  256 x 256 when its rounds are >= 55 % full and not much emptier than the
+    // 256 x 128 rounds (half the LDS fill per FLOP); 256 x 128 when its rounds are >= 70 % full; the round-1 tiles otherwise,
+    // and for the narrow long-K text GEMMs (8192 x 768 x 2304/3072), where the role-specialised 256 x 96/128 tiles stay ahead.
+    static int nt8 = -1;
+    if (nt8 < 0) { const char* e = getenv("MMHIP_NT8"); nt8 = e ? atoi(e) : 1; }
+    if (nt8 && a.M >= 2048 && a.N % 128 == 0 && a.K % 64 == 0) {
+        const long tm = (a.M + 255) / 256;
+        const long t256 = a.N % 256 == 0 ? tm * (a.N / 256) : 0, t128 = tm * (a.N / 128);
+        const double u256 = t256 ? (double)t256 / (double)(((t256 + 255) / 256) * 256) : 0.0;
+        const double u128 = (double)t128 / (double)(((t128 + 255) / 256) * 256);
+        const bool narrow_long = a.N <= 768 && a.K >= 2048 && a.M <= 8192;
+        if (!narrow_long) {
+            if (u256 >= 0.55 && u256 >= u128 - 0.15) return 15;
+            if (u128 >= 0.70) return 16;
+        }
+    }
     static int rule = -1;
     if (rule < 0) { const char* e = getenv("MMHIP_NT_RULE"); rule = e ? atoi(e) : 2; }   // 2: measured best inside the step
     if (rule == 1 && a.N % 128 == 0 && a.N <= 768 && a.M >= 4096) return 9;        // experiment: WS 256x128 for narrow outputs

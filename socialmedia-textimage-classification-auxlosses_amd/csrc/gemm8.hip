@@ -64,7 +64,10 @@ template <int BN> __device__ __forceinline__ int st_piece(int p, int jj, int w) 
 enum { EP_PLAIN = 0, EP_GELU = 1, EP_MULG = 2, EP_ANY = 3 };
 
 template <typename T, int EPI>
-__device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, int n) {
+__device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, int n, const typename Vec<T>::v8& pre) {
+    // `pre`: this lane's 8 values of the residual (EP_PLAIN / EP_ANY) or of mul_in (EP_MULG), loaded by the caller BEFORE the
+    // first store of the tile: vmcnt retires in issue order, so a load issued behind stores can only be consumed once those
+    // stores have completed -- one such load per output fragment serialised the whole epilogue on HBM write latency
     typedef typename Vec<T>::v8 v8;
     const int fl = a.flags;
     if ((EPI == EP_GELU || EPI == EP_ANY) && (fl & GEMM_AUX_PRE)) {
@@ -81,7 +84,11 @@ __device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
     }
-    if (EPI == EP_MULG || (EPI == EP_ANY && (fl & GEMM_MUL_GELU_GRAD))) {
+    if (EPI == EP_MULG) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= mm_gelu_grad(to_f<T>(pre[e]));
+    }
+    if (EPI == EP_ANY && (fl & GEMM_MUL_GELU_GRAD)) {
         v8 u = *reinterpret_cast<const v8*>((const T*)a.mul_in + (size_t)m * a.ldmul + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= mm_gelu_grad(to_f<T>(u[e]));
@@ -96,7 +103,11 @@ __device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, 
             v[e + 1] = k1 ? v[e + 1] * a.drop.keep_scale : 0.f;
         }
     }
-    if (EPI != EP_GELU && (fl & GEMM_RESIDUAL)) {
+    if ((EPI == EP_PLAIN || EPI == EP_ANY) && (fl & GEMM_RESIDUAL)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += to_f<T>(pre[e]);
+    }
+    if (EPI == EP_MULG && (fl & GEMM_RESIDUAL)) {
         v8 r = *reinterpret_cast<const v8*>((const T*)a.residual + (size_t)m * a.ldres + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += to_f<T>(r[e]);
@@ -288,24 +299,47 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTArgs a, int pers
         // n = n0 + wn*TN + 32 j' + 8 (lane>>4); values 0-3 from fragment 2j', 4-7 from fragment 2j'+1
         int m0, n0;
         tile_origin(first + t * stride, m0, n0);
+        // every load of the epilogue first (bias; residual or mul_in of all the lane's fragments), then compute, then stores.
+        // Rows past M are clamped, not masked: they were computed from (clamped) row M-1 and re-store its values.
+        const int nb = n0 + wn * C::TN + 8 * kc;
+        float bias8[C::FN / 2][8];
 #pragma unroll
         for (int jp = 0; jp < C::FN / 2; ++jp) {
-            const int n = n0 + wn * C::TN + 32 * jp + 8 * kc;
-            float bias8[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+            for (int e = 0; e < 8; ++e) bias8[jp][e] = 0.f;
             if (EPI == EP_GELU || (a.flags & GEMM_BIAS)) {
-                f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + n), b1 = *reinterpret_cast<const f32x4*>(a.bias + n + 4);
+                f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + nb + 32 * jp), b1 = *reinterpret_cast<const f32x4*>(a.bias + nb + 32 * jp + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+                for (int e = 0; e < 4; ++e) { bias8[jp][e] = b0[e]; bias8[jp][4 + e] = b1[e]; }
             }
+        }
+        // (BN = 256: two chunks of two fragment-pair columns -- 64 more registers for all sixteen residual fragments would spill)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wm * 64 + i * 16 + l15;
-                float v[8];
+        for (int jc = 0; jc < C::FN / 2; jc += 2) {
+            v8 pre[4][2];
+            const T* pbase = (EPI == EP_MULG) ? (const T*)a.mul_in : (const T*)a.residual;
+            const int pld = (EPI == EP_MULG) ? a.ldmul : a.ldres;
+            const bool want = (EPI == EP_MULG) || ((EPI == EP_PLAIN || EPI == EP_ANY) && (a.flags & GEMM_RESIDUAL));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e] + bias8[e]; v[4 + e] = acc[i][2 * jp + 1][e] + bias8[4 + e]; }
-                if (m < a.M) epilogue8<T, EPI>(a, v, m, n);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    if (EPI != EP_GELU && want) {
+                        const int m = min(m0 + wm * 64 + i * 16 + l15, a.M - 1);
+                        pre[i][j2] = *reinterpret_cast<const v8*>(pbase + (size_t)m * pld + nb + 32 * (jc + j2));
+                    }
+                }
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int jp = jc + j2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = min(m0 + wm * 64 + i * 16 + l15, a.M - 1);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e] + bias8[jp][e]; v[4 + e] = acc[i][2 * jp + 1][e] + bias8[jp][4 + e]; }
+                    epilogue8<T, EPI>(a, v, m, nb + 32 * jp, pre[i][j2]);
+                }
             }
         }
         zero_acc();

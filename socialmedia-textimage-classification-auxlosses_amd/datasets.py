@@ -59,14 +59,17 @@ def normalize_tweet(text):
     return " ".join(out.split())
 
 
-def prepare_data(data, num_labels, testing=False, nsamples=-1, seed=30):
+def prepare_data(data, num_labels, testing=False, nsamples=-1, seed=None):
     """reference models/utils.py:133-200: --testing samples 200 rows; split column -> train/val/test; one-hot labels;
-    sklearn-'balanced' class weights from the training split"""
+    sklearn-'balanced' class weights from the training split.  Like the reference, the subsamples are drawn from numpy's
+    GLOBAL stream (run_mm_late.py:49 seeds it), so the ITM negative sampling that follows continues from the same state as
+    in the reference (pinned by tests/golden/f3_prepare_data.json); `seed` = an explicit RandomState instead."""
+    rs = None if seed is None else np.random.RandomState(seed)
     if testing:
-        data = data.sample(min(200, len(data)), random_state=seed)
+        data = data.sample(min(200, len(data)), random_state=rs)
     parts = {s: data[data.split == s] for s in ("train", "val", "test")}
     if nsamples > 0:
-        parts["train"] = parts["train"].sample(min(nsamples, len(parts["train"])), random_state=seed)
+        parts["train"] = parts["train"].sample(min(nsamples, len(parts["train"])), random_state=rs)
     onehot = lambda df: np.eye(num_labels, dtype=np.int64)[df.label.values.astype(int)]
     weights = balanced_class_weights(parts["train"].label.values, num_labels)
     return parts["train"], onehot(parts["train"]), parts["val"], onehot(parts["val"]), parts["test"], onehot(parts["test"]), weights
@@ -117,7 +120,11 @@ def loaders_from_data_key(cfg, args, trainer):
     if not os.path.isdir(tdir):
         raise FileNotFoundError(f"tokenizer directory {tdir!r} (config.MODEL_DIR_DICT) not found: use --synthetic, or place the model there")
     tok = AutoTokenizer.from_pretrained(tdir)
-    tr, ytr, va, yva, te, yte, w = prepare_data(cfg.data, cfg.num_labels, args.testing, args.nsamples, args.seed)
+    # single process: numpy's global stream, exactly like the reference (run_mm_late.py:49 seeded it; the ITM sampling then
+    # continues from the reference's state).  Data parallel: every rank must draw the SAME subsample, and each rank's global
+    # stream is seeded seed + rank for its own ITM draws -- so an explicit RandomState(seed), which picks the same rows.
+    multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    tr, ytr, va, yva, te, yte, w = prepare_data(cfg.data, cfg.num_labels, args.testing, args.nsamples, args.seed if multi else None)
     # image resize + normalize run on the GPU per batch (image_processing.py) unless --cpu_preprocess asks for the host form
     gpu = not getattr(args, "cpu_preprocess", False) and trainer.device.type == "cuda"
     size = trainer.model.arch["image"]
