@@ -30,6 +30,7 @@ extern "C" {
  * operands (csrc/x3.hip); ~1e-5 on the logits against the fp32 reference, where bf16 gives 5e-3..2e-2 and f16 1e-3..3e-3 */
 enum { MMHIP_BF16 = 0, MMHIP_F16 = 1, MMHIP_F32 = 2, MMHIP_BF16X3 = 2 };
 enum { MMHIP_TXT_BERT = 0, MMHIP_TXT_XLMR = 1 };
+enum { MMHIP_IMG_VIT = 0, MMHIP_IMG_CLIP = 1 };   /* HF ViTModel | HF CLIPVisionModel (pre-LN, quick-GELU, bias-free patch conv, pre_layrnorm) */
 enum { MMHIP_FUSION_CONCAT = 0, MMHIP_FUSION_ATTENTION = 1 };
 /* gradient groups: which parameters receive a gradient for a given flag set */
 enum { MMHIP_G_NEVER = 0, MMHIP_G_ITC = 1, MMHIP_G_ITM = 2, MMHIP_G_FUSION_ATT = 3, MMHIP_G_ALWAYS = 4, MMHIP_G_FROZEN = 5 };
@@ -48,6 +49,9 @@ typedef struct mmhip_config {
     float loss_scale;                    /* gradient scale inside the 16-bit text tower; 0 = default (1 for bf16, 1024 for f16:
                                             f16 has 5 exponent bits, deep-layer activation gradients ~1e-6 would be subnormal).
                                             train_grad is always in true units. */
+    int img_kind;                        /* MMHIP_IMG_*: BASELINE config 4 = MMHIP_IMG_CLIP with hidden_img 1024, heads_img 16, inter_img 4096,
+                                            patch 14, image 224 (257 tokens) or 336 (577), fusion MMHIP_FUSION_CONCAT */
+    int hidden_img, heads_img, inter_img;/* image tower width / heads / MLP width; 0 = the text tower's (ViT-B/16) */
 } mmhip_config;
 
 typedef struct mmhip_param_info {

@@ -68,6 +68,24 @@ class OracleConfig:
     p_hidden: float = 0.1       # text hidden dropout
     p_attn: float = 0.1         # text attention-prob dropout
     p_head: float = 0.05        # --dropout
+    # image tower: "vit" (HF ViTModel, ViT-B/16) or "clip" (HF CLIPVisionModel; BASELINE config 4: CLIP-ViT-L/14 = 1024 wide,
+    # 16 heads, 4096 MLP, patch 14, eps 1e-5).  0 = the text tower's sizes.
+    img_kind: str = "vit"
+    hidden_img: int = 0
+    heads_img: int = 0
+    inter_img: int = 0
+
+    @property
+    def Hv(self) -> int:
+        return self.hidden_img or self.hidden
+
+    @property
+    def Iv(self) -> int:
+        return self.inter_img or self.inter
+
+    @property
+    def heads_v(self) -> int:
+        return self.heads_img or self.heads
 
     @property
     def n_patches(self) -> int:
@@ -87,6 +105,8 @@ def param_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
     s: Dict[str, Tuple[int, ...]] = {}
     de = "dual_encoder."
     s[de + "logit_scale"] = ()
+    if cfg.img_kind == "clip":
+        return _param_shapes_clip(cfg, s)
     vm = de + "vision_model."
     s[vm + "embeddings.cls_token"] = (1, 1, H)
     s[vm + "embeddings.position_embeddings"] = (1, cfg.img_tokens, H)
@@ -111,6 +131,39 @@ def param_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
     s[vm + "layernorm.bias"] = (H,)
     s[vm + "pooler.dense.weight"] = (H, H)
     s[vm + "pooler.dense.bias"] = (H,)
+    return _param_shapes_text_heads(cfg, s)
+
+
+def _param_shapes_clip(cfg: OracleConfig, s):
+    """HF CLIPVisionModel inside the dual encoder, transformers 4.25.1 key names (vision_model.vision_model.*)."""
+    Hv, Iv = cfg.Hv, cfg.Iv
+    vm = "dual_encoder.vision_model.vision_model."
+    s[vm + "embeddings.class_embedding"] = (Hv,)
+    s[vm + "embeddings.patch_embedding.weight"] = (Hv, 3, cfg.patch, cfg.patch)
+    s[vm + "embeddings.position_embedding.weight"] = (cfg.img_tokens, Hv)
+    s[vm + "pre_layrnorm.weight"] = (Hv,)
+    s[vm + "pre_layrnorm.bias"] = (Hv,)
+    for l in range(cfg.layers_img):
+        p = f"{vm}encoder.layers.{l}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[p + f"self_attn.{n}.weight"] = (Hv, Hv)
+            s[p + f"self_attn.{n}.bias"] = (Hv,)
+        s[p + "layer_norm1.weight"] = (Hv,)
+        s[p + "layer_norm1.bias"] = (Hv,)
+        s[p + "mlp.fc1.weight"] = (Iv, Hv)
+        s[p + "mlp.fc1.bias"] = (Iv,)
+        s[p + "mlp.fc2.weight"] = (Hv, Iv)
+        s[p + "mlp.fc2.bias"] = (Hv,)
+        s[p + "layer_norm2.weight"] = (Hv,)
+        s[p + "layer_norm2.bias"] = (Hv,)
+    s[vm + "post_layernorm.weight"] = (Hv,)
+    s[vm + "post_layernorm.bias"] = (Hv,)
+    return _param_shapes_text_heads(cfg, s)
+
+
+def _param_shapes_text_heads(cfg: OracleConfig, s):
+    H, I = cfg.hidden, cfg.inter
+    de = "dual_encoder."
     tm = de + "text_model."
     s[tm + "embeddings.word_embeddings.weight"] = (cfg.vocab, H)
     s[tm + "embeddings.position_embeddings.weight"] = (cfg.max_pos, H)
@@ -134,11 +187,11 @@ def param_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
         s[p + "output.LayerNorm.bias"] = (H,)
     s[tm + "pooler.dense.weight"] = (H, H)
     s[tm + "pooler.dense.bias"] = (H,)
-    s[de + "visual_projection.weight"] = (cfg.proj_dim, H)
+    s[de + "visual_projection.weight"] = (cfg.proj_dim, cfg.Hv)
     s[de + "text_projection.weight"] = (cfg.proj_dim, H)
     # heads, reference models/mm_late.py:73-89
     for n, shp in (("fc_Q", (H, H)), ("fc_K", (H, H)), ("fc_V", (H, H)), ("aspectattention", (1, H)),
-                   ("linear_fusion", (H, 2 * H)), ("linear_cls", (cfg.num_labels, H)),
+                   ("linear_fusion", (H, H + cfg.Hv)), ("linear_cls", (cfg.num_labels, H)),
                    ("linear_tim", (2, H)), ("linear_iadds", (2, H)),
                    ("linear_gmu_t", (2 * H, H)), ("linear_gmu_v", (2 * H, H))):
         s[n + ".weight"] = shp
@@ -158,7 +211,7 @@ def make_param(name: str, shape: Tuple[int, ...], seed: int) -> Tensor:
     if name.endswith("logit_scale"):
         return torch.tensor(2.6592)
     x = torch.randn(shape, generator=g, dtype=torch.float32)
-    if ("LayerNorm.weight" in name or "layernorm" in name and name.endswith(".weight")):
+    if ("LayerNorm.weight" in name or ("layernorm" in name or "layer_norm" in name or "layrnorm" in name) and name.endswith(".weight")):
         return 1.0 + 0.1 * x
     return 0.02 * x
 
@@ -252,6 +305,7 @@ def vit_forward(P: Dict[str, Tensor], pixels: Tensor, cfg: OracleConfig,
                 collect: Optional[list] = None) -> Tuple[Tensor, Tensor]:
     """HF:models/vit/modeling_vit.py:373-388 (ViTModel.forward); all dropouts are 0.0."""
     vm = "dual_encoder.vision_model."
+    assert cfg.Hv == cfg.hidden and cfg.Iv == cfg.inter, "the ViT restatement shares the text tower's sizes"
     B = pixels.shape[0]
     w = P[vm + "embeddings.patch_embeddings.projection.weight"]
     b = P[vm + "embeddings.patch_embeddings.projection.bias"]
@@ -275,6 +329,36 @@ def vit_forward(P: Dict[str, Tensor], pixels: Tensor, cfg: OracleConfig,
             collect.append(x)
     x = _ln(x, P, vm + "layernorm", cfg.ln_eps_img)                                     # :385
     pooled = torch.tanh(_lin(x[:, 0], P, vm + "pooler.dense"))                          # :289-301
+    return x, pooled
+
+
+def clip_vision_forward(P: Dict[str, Tensor], pixels: Tensor, cfg: OracleConfig,
+                        collect: Optional[list] = None) -> Tuple[Tensor, Tensor]:
+    """HF:models/clip/modeling_clip.py -- CLIPVisionEmbeddings (bias-free patch conv, class embedding, learned positions),
+    CLIPVisionTransformer.forward (pre_layrnorm; pre-LN encoder layers with quick-GELU MLPs; last_hidden_state is the encoder
+    output as it is, pooler_output = post_layernorm of its CLS row).  -> (last_hidden_state [B,P,Hv], pooler_output [B,Hv])"""
+    vm = "dual_encoder.vision_model.vision_model."
+    B, Hv, nh = pixels.shape[0], cfg.Hv, cfg.heads_v
+    x = F.conv2d(pixels, P[vm + "embeddings.patch_embedding.weight"], None, stride=cfg.patch).flatten(2).transpose(1, 2)
+    x = torch.cat([P[vm + "embeddings.class_embedding"].expand(B, 1, -1), x], dim=1)
+    x = x + P[vm + "embeddings.position_embedding.weight"]
+    x = _ln(x, P, vm + "pre_layrnorm", cfg.ln_eps_img)
+    scale = (Hv // nh) ** -0.5
+    for l in range(cfg.layers_img):
+        p = f"{vm}encoder.layers.{l}."
+        h = _ln(x, P, p + "layer_norm1", cfg.ln_eps_img)
+        q = _heads(_lin(h, P, p + "self_attn.q_proj"), nh)
+        k = _heads(_lin(h, P, p + "self_attn.k_proj"), nh)
+        v = _heads(_lin(h, P, p + "self_attn.v_proj"), nh)
+        a = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+        c = (a @ v).permute(0, 2, 1, 3).reshape(B, -1, Hv)
+        x = x + _lin(c, P, p + "self_attn.out_proj")
+        h = _lin(_ln(x, P, p + "layer_norm2", cfg.ln_eps_img), P, p + "mlp.fc1")
+        h = h * torch.sigmoid(1.702 * h)                                     # quick_gelu
+        x = x + _lin(h, P, p + "mlp.fc2")
+        if collect is not None:
+            collect.append(x)
+    pooled = _ln(x[:, 0], P, vm + "post_layernorm", cfg.ln_eps_img)
     return x, pooled
 
 
@@ -354,7 +438,7 @@ def mm_forward(P: Dict[str, Tensor], ids: Tensor, mask: Tensor, pixels: Tensor, 
     cv = collect.setdefault("vit_layers", []) if collect is not None else None
     ct = collect.setdefault("txt_layers", []) if collect is not None else None
     B = ids.shape[0]
-    x_v, v_pool = vit_forward(P, pixels, cfg, cv)
+    x_v, v_pool = (clip_vision_forward if cfg.img_kind == "clip" else vit_forward)(P, pixels, cfg, cv)
     x_t, t_pool = text_forward(P, ids, mask, cfg, drop, 0, ct)
     logits_per_text = itc_logits(P, t_pool, v_pool)
     feats = mm_fusion(P, x_t, x_v, cfg)

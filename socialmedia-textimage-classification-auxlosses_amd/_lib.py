@@ -10,6 +10,7 @@ BF16, F16, F32 = 0, 1, 2
 BF16X3 = 2          # as an engine dtype: the strict-parity mode (fp32 activations, bf16x3 matrix products; include/mmhip.h)
 TXT_BERT, TXT_XLMR = 0, 1
 FUSION_CONCAT, FUSION_ATTENTION = 0, 1
+IMG_VIT, IMG_CLIP = 0, 1
 G_NEVER, G_ITC, G_ITM, G_FUSION_ATT, G_ALWAYS, G_FROZEN = range(6)
 
 
@@ -19,7 +20,8 @@ class Config(C.Structure):
                 ("ln_eps_txt", C.c_float), ("ln_eps_img", C.c_float), ("image", C.c_int), ("patch", C.c_int),
                 ("proj_dim", C.c_int), ("num_labels", C.c_int), ("fusion", C.c_int), ("p_hidden", C.c_float),
                 ("p_attn", C.c_float), ("p_head", C.c_float), ("dtype", C.c_int), ("max_posts", C.c_int),
-                ("max_text_len", C.c_int), ("loss_scale", C.c_float)]
+                ("max_text_len", C.c_int), ("loss_scale", C.c_float), ("img_kind", C.c_int), ("hidden_img", C.c_int),
+                ("heads_img", C.c_int), ("inter_img", C.c_int)]
 
 
 class ParamInfo(C.Structure):

@@ -25,7 +25,8 @@ metric_names = ["f1_weighted", "f1_macro", "precision_weighted", "precision_macr
 RES_PATH = "../results/"
 results_dir_mm_late = RES_PATH + "mm_late/"
 MODEL_DIR_DICT = {"bert": "../../../BERT-base/", "bertweet": "../../../BERTWEET-base/", "roberta": "../../../RoBERTa-base/",
-                  "bernice": "../../../BERNICE/", "vit": "../../../ViT/", "beit": "../../../BEiT/", "deit": "../../../DEiT/"}
+                  "bernice": "../../../BERNICE/", "vit": "../../../ViT/", "beit": "../../../BEiT/", "deit": "../../../DEiT/",
+                  "clip": "../../../CLIP-ViT-L-14/", "clip336": "../../../CLIP-ViT-L-14-336/"}
 
 # task -> (num_labels, batch_size), reference models/config.py:13-48
 _TASK_SHAPE = {0: (2, 8), 1: (2, 8), 2: (4, 8), 3: (3, 16), 4: (4, 8), 5: (2, 16), 6: (2, 16)}
@@ -37,7 +38,11 @@ TEXT_ARCH = {
     "bertweet": dict(txt_kind="xlmr", vocab=64001, max_pos=130, type_vocab=1, pad_id=1, ln_eps_txt=1e-5),
     "bert": dict(txt_kind="bert", vocab=30522, max_pos=512, type_vocab=2, pad_id=0, ln_eps_txt=1e-12),
 }
-IMAGE_ARCH = {"vit": dict(image=224, patch=16, ln_eps_img=1e-12)}
+# "clip" / "clip336" (additive; BASELINE config 4): CLIP-ViT-L/14 vision tower, HF CLIPVisionModel -- 1024 wide, 16 heads, 4096 MLP,
+# 24 pre-LN layers, quick-GELU, 14 x 14 patches (257 tokens at 224, 577 at 336: openai/clip-vit-large-patch14[-336])
+IMAGE_ARCH = {"vit": dict(image=224, patch=16, ln_eps_img=1e-12, img_kind="vit"),
+              "clip": dict(image=224, patch=14, ln_eps_img=1e-5, img_kind="clip", hidden_img=1024, heads_img=16, inter_img=4096, layers_img=24),
+              "clip336": dict(image=336, patch=14, ln_eps_img=1e-5, img_kind="clip", hidden_img=1024, heads_img=16, inter_img=4096, layers_img=24)}
 
 
 class Config(object):

@@ -339,6 +339,8 @@ static hipError_t launch_fwd_d(const AttnArgs& a, hipStream_t s) {
     else if (a.S <= 64) launch_fwd_t<T, 2, 2>(a, s);
     else if (a.S <= 128) launch_fwd_t<T, 4, 4>(a, s);
     else if (a.S <= 224) launch_fwd_t<T, 7, 8>(a, s);
+    else if (a.S <= 288) launch_fwd_t<T, 9, 8>(a, s);       // CLIP-ViT-L/14 @224: 257 tokens
+    else if (a.S <= 608) launch_fwd_t<T, 19, 8>(a, s);      // @336: 577 tokens; K + V of a head = 152 KB of the CU's 160 KB LDS
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

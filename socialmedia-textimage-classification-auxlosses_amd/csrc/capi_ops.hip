@@ -95,6 +95,7 @@ int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, 
     if (bias) { a.bias = bias; a.flags |= GEMM_BIAS; }
     if (act == 1) a.flags |= GEMM_GELU;
     if (act == 2) a.flags |= GEMM_TANH;
+    if (act == 3) a.flags |= GEMM_QGELU;
     if (aux_pre) { a.aux = aux_pre; a.ldaux = ldaux; a.flags |= GEMM_AUX_PRE; }
     if (mul_gelu_grad_of) { a.mul_in = mul_gelu_grad_of; a.ldmul = ldmul; a.flags |= GEMM_MUL_GELU_GRAD; }
     if (p_drop > 0.f) { a.drop = drop_of(p_drop, seed, stream_id); a.flags |= GEMM_DROPOUT; }

@@ -84,6 +84,15 @@ struct mmhip_engine {
 
     template <typename U> U* wsp(size_t off) const { return reinterpret_cast<U*>(ws + off); }
     int dt() const { return cfg.dtype; }
+    // image tower geometry: its own width for CLIP-ViT-L/14 (BASELINE config 4), the text tower's otherwise
+    bool clip() const { return cfg.img_kind == MMHIP_IMG_CLIP; }
+    int Hv() const { return cfg.hidden_img > 0 ? cfg.hidden_img : cfg.hidden; }
+    int Iv() const { return cfg.inter_img > 0 ? cfg.inter_img : cfg.inter; }
+    int heads_v() const { return cfg.heads_img > 0 ? cfg.heads_img : cfg.heads; }
+    int P() const { return (cfg.image / cfg.patch) * (cfg.image / cfg.patch) + 1; }
+    int Kp() const { return 3 * cfg.patch * cfg.patch; }                 // patch-embedding reduction length
+    int Kpp() const { return (Kp() + 63) / 64 * 64; }                    // ... padded to the GEMM's k-step (588 -> 640 for 14 x 14)
+    size_t v_pre_ln_w = 0, v_pre_ln_b = 0;                               // CLIP pre_layrnorm
     // f16 activations: gradients inside the text tower are carried multiplied by gscale() (range, not precision) and
     // every fp32 parameter gradient is written multiplied by 1 / gscale(); bf16 needs none
     float gscale() const { return cfg.loss_scale > 0.f ? cfg.loss_scale : (cfg.dtype == MMHIP_F16 ? 1024.f : 1.f); }
@@ -137,8 +146,32 @@ void add_text_layer(Builder& b, const mmhip_config& c, int l, LayerOff& o) {
     o.ln2_b = b.add(p + "output.LayerNorm.bias", 1, g, {H});
     o.end = b.off[1];
 }
+// CLIP vision layer, transformers 4.25.1 keys (CLIPVisionModel wraps the transformer as `.vision_model`):
+// HF:models/clip/modeling_clip.py (CLIPEncoderLayer: pre-LN, quick-GELU MLP)
+void add_clip_layer(Builder& b, int H, int I, int l, LayerOff& o) {
+    const std::string p = "dual_encoder.vision_model.vision_model.encoder.layers." + std::to_string(l) + ".";
+    const int g = MMHIP_G_FROZEN;
+    o.begin = b.off[0];
+    o.qkv_w = b.add(p + "self_attn.q_proj.weight", 0, g, {H, H});
+    b.add(p + "self_attn.k_proj.weight", 0, g, {H, H});
+    b.add(p + "self_attn.v_proj.weight", 0, g, {H, H});
+    o.qkv_b = b.add(p + "self_attn.q_proj.bias", 0, g, {H});
+    b.add(p + "self_attn.k_proj.bias", 0, g, {H});
+    b.add(p + "self_attn.v_proj.bias", 0, g, {H});
+    o.ao_w = b.add(p + "self_attn.out_proj.weight", 0, g, {H, H});
+    o.ao_b = b.add(p + "self_attn.out_proj.bias", 0, g, {H});
+    o.ln1_w = b.add(p + "layer_norm1.weight", 0, g, {H});
+    o.ln1_b = b.add(p + "layer_norm1.bias", 0, g, {H});
+    o.fc1_w = b.add(p + "mlp.fc1.weight", 0, g, {I, H});
+    o.fc1_b = b.add(p + "mlp.fc1.bias", 0, g, {I});
+    o.fc2_w = b.add(p + "mlp.fc2.weight", 0, g, {H, I});
+    o.fc2_b = b.add(p + "mlp.fc2.bias", 0, g, {H});
+    o.ln2_w = b.add(p + "layer_norm2.weight", 0, g, {H});
+    o.ln2_b = b.add(p + "layer_norm2.bias", 0, g, {H});
+    o.end = b.off[0];
+}
 void add_vit_layer(Builder& b, const mmhip_config& c, int l, LayerOff& o) {
-    const int H = c.hidden, I = c.inter;
+    const int H = c.hidden_img > 0 ? c.hidden_img : c.hidden, I = c.inter_img > 0 ? c.inter_img : c.inter;
     const std::string p = "dual_encoder.vision_model.encoder.layer." + std::to_string(l) + ".";
     const int g = MMHIP_G_FROZEN;
     o.begin = b.off[0];
@@ -163,20 +196,36 @@ void add_vit_layer(Builder& b, const mmhip_config& c, int l, LayerOff& o) {
 
 void build_layout(mmhip_engine& e) {
     const mmhip_config& c = e.cfg;
-    const int H = c.hidden, C = c.num_labels, E = c.proj_dim, P = (c.image / c.patch) * (c.image / c.patch) + 1;
+    const int H = c.hidden, C = c.num_labels, E = c.proj_dim, P = e.P(), Hv = e.Hv();
     Builder b{e};
     // ---- frozen: vision tower (every dual_encoder parameter with 'vision' in its name, mm_late.py:67-69)
-    const std::string vm = "dual_encoder.vision_model.";
-    e.v_cls = b.add(vm + "embeddings.cls_token", 0, MMHIP_G_FROZEN, {1, 1, H});
-    e.v_pos = b.add(vm + "embeddings.position_embeddings", 0, MMHIP_G_FROZEN, {1, P, H});
-    e.v_patch_w = b.add(vm + "embeddings.patch_embeddings.projection.weight", 0, MMHIP_G_FROZEN, {H, 3, c.patch, c.patch});
-    e.v_patch_b = b.add(vm + "embeddings.patch_embeddings.projection.bias", 0, MMHIP_G_FROZEN, {H});
     e.vit.resize(c.layers_img);
-    for (int l = 0; l < c.layers_img; ++l) add_vit_layer(b, c, l, e.vit[l]);
-    e.v_ln_w = b.add(vm + "layernorm.weight", 0, MMHIP_G_FROZEN, {H});
-    e.v_ln_b = b.add(vm + "layernorm.bias", 0, MMHIP_G_FROZEN, {H});
-    e.v_pool_w = b.add(vm + "pooler.dense.weight", 0, MMHIP_G_FROZEN, {H, H});
-    e.v_pool_b = b.add(vm + "pooler.dense.bias", 0, MMHIP_G_FROZEN, {H});
+    if (e.clip()) {
+        // HF CLIPVisionTransformer (models/clip/modeling_clip.py): class_embedding [Hv], bias-free patch conv, learned positions,
+        // pre_layrnorm, pre-LN layers, post_layernorm on the pooled CLS row only
+        const std::string vm = "dual_encoder.vision_model.vision_model.";
+        e.v_cls = b.add(vm + "embeddings.class_embedding", 0, MMHIP_G_FROZEN, {Hv});
+        e.v_patch_w = b.add(vm + "embeddings.patch_embedding.weight", 0, MMHIP_G_FROZEN, {Hv, 3, c.patch, c.patch});
+        e.v_patch_b = 0;
+        e.v_pos = b.add(vm + "embeddings.position_embedding.weight", 0, MMHIP_G_FROZEN, {P, Hv});
+        e.v_pre_ln_w = b.add(vm + "pre_layrnorm.weight", 0, MMHIP_G_FROZEN, {Hv});
+        e.v_pre_ln_b = b.add(vm + "pre_layrnorm.bias", 0, MMHIP_G_FROZEN, {Hv});
+        for (int l = 0; l < c.layers_img; ++l) add_clip_layer(b, Hv, e.Iv(), l, e.vit[l]);
+        e.v_ln_w = b.add(vm + "post_layernorm.weight", 0, MMHIP_G_FROZEN, {Hv});
+        e.v_ln_b = b.add(vm + "post_layernorm.bias", 0, MMHIP_G_FROZEN, {Hv});
+        e.v_pool_w = e.v_pool_b = 0;
+    } else {
+        const std::string vm = "dual_encoder.vision_model.";
+        e.v_cls = b.add(vm + "embeddings.cls_token", 0, MMHIP_G_FROZEN, {1, 1, Hv});
+        e.v_pos = b.add(vm + "embeddings.position_embeddings", 0, MMHIP_G_FROZEN, {1, P, Hv});
+        e.v_patch_w = b.add(vm + "embeddings.patch_embeddings.projection.weight", 0, MMHIP_G_FROZEN, {Hv, 3, c.patch, c.patch});
+        e.v_patch_b = b.add(vm + "embeddings.patch_embeddings.projection.bias", 0, MMHIP_G_FROZEN, {Hv});
+        for (int l = 0; l < c.layers_img; ++l) add_vit_layer(b, c, l, e.vit[l]);
+        e.v_ln_w = b.add(vm + "layernorm.weight", 0, MMHIP_G_FROZEN, {Hv});
+        e.v_ln_b = b.add(vm + "layernorm.bias", 0, MMHIP_G_FROZEN, {Hv});
+        e.v_pool_w = b.add(vm + "pooler.dense.weight", 0, MMHIP_G_FROZEN, {Hv, Hv});
+        e.v_pool_b = b.add(vm + "pooler.dense.bias", 0, MMHIP_G_FROZEN, {Hv});
+    }
     // ---- trainable, ordered [never | ITC | ITM | fusion-attention | always: heads, layers last->first, embeddings]
     for (const char* n : {"aspectattention", "linear_iadds", "linear_gmu_t", "linear_gmu_v"}) {
         const int out = !strcmp(n, "aspectattention") ? 1 : (!strcmp(n, "linear_iadds") ? 2 : 2 * H);
@@ -185,7 +234,7 @@ void build_layout(mmhip_engine& e) {
     }
     e.heads_begin = b.off[1];
     e.logit_scale = b.add("dual_encoder.logit_scale", 1, MMHIP_G_ITC, {});
-    e.vproj_w = b.add("dual_encoder.visual_projection.weight", 1, MMHIP_G_ITC, {E, H});
+    e.vproj_w = b.add("dual_encoder.visual_projection.weight", 1, MMHIP_G_ITC, {E, Hv});
     e.tproj_w = b.add("dual_encoder.text_projection.weight", 1, MMHIP_G_ITC, {E, H});
     e.t_pool_w = b.add("dual_encoder.text_model.pooler.dense.weight", 1, MMHIP_G_ITC, {H, H});
     e.t_pool_b = b.add("dual_encoder.text_model.pooler.dense.bias", 1, MMHIP_G_ITC, {H});
@@ -197,7 +246,8 @@ void build_layout(mmhip_engine& e) {
     e.fk_b = b.add("fc_K.bias", 1, MMHIP_G_FUSION_ATT, {H});
     e.fv_w = b.add("fc_V.weight", 1, MMHIP_G_FUSION_ATT, {H, H});
     e.fv_b = b.add("fc_V.bias", 1, MMHIP_G_FUSION_ATT, {H});
-    e.fus_w = b.add("linear_fusion.weight", 1, MMHIP_G_ALWAYS, {H, 2 * H});
+    // 'concat' takes [x_t CLS | x_v CLS]: H + Hv wide (the reference hard-wires 768 + 768, models/config.py:82-84, mm_late.py:81)
+    e.fus_w = b.add("linear_fusion.weight", 1, MMHIP_G_ALWAYS, {H, H + Hv});
     e.fus_b = b.add("linear_fusion.bias", 1, MMHIP_G_ALWAYS, {H});
     e.cls_w = b.add("linear_cls.weight", 1, MMHIP_G_ALWAYS, {C, H});
     e.cls_b = b.add("linear_cls.bias", 1, MMHIP_G_ALWAYS, {C});
@@ -224,20 +274,20 @@ struct Carver {
 void build_workspace(mmhip_engine& e) {
     const mmhip_config& c = e.cfg;
     const size_t H = c.hidden, I = c.inter, E = c.proj_dim, C = c.num_labels;
-    const size_t Bm = c.max_posts, Tm = c.max_text_len, P = (c.image / c.patch) * (c.image / c.patch) + 1;
+    const size_t Bm = c.max_posts, Tm = c.max_text_len, P = e.P(), Hv = e.Hv(), Iv = e.Iv(), Kpp = e.Kpp();
     const size_t Mt = 2 * Bm * Tm, Mv = Bm * P, Bt = 2 * Bm;
     const size_t Z = e.esz();      // bytes per activation / GEMM-operand element: 2 (bf16, f16) or 4 (bf16x3 parity mode)
     Carver w;
-    auto w16 = [&](std::vector<LayerW16>& v, int n, bool transposed) {
+    auto w16 = [&](std::vector<LayerW16>& v, int n, bool transposed, size_t H, size_t I) {
         v.resize(n);
         for (auto& L : v) {
             L.qkv = w.take(3 * H * H * Z); L.ao = w.take(H * H * Z); L.fc1 = w.take(I * H * Z); L.fc2 = w.take(H * I * Z);
             if (transposed) { L.qkvT = w.take(3 * H * H * Z); L.aoT = w.take(H * H * Z); L.fc1T = w.take(I * H * Z); L.fc2T = w.take(H * I * Z); }
         }
     };
-    w16(e.vit_w16, c.layers_img, false);
-    w16(e.txt_w16, c.layers_txt, true);
-    e.patch_w16 = w.take(H * 3 * c.patch * c.patch * Z);
+    w16(e.vit_w16, c.layers_img, false, Hv, Iv);
+    w16(e.txt_w16, c.layers_txt, true, H, I);
+    e.patch_w16 = w.take(Hv * Kpp * Z);
     e.ids_all = w.take(Bt * Tm * 8); e.mask_all = w.take(Bt * Tm * 8); e.pos_ids = w.take(Bt * Tm * 4); e.maskbias = w.take(Bt * Tm * 4);
     e.x0 = w.take(Mt * H * Z); e.xhat_emb = w.take(Mt * H * Z); e.rstd_emb = w.take(Mt * 4);
     e.tact.resize(c.layers_txt);
@@ -247,9 +297,9 @@ void build_workspace(mmhip_engine& e) {
         a.mean1 = w.take(Mt * 4); a.rstd1 = w.take(Mt * 4); a.mean2 = w.take(Mt * 4); a.rstd2 = w.take(Mt * 4);
         a.lse = w.take(Bt * c.heads * Tm * 4);
     }
-    e.v_patches = w.take(Bm * (P - 1) * 3 * c.patch * c.patch * Z); e.v_pe = w.take(Bm * (P - 1) * H * Z);
-    e.v_x = w.take(Mv * H * Z); e.v_ln = w.take(Mv * H * Z); e.v_qkv = w.take(Mv * 3 * H * Z); e.v_ctx = w.take(Mv * H * Z);
-    e.v_h = w.take(Mv * I * Z); e.v_out = w.take(Mv * H * Z);
+    e.v_patches = w.take(Bm * (P - 1) * Kpp * Z); e.v_pe = w.take(Bm * (P - 1) * Hv * Z);
+    e.v_x = w.take(Mv * Hv * Z); e.v_ln = w.take(Mv * Hv * Z); e.v_qkv = w.take(Mv * 3 * Hv * Z); e.v_ctx = w.take(Mv * Hv * Z);
+    e.v_h = w.take(Mv * Iv * Z); e.v_out = w.take(Mv * Hv * Z);
     e.g_dx = w.take(Mt * H * Z); e.g_dx2 = w.take(Mt * H * Z); e.g_dpre = w.take(Mt * H * Z); e.g_ddrop = w.take(Mt * H * Z); e.g_dpre1 = w.take(Mt * H * Z); e.g_ddrop1 = w.take(Mt * H * Z);
     e.g_dqkv = w.take(Mt * 3 * H * Z); e.g_dctx = w.take(Mt * H * Z); e.g_du = w.take(Mt * I * Z);
     e.g_set[0][0] = e.g_dpre; e.g_set[0][1] = e.g_ddrop; e.g_set[0][2] = e.g_du; e.g_set[0][3] = e.g_dpre1; e.g_set[0][4] = e.g_ddrop1; e.g_set[0][5] = e.g_dqkv;
@@ -265,12 +315,12 @@ void build_workspace(mmhip_engine& e) {
             for (int j = 0; j < 2; ++j) e.g_lnp[i][j] = w.take(partial_floats_rows((int)Mt, (int)H, 2) * 4);
     }
     auto f = [&](size_t n) { return w.take(n * 4); };
-    e.h_vpool = f(Bm * H); e.h_tpool = f(Bm * H); e.h_txt_e = f(Bm * E); e.h_img_e = f(Bm * E); e.h_txt_n = f(Bm * E); e.h_img_n = f(Bm * E);
+    e.h_vpool = f(Bm * Hv); e.h_tpool = f(Bm * H); e.h_txt_e = f(Bm * E); e.h_img_e = f(Bm * E); e.h_txt_n = f(Bm * E); e.h_img_n = f(Bm * E);
     e.h_txt_inv = f(Bm); e.h_img_inv = f(Bm); e.h_logits = f(Bm * Bm);
-    e.h_q = f(Bt * H); e.h_qk = f(Bt * H); e.h_prob = f(Bt * P); e.h_xbar = f(Bt * H); e.h_z = f(Bt * 2 * H); e.h_feats = f(Bt * H);
+    e.h_q = f(Bt * H); e.h_qk = f(Bt * H); e.h_prob = f(Bt * P); e.h_xbar = f(Bt * H); e.h_z = f(Bt * (H + Hv)); e.h_feats = f(Bt * H);
     e.h_featd = f(Bm * H); e.h_out_cls = f(Bm * C); e.h_out_tim = f(Bm * 2);
     e.h_d_out_cls = f(Bm * C); e.h_d_logits = f(Bm * Bm); e.h_d_out_tim = f(Bm * 2); e.h_dfeats = f(Bt * H); e.h_dpre = f(Bt * H);
-    e.h_dz = f(Bt * 2 * H); e.h_dxcls = f(Bt * H); e.h_dxbar = f(Bt * H); e.h_dqk = f(Bt * H); e.h_dq = f(Bt * H);
+    e.h_dz = f(Bt * (H + Hv)); e.h_dxcls = f(Bt * H); e.h_dxbar = f(Bt * H); e.h_dqk = f(Bt * H); e.h_dq = f(Bt * H);
     e.h_dtxt_e = f(Bm * E); e.h_dimg_e = f(Bm * E); e.h_dtpool = f(Bm * H); e.h_dprepool = f(Bm * H); e.h_loss = f(8);
     e.ws_need = w.off;
 }
@@ -299,6 +349,7 @@ struct G {
     }
     G& bias(const float* b) { a.bias = b; a.flags |= GEMM_BIAS; return *this; }
     G& gelu() { a.flags |= GEMM_GELU; return *this; }
+    G& qgelu() { a.flags |= GEMM_QGELU; return *this; }
     G& aux(void* p, int ld) { a.aux = p; a.ldaux = ld; a.flags |= GEMM_AUX_PRE; return *this; }
     G& residual(const void* p, int ld) { a.residual = p; a.ldres = ld; a.flags |= GEMM_RESIDUAL; return *this; }
     G& mul_gelu_grad(const void* p, int ld) { a.mul_in = p; a.ldmul = ld; a.flags |= GEMM_MUL_GELU_GRAD; return *this; }
@@ -354,8 +405,7 @@ int side_init(mmhip_engine& e) {
 inline bool use_side(const mmhip_engine& e) { return e.overlap > 0 && e.side && e.timing != 2; }
 
 // ------------------------------------------------------------------------------------------------ weights
-int refresh_layer(mmhip_engine& e, const float* base, const LayerOff& o, const LayerW16& w, bool transposed, hipStream_t s) {
-    const int H = e.cfg.hidden, I = e.cfg.inter;
+int refresh_layer(mmhip_engine& e, const float* base, const LayerOff& o, const LayerW16& w, bool transposed, hipStream_t s, int H, int I) {
     CastMat m[4] = {{base + o.qkv_w, e.ws + w.qkv, transposed ? e.ws + w.qkvT : nullptr, 3 * H, H, 0},
                     {base + o.ao_w, e.ws + w.ao, transposed ? e.ws + w.aoT : nullptr, H, H, 0},
                     {base + o.fc1_w, e.ws + w.fc1, transposed ? e.ws + w.fc1T : nullptr, I, H, 0},
@@ -367,17 +417,22 @@ int refresh_layer(mmhip_engine& e, const float* base, const LayerOff& o, const L
 // ------------------------------------------------------------------------------------------------ forward pieces
 int vit_forward(mmhip_engine& e, const float* pixels, hipStream_t s) {
     const mmhip_config& c = e.cfg;
-    const int H = c.hidden, I = c.inter, B = e.B, np = c.image / c.patch, P = np * np + 1, Kp = 3 * c.patch * c.patch, dt = e.dt();
+    const int H = e.Hv(), I = e.Iv(), B = e.B, P = e.P(), Kpp = e.Kpp(), dt = e.dt();
     const int Mv = B * P;
+    const bool clip = e.clip();
     const float* F = e.frozen;
-    CHECK_HIP(launch_patchify(pixels, e.ws + e.v_patches, B, c.image, c.patch, dt, s));
+    CHECK_HIP(launch_patchify(pixels, e.ws + e.v_patches, B, c.image, c.patch, Kpp, dt, s));
     {
-        G g(e.ws + e.v_patches, Kp, e.ws + e.patch_w16, Kp, e.ws + e.v_pe, H, B * (P - 1), H, Kp);
-        g.bias(F + e.v_patch_b);
+        G g(e.ws + e.v_patches, Kpp, e.ws + e.patch_w16, Kpp, e.ws + e.v_pe, H, B * (P - 1), H, Kpp);
+        if (!clip) g.bias(F + e.v_patch_b);           // CLIP's patch conv has no bias
         if (int r = run_gemm(e, g, s)) return r;
     }
     CHECK_HIP(launch_vit_assemble(e.ws + e.v_pe, F + e.v_cls, F + e.v_pos, e.ws + e.v_x, B, P, H, dt, s));
     char* x = e.ws + e.v_x;
+    if (clip) {      // pre_layrnorm, in place (HF:models/clip/modeling_clip.py CLIPVisionTransformer.forward)
+        LNArgs ln{x, x, F + e.v_pre_ln_w, F + e.v_pre_ln_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+        CHECK_HIP(launch_layernorm_fwd(ln, dt, s));
+    }
     // 768-wide outputs of M = B*197 rows: 160-row tiles (474 tiles = one round of the 512 block slots, instead of 594 of
     // 128x128 or 300 one-per-CU 256x128) are faster when this tower runs alone (serial: -0.4 ms/step) but not beside the text
     // tower (same-box, image tower on its high-priority stream: +0.2 ms/step) -- opt-in: MMHIP_VIT_TILE160=1
@@ -392,14 +447,22 @@ int vit_forward(mmhip_engine& e, const float* pixels, hipStream_t s) {
         { G g(e.ws + e.v_ln, H, e.ws + w.qkv, H, e.ws + e.v_qkv, 3 * H, Mv, 3 * H, H); g.bias(F + o.qkv_b); if (int r = run_gemm(e, g, s)) return r; }
         AttnArgs at;
         memset(&at, 0, sizeof(at));
-        at.qkv = e.ws + e.v_qkv; at.ctx = e.ws + e.v_ctx; at.posts = B; at.S = P; at.heads = c.heads; at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
-        at.scale = 1.0f / sqrtf((float)(H / c.heads));
+        at.qkv = e.ws + e.v_qkv; at.ctx = e.ws + e.v_ctx; at.posts = B; at.S = P; at.heads = e.heads_v(); at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
+        at.scale = 1.0f / sqrtf((float)(H / e.heads_v()));
         CHECK_HIP(launch_attn_fwd(at, dt, s));
         { G g(e.ws + e.v_ctx, H, e.ws + w.ao, H, x, H, Mv, H, H); g.bias(F + o.ao_b).residual(x, H); g.a.tile = narrow_tile; if (int r = run_gemm(e, g, s)) return r; }
         LNArgs ln2{x, e.ws + e.v_ln, F + o.ln2_w, F + o.ln2_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
         CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
-        { G g(e.ws + e.v_ln, H, e.ws + w.fc1, H, e.ws + e.v_h, I, Mv, I, H); g.bias(F + o.fc1_b).gelu(); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_ln, H, e.ws + w.fc1, H, e.ws + e.v_h, I, Mv, I, H); g.bias(F + o.fc1_b); if (clip) g.qgelu(); else g.gelu(); if (int r = run_gemm(e, g, s)) return r; }
         { G g(e.ws + e.v_h, I, e.ws + w.fc2, I, x, H, Mv, H, I); g.bias(F + o.fc2_b).residual(x, H); g.a.tile = narrow_tile; if (int r = run_gemm(e, g, s)) return r; }
+    }
+    if (clip) {
+        // last_hidden_state = the encoder output as it is; pooler_output = post_layernorm(CLS row)   (CLIPVisionTransformer.forward)
+        CHECK_HIP(hipMemcpyAsync(e.ws + e.v_out, x, (size_t)Mv * H * e.esz(), hipMemcpyDeviceToDevice, s));
+        CHECK_HIP(launch_gather_rows_f32(x, (size_t)P * H, e.wsp<float>(e.h_vpool), H, B, H, dt, s));
+        LNArgs lnp{e.wsp<float>(e.h_vpool), e.wsp<float>(e.h_vpool), F + e.v_ln_w, F + e.v_ln_b, nullptr, nullptr, B, H, H, H, c.ln_eps_img};
+        CHECK_HIP(launch_layernorm_fwd(lnp, DT_F32, s));
+        return 0;
     }
     LNArgs lnf{x, e.ws + e.v_out, F + e.v_ln_w, F + e.v_ln_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
     CHECK_HIP(launch_layernorm_fwd(lnf, dt, s));
@@ -466,33 +529,33 @@ const char* text_last(const mmhip_engine& e) { return e.cfg.layers_txt ? e.ws + 
 int heads_forward(mmhip_engine& e, float* out_cls, float* logits, float* out_tim, float* feats_out, hipStream_t s) {
     const mmhip_config& c = e.cfg;
     const int H = c.hidden, E = c.proj_dim, C = c.num_labels, T = e.T, B = e.B, Bt = e.Bt, dt = e.dt();
-    const int P = (c.image / c.patch) * (c.image / c.patch) + 1;
+    const int P = e.P(), Hv = e.Hv(), ZW = H + Hv;     // z = [x_t CLS | image feature]: H + Hv wide
     const float* W = e.train;
     const char* xt = text_last(e);
     const int cs = e.cls_compact ? H : T * H;           // row stride of the CLS rows of the last hidden state
     // text pooler (first B posts) and ITC similarity -- HF dual encoder :261-274
     CHECK_HIP(launch_small_nt(small(xt, cs, W + e.t_pool_w, H, W + e.t_pool_b, e.wsp<float>(e.h_tpool), H, B, H, H, ACT_TANH), dt, s));
     CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_tpool), H, W + e.tproj_w, H, nullptr, e.wsp<float>(e.h_txt_e), E, B, E, H), DT_F32, s));
-    CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_vpool), H, W + e.vproj_w, H, nullptr, e.wsp<float>(e.h_img_e), E, B, E, H), DT_F32, s));
+    CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_vpool), Hv, W + e.vproj_w, Hv, nullptr, e.wsp<float>(e.h_img_e), E, B, E, Hv), DT_F32, s));
     ItcArgs it{e.wsp<float>(e.h_txt_e), e.wsp<float>(e.h_img_e), W + e.logit_scale, e.wsp<float>(e.h_txt_n), e.wsp<float>(e.h_img_n),
                e.wsp<float>(e.h_txt_inv), e.wsp<float>(e.h_img_inv), e.wsp<float>(e.h_logits), B, E};
     CHECK_HIP(launch_itc_fwd(it, s));
     // z = [x_t[:,0] | fused image feature]
     float* z = e.wsp<float>(e.h_z);
-    CHECK_HIP(launch_gather_rows_f32(xt, (size_t)cs, z, 2 * H, Bt, H, dt, s));
+    CHECK_HIP(launch_gather_rows_f32(xt, (size_t)cs, z, ZW, Bt, H, dt, s));
     if (c.fusion == MMHIP_FUSION_ATTENTION) {
         CHECK_HIP(launch_small_nt(small(xt, cs, W + e.fq_w, H, W + e.fq_b, e.wsp<float>(e.h_q), H, Bt, H, H), dt, s));
         CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_q), H, W + e.fk_w, H, nullptr, e.wsp<float>(e.h_qk), H, Bt, H, H), s));
         FusionAttnArgs fa{e.wsp<float>(e.h_qk), e.ws + e.v_out, e.wsp<float>(e.h_prob), e.wsp<float>(e.h_xbar), Bt, B, P, H, 1.0f / sqrtf((float)H)};
         CHECK_HIP(launch_fusion_attn_fwd(fa, dt, s));
-        CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_xbar), H, W + e.fv_w, H, W + e.fv_b, z + H, 2 * H, Bt, H, H), DT_F32, s));
+        CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_xbar), H, W + e.fv_w, H, W + e.fv_b, z + H, ZW, Bt, H, H), DT_F32, s));
     } else {
         // concat: image CLS row of post bt % B -- two strided copies (original rows, ITM rows)
-        CHECK_HIP(launch_gather_rows_f32(e.ws + e.v_out, (size_t)P * H, z + H, 2 * H, B, H, dt, s));
-        if (Bt > B) CHECK_HIP(launch_gather_rows_f32(e.ws + e.v_out, (size_t)P * H, z + (size_t)B * 2 * H + H, 2 * H, B, H, dt, s));
+        CHECK_HIP(launch_gather_rows_f32(e.ws + e.v_out, (size_t)P * Hv, z + H, ZW, B, Hv, dt, s));
+        if (Bt > B) CHECK_HIP(launch_gather_rows_f32(e.ws + e.v_out, (size_t)P * Hv, z + (size_t)B * ZW + H, ZW, B, Hv, dt, s));
     }
     float* feats = e.wsp<float>(e.h_feats);
-    CHECK_HIP(launch_small_nt(small(z, 2 * H, W + e.fus_w, 2 * H, W + e.fus_b, feats, H, Bt, H, 2 * H, ACT_RELU), DT_F32, s));
+    CHECK_HIP(launch_small_nt(small(z, ZW, W + e.fus_w, ZW, W + e.fus_b, feats, H, Bt, H, ZW, ACT_RELU), DT_F32, s));
     CHECK_HIP(launch_elementwise(EW_DROPOUT, feats, nullptr, e.wsp<float>(e.h_featd), (size_t)B * H, 0.f,
                                  make_drop(c.p_head, e.seed, STREAM_HEAD, e.train_mode), s));
     CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_featd), H, W + e.cls_w, H, W + e.cls_b, e.wsp<float>(e.h_out_cls), C, B, C, H), DT_F32, s));
@@ -508,7 +571,7 @@ int heads_forward(mmhip_engine& e, float* out_cls, float* logits, float* out_tim
 int heads_backward(mmhip_engine& e, hipStream_t s) {
     const mmhip_config& c = e.cfg;
     const int H = c.hidden, E = c.proj_dim, C = c.num_labels, T = e.T, B = e.B, Bt = e.Bt, dt = e.dt();
-    const int P = (c.image / c.patch) * (c.image / c.patch) + 1;
+    const int P = e.P(), Hv = e.Hv(), ZW = H + Hv;     // z = [x_t CLS | image feature]: H + Hv wide
     const float* W = e.train;
     float* Gd = e.grad;
     const float* d_out_cls = e.bd_out_cls ? e.bd_out_cls : e.wsp<float>(e.h_d_out_cls);
@@ -537,24 +600,24 @@ int heads_backward(mmhip_engine& e, hipStream_t s) {
     // feats = relu(linear_fusion(z))
     float* dpre = e.wsp<float>(e.h_dpre);
     CHECK_HIP(launch_elementwise(EW_RELU_BWD, dfeats, feats, dpre, (size_t)Bt * H, 0.f, nodrop, s));
-    CHECK_HIP(launch_small_tn(small(dpre, H, z, 2 * H, nullptr, Gd + e.fus_w, 2 * H, Bt, 2 * H, 0, 0, 1), DT_F32, H, s));
+    CHECK_HIP(launch_small_tn(small(dpre, H, z, ZW, nullptr, Gd + e.fus_w, ZW, Bt, ZW, 0, 0, 1), DT_F32, H, s));
     CHECK_HIP(launch_bias_grad_f32(dpre, Bt, H, H, Gd + e.fus_b, 1, s));
     float* dz = e.wsp<float>(e.h_dz);
-    CHECK_HIP(launch_small_nn(small(dpre, H, W + e.fus_w, 2 * H, nullptr, dz, 2 * H, Bt, 2 * H, H), s));
+    CHECK_HIP(launch_small_nn(small(dpre, H, W + e.fus_w, ZW, nullptr, dz, ZW, Bt, ZW, H), s));
     // d x_t[:,0] starts as dz[:, :H]
-    CHECK_HIP(hipMemcpy2DAsync(dxcls, (size_t)H * 4, dz, (size_t)2 * H * 4, (size_t)H * 4, Bt, hipMemcpyDeviceToDevice, s));
+    CHECK_HIP(hipMemcpy2DAsync(dxcls, (size_t)H * 4, dz, (size_t)ZW * 4, (size_t)H * 4, Bt, hipMemcpyDeviceToDevice, s));
     if (c.fusion == MMHIP_FUSION_ATTENTION) {
-        const float* dctx = dz + H;      // ld 2H
+        const float* dctx = dz + H;      // ld ZW
         float* q = e.wsp<float>(e.h_q);
-        CHECK_HIP(launch_small_tn(small(dctx, 2 * H, e.wsp<float>(e.h_xbar), H, nullptr, Gd + e.fv_w, H, Bt, H, 0, 0, 1), DT_F32, H, s));
-        CHECK_HIP(launch_bias_grad_f32(dctx, Bt, H, 2 * H, Gd + e.fv_b, 1, s));
-        CHECK_HIP(launch_small_nn(small(dctx, 2 * H, W + e.fv_w, H, nullptr, e.wsp<float>(e.h_dxbar), H, Bt, H, H), s));
+        CHECK_HIP(launch_small_tn(small(dctx, ZW, e.wsp<float>(e.h_xbar), H, nullptr, Gd + e.fv_w, H, Bt, H, 0, 0, 1), DT_F32, H, s));
+        CHECK_HIP(launch_bias_grad_f32(dctx, Bt, H, ZW, Gd + e.fv_b, 1, s));
+        CHECK_HIP(launch_small_nn(small(dctx, ZW, W + e.fv_w, H, nullptr, e.wsp<float>(e.h_dxbar), H, Bt, H, H), s));
         FusionAttnBwdArgs fb{e.wsp<float>(e.h_dxbar), e.wsp<float>(e.h_prob), e.ws + e.v_out, e.wsp<float>(e.h_dqk), Bt, B, P, H, 1.0f / sqrtf((float)H)};
         CHECK_HIP(launch_fusion_attn_bwd(fb, dt, s));
         // qk = q . W_K  ->  dW_K[o][i] = sum q[:,o] dqk[:,i];  dq = dqk . W_K^T ;  fc_K.bias gets an exactly-zero gradient
         CHECK_HIP(launch_small_tn(small(q, H, e.wsp<float>(e.h_dqk), H, nullptr, Gd + e.fk_w, H, Bt, H, 0, 0, 1), DT_F32, H, s));
         CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_dqk), H, W + e.fk_w, H, nullptr, e.wsp<float>(e.h_dq), H, Bt, H, H), DT_F32, s));
-        CHECK_HIP(launch_small_tn(small(e.wsp<float>(e.h_dq), H, z, 2 * H, nullptr, Gd + e.fq_w, H, Bt, H, 0, 0, 1), DT_F32, H, s));
+        CHECK_HIP(launch_small_tn(small(e.wsp<float>(e.h_dq), H, z, ZW, nullptr, Gd + e.fq_w, H, Bt, H, 0, 0, 1), DT_F32, H, s));
         CHECK_HIP(launch_bias_grad_f32(e.wsp<float>(e.h_dq), Bt, H, H, Gd + e.fq_b, 1, s));
         CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_dq), H, W + e.fq_w, H, nullptr, dxcls, H, Bt, H, H, ACT_NONE, 1), s));
     }
@@ -563,10 +626,10 @@ int heads_backward(mmhip_engine& e, hipStream_t s) {
                       e.wsp<float>(e.h_img_inv), W + e.logit_scale, e.wsp<float>(e.h_dtxt_e), e.wsp<float>(e.h_dimg_e), Gd + e.logit_scale, B, E};
         CHECK_HIP(launch_itc_bwd(ib, s));
         CHECK_HIP(launch_small_tn(small(e.wsp<float>(e.h_dtxt_e), E, e.wsp<float>(e.h_tpool), H, nullptr, Gd + e.tproj_w, H, B, H, 0, 0, 1), DT_F32, E, s));
-        CHECK_HIP(launch_small_tn(small(e.wsp<float>(e.h_dimg_e), E, e.wsp<float>(e.h_vpool), H, nullptr, Gd + e.vproj_w, H, B, H, 0, 0, 1), DT_F32, E, s));
+        CHECK_HIP(launch_small_tn(small(e.wsp<float>(e.h_dimg_e), E, e.wsp<float>(e.h_vpool), Hv, nullptr, Gd + e.vproj_w, Hv, B, Hv, 0, 0, 1), DT_F32, E, s));
         CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_dtxt_e), E, W + e.tproj_w, H, nullptr, e.wsp<float>(e.h_dtpool), H, B, H, E), s));
         CHECK_HIP(launch_elementwise(EW_TANH_BWD, e.wsp<float>(e.h_dtpool), e.wsp<float>(e.h_tpool), e.wsp<float>(e.h_dprepool), (size_t)B * H, 0.f, nodrop, s));
-        CHECK_HIP(launch_small_tn(small(e.wsp<float>(e.h_dprepool), H, z, 2 * H, nullptr, Gd + e.t_pool_w, H, B, H, 0, 0, 1), DT_F32, H, s));
+        CHECK_HIP(launch_small_tn(small(e.wsp<float>(e.h_dprepool), H, z, ZW, nullptr, Gd + e.t_pool_w, H, B, H, 0, 0, 1), DT_F32, H, s));
         CHECK_HIP(launch_bias_grad_f32(e.wsp<float>(e.h_dprepool), B, H, H, Gd + e.t_pool_b, 1, s));
         CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_dprepool), H, W + e.t_pool_w, H, nullptr, dxcls, H, B, H, H, ACT_NONE, 1), s));
     }
@@ -717,8 +780,16 @@ int mmhip_create(const mmhip_config* cfg, mmhip_handle* out) {
     if (!cfg || !out) return MMHIP_E_INVALID;
     const mmhip_config& c = *cfg;
     if (c.hidden <= 0 || c.hidden % 64 || c.hidden > 1024 || c.heads * 64 != c.hidden || c.inter % 128 || c.hidden % 128) return MMHIP_E_INVALID;
-    if (c.image % c.patch || c.patch % 8 || (3 * c.patch * c.patch) % 64) return MMHIP_E_INVALID;
-    if ((c.image / c.patch) * (c.image / c.patch) + 1 > 224) return MMHIP_E_INVALID;
+    {   // image tower: ViT (HF ViTModel) or CLIP vision (HF CLIPVisionModel), its own width allowed (CLIP-ViT-L/14: 1024 / 16 / 4096)
+        const int hv = c.hidden_img > 0 ? c.hidden_img : c.hidden, iv = c.inter_img > 0 ? c.inter_img : c.inter, nh = c.heads_img > 0 ? c.heads_img : c.heads;
+        if (c.img_kind != MMHIP_IMG_VIT && c.img_kind != MMHIP_IMG_CLIP) return MMHIP_E_INVALID;
+        if (hv % 128 || hv > 1024 || nh * 64 != hv || iv % 128 || c.patch < 2 || c.image % c.patch) return MMHIP_E_INVALID;
+        if (c.fusion == MMHIP_FUSION_ATTENTION && hv != c.hidden) return MMHIP_E_INVALID;       // fc_K / fc_V are hidden x hidden (mm_late.py:74-75)
+        // attention keeps the K / V of a head in LDS: 608 keys of 64 x 16 bit fill the 160 KB of a CU (336 / 14 -> 577 tokens);
+        // the fp32 parity-mode attention holds 4-byte K / V: 288 keys
+        const int P = (c.image / c.patch) * (c.image / c.patch) + 1;
+        if (P > (c.dtype == MMHIP_BF16X3 ? 288 : 608)) return MMHIP_E_INVALID;
+    }
     if (c.max_text_len > 128 || c.max_text_len < 1 || c.max_posts < 1 || c.max_posts > 1024) return MMHIP_E_INVALID;
     if (c.dtype != MMHIP_BF16 && c.dtype != MMHIP_F16 && c.dtype != MMHIP_BF16X3) return MMHIP_E_INVALID;
     if (c.num_labels < 1 || c.num_labels > 64 || c.proj_dim < 1 || c.proj_dim > 1024) return MMHIP_E_INVALID;
@@ -766,12 +837,13 @@ int mmhip_refresh_weights(mmhip_handle h, int which, void* stream) {
     mmhip_engine& e = *h;
     if (which & 1) {
         for (int l = 0; l < e.cfg.layers_img; ++l)
-            if (int r = refresh_layer(e, e.frozen, e.vit[l], e.vit_w16[l], false, s)) return r;
-        CHECK_HIP(launch_cast(e.frozen + e.v_patch_w, e.ws + e.patch_w16, (size_t)e.cfg.hidden * 3 * e.cfg.patch * e.cfg.patch, e.dt(), s));
+            if (int r = refresh_layer(e, e.frozen, e.vit[l], e.vit_w16[l], false, s, e.Hv(), e.Iv())) return r;
+        // patch-embedding weight [Hv, 3*p*p], rows zero-padded to the GEMM's k-step (14 x 14 patches: 588 -> 640)
+        CHECK_HIP(launch_cast_pad(e.frozen + e.v_patch_w, e.ws + e.patch_w16, e.Hv(), e.Kp(), e.Kpp(), e.dt(), s));
     }
     if (which & 2)
         for (int l = 0; l < e.cfg.layers_txt; ++l)
-            if (int r = refresh_layer(e, e.train, e.txt[l], e.txt_w16[l], true, s)) return r;
+            if (int r = refresh_layer(e, e.train, e.txt[l], e.txt_w16[l], true, s, e.cfg.hidden, e.cfg.inter)) return r;
     return 0;
 }
 
@@ -840,7 +912,7 @@ __global__ __launch_bounds__(256) void vision_copy_kernel(int to_cache, const in
     }
 }
 int vision_copy(mmhip_engine& e, int to_cache, const int64_t* slots, void* cache, uint64_t cache_records, int B, hipStream_t s) {
-    const int P = (e.cfg.image / e.cfg.patch) * (e.cfg.image / e.cfg.patch) + 1, H = e.cfg.hidden;
+    const int P = e.P(), H = e.Hv();
     const uint32_t tok_bytes = (uint32_t)(P * H * e.esz()), pool_bytes = (uint32_t)H * 4;
     if (tok_bytes % 16 || pool_bytes % 16) return MMHIP_E_INVALID;
     hipLaunchKernelGGL(vision_copy_kernel, dim3(16, B), dim3(256), 0, s, to_cache, slots, (char*)cache, mmhip_vision_record_bytes(&e), cache_records,
@@ -852,7 +924,7 @@ int vision_copy(mmhip_engine& e, int to_cache, const int64_t* slots, void* cache
 uint64_t mmhip_vision_record_bytes(mmhip_handle h) {
     if (!h) return 0;
     const uint64_t P = (uint64_t)(h->cfg.image / h->cfg.patch) * (h->cfg.image / h->cfg.patch) + 1;
-    return (P * h->cfg.hidden * h->esz() + (uint64_t)h->cfg.hidden * 4 + 255) & ~255ull;
+    return (P * h->Hv() * h->esz() + (uint64_t)h->Hv() * 4 + 255) & ~255ull;
 }
 int mmhip_vision_export(mmhip_handle h, const int64_t* slots, void* cache, uint64_t cache_records, void* stream) {
     if (!h || !h->ws || !h->fwd_done) return MMHIP_E_STATE;

@@ -253,6 +253,10 @@ void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
             }
+            if (fl & GEMM_QGELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = mm_qgelu(v[e]);
+            }
             if (fl & GEMM_MUL_GELU_GRAD) {
                 v8 u = pre[ch][p];
                 if (!pre_mul) u = *reinterpret_cast<const v8*>((const T*)a.mul_in + (size_t)m * a.ldmul + n);
@@ -546,6 +550,7 @@ __global__ __launch_bounds__(256) void slow_nt_kernel(GemmNTArgs a) {
     if (fl & GEMM_AUX_PRE) ((T*)a.aux)[(size_t)m * a.ldaux + n] = from_f<T>(v);
     if (fl & GEMM_GELU) v = mm_gelu(v);
     if (fl & GEMM_TANH) v = tanhf(v);
+    if (fl & GEMM_QGELU) v = mm_qgelu(v);
     if (fl & GEMM_MUL_GELU_GRAD) v *= mm_gelu_grad(to_f<T>(((const T*)a.mul_in)[(size_t)m * a.ldmul + n]));
     if ((fl & GEMM_DROPOUT) && a.drop.thresh16) v = mm_keep((uint32_t)m * (uint32_t)(a.drop_row_mul ? a.drop_row_mul : 1) * (uint32_t)a.N + (uint32_t)n, a.drop) ? v * a.drop.keep_scale : 0.f;
     if (fl & GEMM_RESIDUAL) v += to_f<T>(((const T*)a.residual)[(size_t)m * a.ldres + n]);

@@ -84,6 +84,10 @@ __device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
     }
+    if (EPI == EP_ANY && (fl & GEMM_QGELU)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mm_qgelu(v[e]);
+    }
     if (EPI == EP_MULG) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= mm_gelu_grad(to_f<T>(pre[e]));

@@ -94,6 +94,7 @@ __device__ __forceinline__ float mm_erf(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float mm_gelu(float x) { return 0.5f * x * (1.0f + mm_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float mm_qgelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float mm_gelu_grad(float x) {
     float cdf = 0.5f * (1.0f + mm_erf(x * 0.70710678118654752f));
     float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);

@@ -19,6 +19,7 @@ enum {
     GEMM_AUX_PRE = 32,        // aux[m][n] = value after bias, before the activation (16-bit)
     GEMM_MUL_GELU_GRAD = 64,  // value *= gelu'(mul_in[m][n])
     GEMM_TANH = 128,
+    GEMM_QGELU = 256,         // quick-GELU x * sigmoid(1.702 x)   (HF CLIP hidden_act "quick_gelu")
 };
 struct GemmNTArgs {
     const void* A; const void* B; void* C; void* aux; const float* bias; const void* residual; const void* mul_in;
@@ -129,7 +130,8 @@ struct EmbedBwdArgs {
 hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s);
 hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s);
 
-hipError_t launch_patchify(const float* pixels, void* out, int B, int img, int patch, int dtype, hipStream_t s);
+hipError_t launch_patchify(const float* pixels, void* out, int B, int img, int patch, int ld, int dtype, hipStream_t s);   // rows of ld >= 3*patch^2 columns, zero-padded
+hipError_t launch_cast_pad(const float* src, void* dst, int rows, int cols, int ld, int dtype, hipStream_t s);   // dst[r][0..ld) = cast(src[r][0..cols)), 0 beyond
 hipError_t launch_vit_assemble(const void* patches, const float* cls, const float* pos, void* x, int B, int P, int H, int dtype, hipStream_t s);
 hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, int dtype, hipStream_t s, float* partial = nullptr, float alpha = 1.0f);   // out[c] += sum_r x[r][c]
 size_t partial_floats_rows(int rows, int width, int nvec);

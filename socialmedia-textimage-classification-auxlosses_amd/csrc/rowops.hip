@@ -456,6 +456,33 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         *reinterpret_cast<typename Vec<T>::v8*>(out + prow * K + col) = o;
     }
 }
+// any patch size (14 x 14 for CLIP-ViT-L/14: 588 columns), rows zero-padded to `ld` columns (the GEMM's k-step)
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_any_kernel(const float* __restrict__ px, T* __restrict__ out, int B, int img, int ps, int ld) {
+    const int np = img / ps, K = 3 * ps * ps;
+    const size_t total = (size_t)B * np * np * ld;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int col = idx % ld;
+        const size_t prow = idx / ld;
+        float v = 0.f;
+        if (col < K) {
+            const int c = col / (ps * ps), i = (col / ps) % ps, j = col % ps;
+            const int b = prow / (np * np), py = (prow / np) % np, pxi = prow % np;
+            v = px[(((size_t)b * 3 + c) * img + (py * ps + i)) * img + pxi * ps + j];
+        }
+        out[idx] = from_f<T>(v);
+    }
+}
+// dst[r][0..ld) = cast(src[r][0..cols)), zero beyond cols
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols, int ld) {
+    const size_t total = (size_t)rows * ld;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = idx % ld;
+        const size_t r = idx / ld;
+        dst[idx] = from_f<T>(c < cols ? src[r * cols + c] : 0.f);
+    }
+}
 // x[b*P] = cls + pos[0]; x[b*P + 1 + p] = patches[b*(P-1) + p] + pos[1 + p]      (HF vit :146-157)
 template <typename T>
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const T* __restrict__ patches, const float* __restrict__ cls, const float* __restrict__ pos, T* __restrict__ x, int B, int P, int H) {
@@ -693,9 +720,25 @@ hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s) {
     }
     return hipGetLastError();
 }
-hipError_t launch_patchify(const float* pixels, void* out, int B, int img, int patch, int dtype, hipStream_t s) {
+hipError_t launch_cast_pad(const float* src, void* dst, int rows, int cols, int ld, int dtype, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    if (ld < cols) return hipErrorInvalidValue;
+    const int grid = cap_grid((size_t)rows * ld);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, rows, cols, ld);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(cast_pad_kernel<f16_t>, dim3(grid), dim3(256), 0, s, src, (f16_t*)dst, rows, cols, ld);
+    else hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, rows, cols, ld);
+    return hipGetLastError();
+}
+hipError_t launch_patchify(const float* pixels, void* out, int B, int img, int patch, int ld, int dtype, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (patch % 8 || img % patch) return hipErrorInvalidValue;
+    if (img % patch || ld < 3 * patch * patch) return hipErrorInvalidValue;
+    if (patch % 8 || ld != 3 * patch * patch) {
+        const int grid = cap_grid((size_t)B * (img / patch) * (img / patch) * ld);
+        if (dtype == DT_BF16) hipLaunchKernelGGL(patchify_any_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, pixels, (bf16_t*)out, B, img, patch, ld);
+        else if (dtype == DT_F16) hipLaunchKernelGGL(patchify_any_kernel<f16_t>, dim3(grid), dim3(256), 0, s, pixels, (f16_t*)out, B, img, patch, ld);
+        else hipLaunchKernelGGL(patchify_any_kernel<float>, dim3(grid), dim3(256), 0, s, pixels, (float*)out, B, img, patch, ld);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)B * (img / patch) * (img / patch) * (3 * patch * patch / 8);
     if (dtype == DT_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(cap_grid(total)), dim3(256), 0, s, pixels, (bf16_t*)out, B, img, patch);
     else if (dtype == DT_F16) hipLaunchKernelGGL(patchify_kernel<f16_t>, dim3(cap_grid(total)), dim3(256), 0, s, pixels, (f16_t*)out, B, img, patch);

@@ -95,6 +95,10 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmNTArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
             }
+            if (fl & GEMM_QGELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mm_qgelu(v[e]);
+            }
             if (fl & GEMM_MUL_GELU_GRAD) {
                 const f32x4 u = *reinterpret_cast<const f32x4*>((const float*)a.mul_in + (size_t)m * a.ldmul + n);
 #pragma unroll
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(256) void slow_nt_f32_kernel(GemmNTArgs a) {
     if (fl & GEMM_AUX_PRE) ((float*)a.aux)[(size_t)m * a.ldaux + n] = v;
     if (fl & GEMM_GELU) v = mm_gelu(v);
     if (fl & GEMM_TANH) v = tanhf(v);
+    if (fl & GEMM_QGELU) v = mm_qgelu(v);
     if (fl & GEMM_MUL_GELU_GRAD) v *= mm_gelu_grad(((const float*)a.mul_in)[(size_t)m * a.ldmul + n]);
     if ((fl & GEMM_DROPOUT) && a.drop.thresh16) v = mm_keep((uint32_t)m * (uint32_t)(a.drop_row_mul ? a.drop_row_mul : 1) * (uint32_t)a.N + (uint32_t)n, a.drop) ? v * a.drop.keep_scale : 0.f;
     if (fl & GEMM_RESIDUAL) v += ((const float*)a.residual)[(size_t)m * a.ldres + n];

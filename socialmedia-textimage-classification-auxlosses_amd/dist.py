@@ -82,9 +82,10 @@ def sparse_rows_exchange_finish(state, table_grad, row_state=None):
     for w in works:
         w.wait()
     table_grad.index_fill_(0, own_ids, 0.0)
+    me = rank()
     for r in range(len(ids_all)):
         table_grad.index_add_(0, ids_all[r], pay_all[r])
-        if row_state is not None:
+        if row_state is not None and r != me:        # the own rows were flagged by the backward kernel (padding rows are not)
             row_state[ids_all[r]] = row_state[ids_all[r]] | 1
 
 

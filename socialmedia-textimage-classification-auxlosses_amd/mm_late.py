@@ -45,8 +45,9 @@ def default_arch(txt_model_name, img_model_name):
     if txt_model_name not in TEXT_ARCH:
         raise ValueError(f"text model {txt_model_name!r}: late-fusion path supports {sorted(TEXT_ARCH)}")
     if img_model_name not in IMAGE_ARCH:
-        raise ValueError(f"image model {img_model_name!r}: late-fusion HIP path supports {sorted(IMAGE_ARCH)} (ViT-B/16)")
-    a = dict(hidden=768, heads=12, inter=3072, layers_txt=12, layers_img=12, proj_dim=512, p_hidden=0.1, p_attn=0.1)
+        raise ValueError(f"image model {img_model_name!r}: late-fusion HIP path supports {sorted(IMAGE_ARCH)} (ViT-B/16, CLIP-ViT-L/14)")
+    a = dict(hidden=768, heads=12, inter=3072, layers_txt=12, layers_img=12, proj_dim=512, p_hidden=0.1, p_attn=0.1,
+             img_kind="vit", hidden_img=0, heads_img=0, inter_img=0)
     a.update(TEXT_ARCH[txt_model_name])
     a.update(IMAGE_ARCH[img_model_name])
     return a
@@ -66,6 +67,12 @@ def _read_hf_dir(path):
     elif os.path.isfile(os.path.join(path, "pytorch_model.bin")):
         sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
     return cfg, sd
+
+
+def _clip_key_to_ref(k):
+    """HF CLIPVisionModel state-dict keys -> the dual encoder's 4.25.1 names (CLIPVisionModel wraps its transformer as
+    `.vision_model`: dual_encoder.vision_model.vision_model.*; transformers >= 5 flattens one level)"""
+    return k if k.startswith("vision_model.") else "vision_model." + k
 
 
 def _vit_key_to_ref(k):
@@ -132,9 +139,16 @@ class MM_Model(nn.Module):
                      pad_id=txt_cfg.get("pad_token_id", a["pad_id"]), p_hidden=txt_cfg.get("hidden_dropout_prob", 0.1),
                      p_attn=txt_cfg.get("attention_probs_dropout_prob", 0.1))
         if img_cfg:
+            img_cfg = img_cfg.get("vision_config", img_cfg)            # a full CLIP checkpoint directory nests the tower's config
             a.update(layers_img=img_cfg["num_hidden_layers"], image=img_cfg.get("image_size", 224), patch=img_cfg.get("patch_size", 16),
                      ln_eps_img=img_cfg.get("layer_norm_eps", 1e-12))
+            if a["img_kind"] == "clip":
+                a.update(hidden_img=img_cfg.get("hidden_size", 1024), heads_img=img_cfg.get("num_attention_heads", 16),
+                         inter_img=img_cfg.get("intermediate_size", 4096))
         a.update(arch or {})
+        if fusion_name == "attention" and a["hidden_img"] not in (0, a["hidden"]):
+            raise NotImplementedError("attention fusion needs image tokens as wide as the text tower (fc_K / fc_V are 768 x 768, reference "
+                                      "models/mm_late.py:74-75): use fusion_name='concat' with the CLIP-ViT-L/14 tower")
         self.arch = a
         self.dtype_name = dtype
         self._cfg_kw = dict(hidden=a["hidden"], heads=a["heads"], inter=a["inter"], layers_txt=a["layers_txt"], layers_img=a["layers_img"],
@@ -144,6 +158,8 @@ class MM_Model(nn.Module):
                             proj_dim=a["proj_dim"], num_labels=num_labels,
                             fusion=_lib.FUSION_ATTENTION if fusion_name == "attention" else _lib.FUSION_CONCAT,
                             p_hidden=a["p_hidden"], p_attn=a["p_attn"], p_head=float(dropout),
+                            img_kind=_lib.IMG_CLIP if a["img_kind"] == "clip" else _lib.IMG_VIT, hidden_img=int(a["hidden_img"]),
+                            heads_img=int(a["heads_img"]), inter_img=int(a["inter_img"]),
                             dtype={"bf16": _lib.BF16, "f16": _lib.F16, "bf16x3": _lib.BF16X3}[dtype])
         self._handle = None
         self._capacity = (0, 0)
@@ -157,7 +173,7 @@ class MM_Model(nn.Module):
         if txt_sd is not None:
             self._load_tower(txt_sd, "dual_encoder.text_model.", lambda k: k)
         if img_sd is not None:
-            self._load_tower(img_sd, "dual_encoder.vision_model.", _vit_key_to_ref)
+            self._load_tower(img_sd, "dual_encoder.vision_model.", _clip_key_to_ref if a["img_kind"] == "clip" else _vit_key_to_ref)
         self._refresh_weights(3)
 
     # ------------------------------------------------------------------ engine / buffers
@@ -236,7 +252,7 @@ class MM_Model(nn.Module):
                 if n.startswith("dual_encoder."):
                     if n.endswith("logit_scale"):
                         p.fill_(2.6592)
-                    elif "LayerNorm.weight" in n or ("layernorm" in n and n.endswith("weight")):
+                    elif "LayerNorm.weight" in n or (("layernorm" in n or "layer_norm" in n or "layrnorm" in n) and n.endswith("weight")):
                         p.fill_(1.0)
                     elif n.endswith(".bias"):
                         p.zero_()

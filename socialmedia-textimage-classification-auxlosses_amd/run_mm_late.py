@@ -32,7 +32,8 @@ def build_parser():
     p = argparse.ArgumentParser(description="run late fusion models")
     # reference flags, models/run_mm_late.py:21-43 (names, types, choices, defaults unchanged)
     p.add_argument("--txt_model_name", type=str, choices=["bert", "bernice", "bertweet", "roberta"], help="model name")
-    p.add_argument("--img_model_name", type=str, choices=["vit", "beit", "deit", "resnet50", "resnet152"], help="model name")
+    p.add_argument("--img_model_name", type=str, choices=["vit", "beit", "deit", "resnet50", "resnet152", "clip", "clip336"],
+                   help="model name (clip / clip336: CLIP-ViT-L/14 vision tower at 224 / 336, additive: BASELINE config 4; use --fusion_name concat)")
     p.add_argument("--fusion_name", type=str, choices=["xatt", "concat", "attention", "concat_cnn", "aspect-att", "gmu"], help="fusion method")
     p.add_argument("--use_clip_loss", action="store_true", help="use contrastive Loss")
     p.add_argument("--use_tim_loss", action="store_true", help="use TIM Loss")

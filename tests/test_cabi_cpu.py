@@ -78,7 +78,7 @@ def test_layout_matches_reference_state_dict(lib):
 
 def test_create_rejects_bad_configs(lib):
     h = C.c_void_p()
-    for bad in (dict(hidden=700), dict(heads=8), dict(max_text_len=256), dict(dtype=3), dict(max_pos=64), dict(patch=14)):
+    for bad in (dict(hidden=700), dict(heads=8), dict(max_text_len=256), dict(dtype=3), dict(max_pos=64), dict(patch=15), dict(hidden_img=1000), dict(fusion=1, hidden_img=1024, heads_img=16)):
         cfg = _cfg(**bad)
         assert lib.mmhip_create(C.byref(cfg), C.byref(h)) == -1, bad
     assert lib.mmhip_forward(None, None, None, None, None, None, 1, 1, 0, 0, None, None, None, None, None) == -2

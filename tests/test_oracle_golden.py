@@ -45,6 +45,25 @@ def test_forward_matches_reference(golden_dir, name):
         assert (x - t(z, "txt_cls_per_layer")).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("name", ["clip_small_224", "clip_small_336"])
+def test_clip_vision_tower_matches_hf(golden_dir, name):
+    """BASELINE config 4's image tower: the oracle's CLIPVisionModel restatement against vectors produced by HuggingFace's own
+    VisionTextDualEncoderModel + CLIPVisionModel (tests/golden/make_clip_golden.py); 257 tokens at 224, 577 at 336"""
+    z, cfg = load(golden_dir, name + ".npz")
+    P = O.make_params(cfg, int(z["seed_w"]))
+    ids, mask, pixels, _ = O.synthetic_batch(cfg, int(z["B"]), int(z["T"]), int(z["seed_x"]), True)
+    assert torch.equal(ids, t(z, "ids")) and torch.equal(mask, t(z, "mask"))
+    with torch.no_grad():
+        x_v, v_pool = O.clip_vision_forward(P, pixels, cfg)
+        _, t_pool = O.text_forward(P, ids, mask, cfg)
+        lpt = O.itc_logits(P, t_pool, v_pool)
+    assert x_v.shape[1] == (cfg.image // 14) ** 2 + 1
+    for got, key in ((x_v[:, 0], "v_cls"), (x_v[:, 7], "v_tok7"), (x_v[:, -1], "v_last"), (v_pool, "v_pool"), (t_pool, "t_pool"), (lpt, "logits_per_text")):
+        ref = t(z, key)
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-5, (key, err)
+
+
 def test_train_losses_and_grads_match_reference(golden_dir):
     z, cfg = load(golden_dir, "train_small_xlmr.npz")
     P = {k: v.requires_grad_(O.trainable(k)) for k, v in O.make_params(cfg, int(z["seed_w"])).items()}
