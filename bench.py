@@ -19,7 +19,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic FLOPs per post, BASELINE.md 2 (2*MAC; forward 58.173, backward text 44.695 + heads 0.930; ViT frozen)
-GF_PER_POST = {"plain": 103.798, "aux": 171.528}
+GF_PER_POST = {"plain": 103.798, "aux": 171.528,
+               # BASELINE config 4 (CLIP-ViT-L/14 frozen tower + Bernice, concat): 24 x (2 P (4 Hv^2 + 2 Hv Iv) + 4 P^2 Hv) + patch embed,
+               # Hv = 1024, Iv = 4096, P = 257 (224 px) / 577 (336 px); + text forward 22.347 + text backward 44.695 + heads 0.01
+               "clip224": 229.1, "clip336": 448.9}
 PEAK_TFLOPS = 2500.0        # bf16 / f16 dense MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 
 
@@ -59,11 +62,19 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--aux", action="store_true", help="BASELINE config 3: ITC + ITM auxiliary losses")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4], help="BASELINE.json config index (3 = --aux; 4 = CLIP-ViT-L/14 + concat, bs=32)")
+    ap.add_argument("--image", type=int, default=224, choices=[224, 336], help="config 4: image size (257 / 577 image tokens)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "bf16x3"])
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=0, help="posts per GPU (default: 64; 32 for config 4)")
     ap.add_argument("--txt_model_name", default="bernice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.config == 3:
+        args.aux = True
+    if not args.batch:
+        args.batch = 32 if args.config == 4 else 64
+    img_name = "vit" if args.config != 4 else ("clip" if args.image == 224 else "clip336")
+    fusion = "concat" if args.config == 4 else "attention"
 
     import types
     import numpy as np
@@ -83,7 +94,7 @@ def main():
     B, T, C = args.batch, 128, (3 if args.aux else 2)
     cfg = types.SimpleNamespace(batch_size=B, num_labels=C, use_clip_loss=args.aux, beta_itc=0.1 if args.aux else None,
                                 use_tim_loss=args.aux, beta_itm=0.1 if args.aux else None, max_length=T, dropout=0.05)
-    trainer = MMLate_Model(cfg, args.txt_model_name, "vit", "attention", dtype=args.dtype, seed=0)
+    trainer = MMLate_Model(cfg, args.txt_model_name, img_name, fusion, dtype=args.dtype, seed=0)
     a = trainer.model.arch
     ids, mask, pixels, onehot = synthetic_batch(a["vocab"], C, B, T, 1234 + rank, a["txt_kind"], a["pad_id"], False, a["image"], dev)
     np.random.seed(30 + rank)
@@ -113,6 +124,26 @@ def main():
     ms_step = elapsed / args.steps * 1e3
     posts_s = world * B * args.steps / elapsed
     final_loss = float(loss[0].item())
+
+    # ---- N > 1: what the gradient exchange costs -- bytes on the wire per rank and step, and the step time it leaves exposed
+    # (the same steps timed without the collectives; the replicas diverge, which no longer matters after the timed region)
+    exch = None
+    if world > 1:
+        mmdist.SKIP_EXCHANGE = True
+        for _ in range(2):
+            step_no += 1
+            trainer.train_step(ids, mask, pixels, onehot, None, lr, wd, step_no)
+        sync()
+        t2 = time.perf_counter()
+        nx = max(3, args.steps // 2)
+        for _ in range(nx):
+            step_no += 1
+            trainer.train_step(ids, mask, pixels, onehot, None, lr, wd, step_no)
+        sync()
+        noex_ms = (time.perf_counter() - t2) / nx * 1e3
+        mmdist.SKIP_EXCHANGE = False
+        exch = {"exchange_bytes_per_step": int(trainer.model._last.get("exchange_bytes", 0)), "ms_per_step_without_exchange": round(noex_ms, 3),
+                "exposed_exchange_ms": round(ms_step - noex_ms, 3), "hardware_note": "RCCL path measured only where the driver provides > 1 GPU"}
 
     # ---- extra: forward+backward only (no optimizer / refresh), same batch
     lib, m = _lib.lib(), trainer.model
@@ -165,7 +196,7 @@ def main():
     for tfile in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_gemm_traffic.json")), reverse=True):
         with open(os.path.join(ROOT, "profiles", tfile)) as f:
             tj = json.load(f)
-        if tj.get("csrc_sha256_16") == src_hash and not args.aux and B == 64 and world == 1 and tj.get("dtype", "bf16") == args.dtype:
+        if tj.get("csrc_sha256_16") == src_hash and args.config == 2 and not args.aux and B == 64 and world == 1 and tj.get("dtype", "bf16") == args.dtype:
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/" + tfile
             break
     roofline = {"bound": "mfma", "kernel": "NT GEMM family (gemm_nt_kernel / gemm_nt8_kernel, MFMA 16x16x32, LDS-DMA staged)",
@@ -177,14 +208,16 @@ def main():
                 "algorithmic_flops_per_launch": round(gf / max(1, gl)),
                 "launches_per_step": gl // 2, "avg_launch_us": round(gms * 1e3 / max(1, gl), 2),
                 "gemm_ms_per_step": round(gms / 2, 3), "gemm_ms_per_step_serial": round(gms_serial / 2, 3)}
-    mode = "aux" if args.aux else "plain"
+    mode = ("clip224" if args.image == 224 else "clip336") if args.config == 4 else ("aux" if args.aux else "plain")
     out = {
         "metric": "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion, bs=64",
         "value": round(posts_s, 1), "unit": "posts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("BASELINE config 3: Bernice+ViT-B/16, attention fusion, ITC+ITM, bs=64/GPU" if args.aux else
+        "config": {"workload": (f"BASELINE config 4: CLIP-ViT-L/14 image encoder ({args.image} px) + Bernice, concat fusion, bs={B}/GPU" if args.config == 4 else
+                                "BASELINE config 3: Bernice+ViT-B/16, attention fusion, ITC+ITM, bs=64/GPU" if args.aux else
                                 "BASELINE config 2: Bernice+ViT-B/16, attention fusion, no aux loss, bs=64/GPU"),
+                   "gf_per_post": GF_PER_POST[mode],
                    "step": "full train step: fwd + loss + bwd + grad exchange + AdamW + weight refresh",
                    "posts_per_gpu": B, "text_tokens": T, "image": a["image"], "vocab": a["vocab"], "parallelism": f"dp{world}",
                    "weights": "random-init at true shapes"},
@@ -193,6 +226,8 @@ def main():
         "model_frac_of_peak": round(posts_s / world * GF_PER_POST[mode] / 1e3 / PEAK_TFLOPS, 4),
         "final_loss": round(final_loss, 5), "roofline": roofline,
     }
+    if exch is not None:
+        out["exchange"] = exch
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -36,6 +36,43 @@ def init_from_env(backend=None):
     td.init_process_group(backend=backend)
 
 
+SKIP_EXCHANGE = False      # bench.py only: time the step without its collectives (replicas diverge; never set while training)
+
+
+def shard_eval_loader(dataloader):
+    """rank r's share (items r, r + W, ...) of an evaluation DataLoader, or None when it cannot / need not be sharded.
+    MMHIP_EVAL_SHARD=0 keeps the reference behaviour (every rank evaluates everything)."""
+    W = world_size()
+    ds = getattr(dataloader, "dataset", None)
+    if W == 1 or ds is None or os.environ.get("MMHIP_EVAL_SHARD", "1") == "0" or not hasattr(ds, "__len__"):
+        return None
+    idx = list(range(rank(), len(ds), W))
+    return torch.utils.data.DataLoader(torch.utils.data.Subset(ds, idx), batch_size=dataloader.batch_size, shuffle=False,
+                                       collate_fn=dataloader.collate_fn, num_workers=dataloader.num_workers)
+
+
+def gather_eval(res):
+    """all ranks' eval dicts (data_id / predictions / labels of interleaved shards, per-batch losses) -> the full dict in data-set order
+    on every rank"""
+    W = world_size()
+    parts = [None] * W
+    td.all_gather_object(parts, res)
+    import numpy as np
+    n = sum(len(p["predictions"]) for p in parts)
+    out = {}
+    for key in ("data_id", "predictions", "labels"):
+        if any(len(p[key]) != len(p["predictions"]) for p in parts):
+            out[key] = np.concatenate([p[key] for p in parts]) if parts[0][key] is not None else None
+            continue
+        full = np.zeros(n, dtype=np.asarray(parts[0][key]).dtype)
+        for r, p in enumerate(parts):
+            full[r::W] = p[key]
+        out[key] = full
+    losses = [l for p in parts for l in p["batch_losses"]]
+    out["loss"] = float(np.mean(losses)) if losses else float("nan")
+    return out
+
+
 def force_exchange():
     """MMHIP_FORCE_EXCHANGE=1: run the collectives even at world size 1 (exercises the RCCL call pattern on a one-GPU box)"""
     return os.environ.get("MMHIP_FORCE_EXCHANGE", "0") == "1" and td.is_available() and td.is_initialized()

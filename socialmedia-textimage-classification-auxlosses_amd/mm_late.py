@@ -494,8 +494,8 @@ class MMLate_Model(object):
         cw = None if class_weight is None else class_weight.to(self.device, torch.float32).contiguous()
         loss = torch.empty(4, device=self.device)
         ncorr = torch.empty(1, dtype=torch.int32, device=self.device)
-        exchange = self.world > 1 or mmdist.force_exchange()
-        if not exchange and vision_keys is None and os.environ.get("MMHIP_NATIVE_STEP", "1") != "0":
+        exchange = (self.world > 1 and not mmdist.SKIP_EXCHANGE) or mmdist.force_exchange()
+        if not exchange and self.world == 1 and vision_keys is None and os.environ.get("MMHIP_NATIVE_STEP", "1") != "0":
             # single rank: the whole step is one native call (include/mmhip.h: mmhip_train_step) -- the host enqueues ~250
             # kernels from C++ instead of crossing ctypes ~40 times per step
             return self._native_step(ids, mask, pixel_values, tim_ids, tim_mask, lbl_tim, onehot, cw, lr, weight_decay, step, loss, ncorr)
@@ -638,8 +638,12 @@ class MMLate_Model(object):
         ids_all, preds, labels, losses = [], [], [], []
         w_cls, w_itc, w_itm = self.loss_weights()
         cw = None if class_weight is None else class_weight.to(self.device, torch.float32).contiguous()
+        # data parallel: each rank evaluates its interleaved share of the data set and the predictions are gathered (the
+        # reference evaluates everything in its one process; per-post predictions do not depend on the batch composition,
+        # the reported loss is the mean of the per-batch losses of all ranks)
+        shard = mmdist.shard_eval_loader(dataloader)
         with torch.no_grad():
-            for batch in self._device_batches(dataloader):
+            for batch in self._device_batches(shard if shard is not None else dataloader):
                 ids, mask, px = self._unpack(batch)
                 ids, mask = ids.to(self.device), mask.to(self.device)
                 tim = self.prepare_itm_inputs(ids, mask) if self.use_tim_loss else None
@@ -655,6 +659,12 @@ class MMLate_Model(object):
                 labels.append(onehot.argmax(dim=1))
                 if "data_id" in batch:
                     ids_all.append(batch["data_id"])
-        return {"data_id": torch.cat(ids_all).cpu().numpy() if ids_all else np.zeros(0, dtype=np.int64),
-                "loss": float(torch.cat(losses).mean().item()) if losses else float("nan"),
-                "predictions": torch.cat(preds).cpu().numpy(), "labels": torch.cat(labels).cpu().numpy()}
+        batch_losses = torch.cat(losses).cpu().numpy().tolist() if losses else []
+        res = {"data_id": torch.cat(ids_all).cpu().numpy() if ids_all else np.zeros(0, dtype=np.int64),
+               "loss": float(np.mean(batch_losses)) if batch_losses else float("nan"),
+               "predictions": torch.cat(preds).cpu().numpy() if preds else np.zeros(0, dtype=np.int64),
+               "labels": torch.cat(labels).cpu().numpy() if labels else np.zeros(0, dtype=np.int64)}
+        if shard is not None:
+            res["batch_losses"] = batch_losses
+            res = mmdist.gather_eval(res)
+        return res

@@ -64,6 +64,22 @@ def _worker(rank, world, port, q):
         w_.wait()
     mmdist.BUCKET_BYTES = old
     same = same and bool((flat2 - ref3).abs().max() < 1e-5) and bk.bytes == 64 * 4 and len(bk.works) == 2
+    # sharded evaluation: rank r evaluates items r, r + W, ...; the gathered dict is in data-set order on every rank
+    import numpy as np
+
+    class _DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 11
+
+        def __getitem__(self, i):
+            return {"x": torch.tensor(i)}
+
+    loader = torch.utils.data.DataLoader(_DS(), batch_size=4, shuffle=False)
+    sh = mmdist.shard_eval_loader(loader)
+    mine = np.concatenate([b["x"].numpy() for b in sh])
+    full = mmdist.gather_eval({"data_id": mine + 100, "predictions": mine * 2, "labels": mine % 3, "batch_losses": [float(rank + 1)] * 2, "loss": 0.0})
+    same = same and full["predictions"].tolist() == [2 * i for i in range(11)] and full["data_id"].tolist() == [100 + i for i in range(11)] \
+        and full["labels"].tolist() == [i % 3 for i in range(11)] and abs(full["loss"] - (sum(range(1, world + 1)) / world)) < 1e-9
     touched = (ref2.abs().sum(1) > 0)
     ok_flags = bool(((state[:V] & 1).bool() | ~touched).all())
     q.put((rank, float((table - ref_table).abs().max()), float(max((flat - ref_flat).abs().max(), (table2 - ref2).abs().max())) + (0.0 if ok_flags else 1.0) + (0.0 if same else 2.0)))
