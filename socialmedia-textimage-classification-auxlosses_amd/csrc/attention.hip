@@ -238,12 +238,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
                 const int qt = pair * 2 + t2;
                 if (qt >= qlim) break;
                 const int q0 = qt * 32;
-                const int qrow = min(q0 + r, S - 1);
                 f32x16 sacc = f32x16{}, pacc = f32x16{};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    v8 qf = *reinterpret_cast<const v8*>(qb + (size_t)qrow * a.ld_qkv + 16 * s + 8 * h2);
-                    v8 gf = *reinterpret_cast<const v8*>(dob + (size_t)qrow * a.ld_ctx + 16 * s + 8 * h2);
+                    // row reads of the already-staged Q / dO images (one image serves the row reads here and the transposed reads of
+                    // dV / dK below): the fragments used to come from global memory again, four waves re-reading every query row with
+                    // the load latency exposed in front of each tile's first MFMA.  Image rows past S hold row S-1 (stage_image).
+                    v8 qf = lds_read8<T>(Qtr, trimg_off(q0 + r, 2 * s + h2));
+                    v8 gf = lds_read8<T>(dOtr, trimg_off(q0 + r, 2 * s + h2));
                     sacc = mfma32(qf, kf[s], sacc);      // S[q][key]
                     pacc = mfma32(gf, vf[s], pacc);      // dP[q][key]
                 }

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTArgs a, int pers
         int m0, n0;
         tile_origin(first + t * stride, m0, n0);
         // every load of the epilogue first (bias; residual or mul_in of all the lane's fragments), then compute, then stores.
-        // Rows past M are clamped, not masked: they were computed from (clamped) row M-1 and re-store its values.
+        // Rows past M: loads read (clamped) row M-1, stores are masked -- C may alias the residual (x += f(x) in the image tower),
+        // so a duplicate of row M-1 must never be stored: another wave could read it back as residual.
         const int nb = n0 + wn * C::TN + 8 * kc;
         float bias8[C::FN / 2][8];
 #pragma unroll
@@ -338,11 +339,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTArgs a, int pers
                 const int jp = jc + j2;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int m = min(m0 + wm * 64 + i * 16 + l15, a.M - 1);
+                    const int m = m0 + wm * 64 + i * 16 + l15;
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e] + bias8[jp][e]; v[4 + e] = acc[i][2 * jp + 1][e] + bias8[jp][4 + e]; }
-                    epilogue8<T, EPI>(a, v, m, nb + 32 * jp, pre[i][j2]);
+                    if (m < a.M) epilogue8<T, EPI>(a, v, m, nb + 32 * jp, pre[i][j2]);
                 }
             }
         }

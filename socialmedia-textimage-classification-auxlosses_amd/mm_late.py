@@ -382,6 +382,7 @@ class MM_Model(nn.Module):
         B = self._last["B"]
         dev = self.device_
         self._flat_grad.zero_()
+        self._word_row_state.bitwise_and_(0xFE)
         f = lambda t: None if t is None else t.to(dev, torch.float32).contiguous()
         d_cls = f(d_cls) if d_cls is not None else torch.zeros(B, self.num_labels, device=dev)
         d_lpt, d_tim, d_feats = f(d_lpt), f(d_tim), f(d_feats)
@@ -394,11 +395,16 @@ class MM_Model(nn.Module):
                 out.append(self._flat_grad[inf["offset"]: inf["offset"] + inf["numel"]].view(inf["shape"]).clone())
             else:
                 out.append(None)
-        # leave the entry condition of include/mmhip.h's backward contract behind (the fused step relies on it): no stale
-        # gradients, no stale "row has a gradient" flags
-        self._flat_grad.zero_()
-        self._word_row_state.bitwise_and_(0xFE)
+        # _flat_grad keeps this call's gradient (tests and callers inspect it); the fused step re-establishes the entry condition
+        # of include/mmhip.h's backward contract (zero gradient, no "row has a gradient" flags) when it finds this mark
+        self._grad_dirty = True
         return out
+
+    def _clean_grad(self):
+        if getattr(self, "_grad_dirty", False):
+            self._flat_grad.zero_()
+            self._word_row_state.bitwise_and_(0xFE)
+            self._grad_dirty = False
 
     # ------------------------------------------------------------------ reference interface
     def forward(self, ids, mask, pixel_values, tim_inputs=None, iadds_task=False):
@@ -489,6 +495,7 @@ class MMLate_Model(object):
         tim_ids, tim_mask, lbl_tim = tim if tim is not None else (None, None, None)
         if not m.training:
             m.train()                              # walks ~370 submodules (1.3 ms of host time): only on a mode change
+        m._clean_grad()                            # an autograd-path backward before this step left its gradient in the flat buffer
         w_cls, w_itc, w_itm = self.loss_weights()
         onehot = onehot.to(self.device, torch.int64).contiguous()
         cw = None if class_weight is None else class_weight.to(self.device, torch.float32).contiguous()
