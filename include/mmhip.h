@@ -150,6 +150,14 @@ int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width
 /* register (or with NULL remove) the word-table row flags the backward pass maintains */
 int mmhip_set_row_state(mmhip_handle h, uint8_t* row_state);
 
+/* ---- overflow guard (f16 mode carries the text tower's gradients multiplied by loss_scale; an inf / NaN there would poison the
+ * optimizer state for good).  mmhip_set_nonfinite_counter: a uint32 on the device (zero it yourself); the AdamW entry points
+ * read a non-finite gradient element as 0 -- its moments and parameter only take the decay -- and add to the counter once per
+ * thread that met one.  The caller polls the counter when it reads the loss anyway and reacts: mmhip_set_loss_scale lowers
+ * the scale (0 = back to the default); with bf16 (no scale) a count means a real divergence. */
+int mmhip_set_nonfinite_counter(uint32_t* device_counter);
+int mmhip_set_loss_scale(mmhip_handle h, float loss_scale);
+
 /* ---- one whole training step of MMLate_Model.train (models/mm_late.py:452-491: zero_grad, forward, loss mix, backward,
  * optimizer.step) in ONE call: mmhip_forward(train) + mmhip_loss + mmhip_backward + AdamW over exactly the parameter ranges
  * that receive a gradient for this flag set (torch.optim.AdamW skips `grad is None` tensors: never-used heads always; the ITC

@@ -60,6 +60,8 @@ _SIGS = {
     "mmhip_adamw": (I, [P, P, P, P, U64, F, F, F, F, F, I, F, I, P]),
     "mmhip_adamw_rows": (I, [P, P, P, P, I, I, P, F, F, F, F, F, I, F, I, P]),
     "mmhip_set_row_state": (I, [P, P]),
+    "mmhip_set_nonfinite_counter": (I, [P]),
+    "mmhip_set_loss_scale": (I, [P, F]),
     "mmhip_train_step": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P]),
     "mmhip_image_plan_words": (U64, [I, P, P, I]),
     "mmhip_image_plan_build": (I, [I, P, P, P, I, P, U64]),

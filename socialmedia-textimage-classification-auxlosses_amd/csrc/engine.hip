@@ -1024,6 +1024,19 @@ int mmhip_backward(mmhip_handle h, const float* d_out_cls, const float* d_logits
     return mmhip_backward_finish(h, stream);
 }
 
+// process-wide device counter of non-finite gradient elements met by the AdamW kernels (one engine per process and device)
+static unsigned* g_nonfinite = nullptr;
+int mmhip_set_nonfinite_counter(uint32_t* device_counter) {
+    if ((uintptr_t)device_counter & 3) return MMHIP_E_INVALID;
+    g_nonfinite = device_counter;
+    return 0;
+}
+int mmhip_set_loss_scale(mmhip_handle h, float loss_scale) {
+    if (!h || !(loss_scale >= 0.f)) return MMHIP_E_INVALID;
+    h->cfg.loss_scale = loss_scale;
+    return 0;
+}
+
 int mmhip_adamw(float* p, float* g, float* m, float* v, uint64_t n, float lr, float beta1, float beta2, float eps,
                 float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
     if (!p || !g || !m || !v || step < 1) return MMHIP_E_INVALID;
@@ -1032,7 +1045,7 @@ int mmhip_adamw(float* p, float* g, float* m, float* v, uint64_t n, float lr, fl
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
     a.bc1 = (float)(1.0 - pow((double)beta1, step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
-    a.zero_grad = zero_grad; a.grad_scale = grad_scale;
+    a.zero_grad = zero_grad; a.grad_scale = grad_scale; a.nonfinite = g_nonfinite;
     CHECK_HIP(launch_adamw(a, (hipStream_t)stream));
     return 0;
 }
@@ -1052,7 +1065,7 @@ int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = (size_t)rows * width; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
     a.bc1 = (float)(1.0 - pow((double)beta1, step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
-    a.zero_grad = zero_grad; a.grad_scale = grad_scale;
+    a.zero_grad = zero_grad; a.grad_scale = grad_scale; a.nonfinite = g_nonfinite;
     CHECK_HIP(launch_adamw_rows(a, rows, width, row_state, (hipStream_t)stream));
     return 0;
 }

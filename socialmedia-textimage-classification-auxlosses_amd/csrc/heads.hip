@@ -317,8 +317,16 @@ __global__ __launch_bounds__(256) void bias_grad_f32_kernel(const float* d, int 
 
 // ------------------------------------------------------------------------------------------------ fused AdamW
 // torch.optim.AdamW semantics (decoupled decay first, then moments; models/mm_late.py:420-422) over one flat fp32 buffer.
+// a gradient element that is inf / NaN (f16 mode: an overflow in the 16-bit gradient chain) must not reach m / v / p: it is read as
+// 0 and counted; the trainer lowers the loss scale / raises when the counter moves (MMLate_Model.train)
+__device__ __forceinline__ float guard_finite(float g, bool& bad) {
+    const bool ok = fabsf(g) <= 3.4028234e38f;       // false for NaN
+    bad = bad || !ok;
+    return ok ? g : 0.f;
+}
 __global__ __launch_bounds__(256) void adamw_kernel(AdamWArgs a) {
     const size_t n4 = a.n / 4;
+    bool bad = false;
     const float one_m_b1 = 1.f - a.beta1, one_m_b2 = 1.f - a.beta2;
     const float decay = 1.f - a.lr * a.wd, step = a.lr / a.bc1;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamWArgs a) {
         f32x4 m = reinterpret_cast<f32x4*>(a.m)[i], v = reinterpret_cast<f32x4*>(a.v)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float ge = g[e] * a.grad_scale;
+            const float ge = guard_finite(g[e] * a.grad_scale, bad);
             p[e] *= decay;
             m[e] = m[e] + one_m_b1 * (ge - m[e]);
             v[e] = v[e] * a.beta2 + one_m_b2 * ge * ge;
@@ -338,9 +346,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamWArgs a) {
         reinterpret_cast<f32x4*>(a.v)[i] = v;
         if (a.zero_grad) reinterpret_cast<f32x4*>(a.g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (bad && a.nonfinite) atomicAdd(a.nonfinite, 1u);
     if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
-        const float ge = a.g[i] * a.grad_scale;
+        bool bad1 = false;
+        const float ge = guard_finite(a.g[i] * a.grad_scale, bad1);
         float p = a.p[i] * decay;
         const float m = a.m[i] + one_m_b1 * (ge - a.m[i]);
         const float v = a.v[i] * a.beta2 + one_m_b2 * ge * ge;
@@ -405,6 +415,7 @@ __global__ __launch_bounds__(256) void adamw_rows_kernel(AdamWArgs a, int rows, 
     const int nch = width >> 2;
     const float one_m_b1 = 1.f - a.beta1, one_m_b2 = 1.f - a.beta2;
     const float decay = 1.f - a.lr * a.wd, step = a.lr / a.bc1;
+    bool bad = false;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         const int st = state[row];
         f32x4* __restrict__ p4 = reinterpret_cast<f32x4*>(a.p + (size_t)row * width);
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(256) void adamw_rows_kernel(AdamWArgs a, int rows, 
             f32x4 g = has_g ? g4[c] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float ge = g[e] * a.grad_scale;
+                const float ge = guard_finite(g[e] * a.grad_scale, bad);
                 p[e] *= decay;
                 m[e] = m[e] + one_m_b1 * (ge - m[e]);
                 v[e] = v[e] * a.beta2 + one_m_b2 * ge * ge;
@@ -439,6 +450,7 @@ __global__ __launch_bounds__(256) void adamw_rows_kernel(AdamWArgs a, int rows, 
         const int nst = ROW_HAS_MOMENTS | ((has_g && !a.zero_grad) ? ROW_HAS_GRAD : 0);
         if (lane == 0 && nst != st) state[row] = (uint8_t)nst;
     }
+    if (bad && a.nonfinite) atomicAdd(a.nonfinite, 1u);
 }
 hipError_t launch_adamw_rows(const AdamWArgs& a, int rows, int width, uint8_t* row_state, hipStream_t s) {
     if (rows <= 0) return hipSuccess;

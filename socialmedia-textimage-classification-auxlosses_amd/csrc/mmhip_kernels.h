@@ -200,6 +200,7 @@ struct AdamWArgs {
     float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt;
     int zero_grad;
     float grad_scale;     // gradients are multiplied by this before use (1/world for DP averaging)
+    unsigned* nonfinite;  // optional device counter: a non-finite gradient element is treated as 0 (its moments are not poisoned) and counted
 };
 hipError_t launch_adamw(const AdamWArgs& a, hipStream_t s);
 // row-lazy AdamW over a [rows, width] table (a.p .. a.v, a.n = rows*width): rows whose state byte is 0 (no gradient now,

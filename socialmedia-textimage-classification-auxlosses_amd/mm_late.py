@@ -203,6 +203,12 @@ class MM_Model(nn.Module):
             self._word_info = next(i for i in self._train_params if i["name"].endswith("word_embeddings.weight"))
             self._word_row_state = torch.zeros((self._word_info["shape"][0] + 3) // 4 * 4, dtype=torch.uint8, device=dev)
         _lib.check(lib.mmhip_set_row_state(h, _lib.ptr(self._word_row_state)), "set_row_state")
+        if first:
+            self._nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)      # include/mmhip.h: overflow guard of the AdamW kernels
+            self._loss_scale = 0.0
+        _lib.check(lib.mmhip_set_nonfinite_counter(_lib.ptr(self._nonfinite)), "set_nonfinite_counter")
+        if self._loss_scale > 0:
+            _lib.check(lib.mmhip_set_loss_scale(h, self._loss_scale), "set_loss_scale")
         self._ws = None
         torch.cuda.empty_cache()
         self._ws = torch.empty(lib.mmhip_workspace_bytes(h), dtype=torch.uint8, device=dev)
@@ -583,6 +589,22 @@ class MMLate_Model(object):
                                                 _lib.ptr(m._word_row_state), lr, 0.9, 0.999, 1e-8, weight_decay, step,
                                                 1.0 / self.world, 1, _lib.stream_ptr()), "adamw_rows")
 
+    def check_overflow(self):
+        """non-finite gradient elements since the last call (the AdamW kernels skipped and counted them, include/mmhip.h).
+        f16: halve the loss scale (dynamic loss scaling) and go on; other dtypes: a real divergence -> FloatingPointError."""
+        m = self.model
+        n = int(m._nonfinite.item())
+        if n == 0:
+            return 0
+        m._nonfinite.zero_()
+        if m.dtype_name != "f16":
+            raise FloatingPointError(f"{n} AdamW threads met non-finite gradients ({m.dtype_name}): the run has diverged")
+        cur = m._loss_scale if m._loss_scale > 0 else 1024.0
+        m._loss_scale = max(cur / 2.0, 1.0)
+        _lib.check(_lib.lib().mmhip_set_loss_scale(m._handle, m._loss_scale), "set_loss_scale")
+        logger.warning("f16 gradient overflow (%d AdamW threads skipped non-finite elements): loss scale %g -> %g", n, cur, m._loss_scale)
+        return n
+
     @staticmethod
     def _unpack(batch):
         """reference :438-447: [B,1,T] -> [B,T], [B,1,3,H,W] -> [B,3,H,W] (with the B == 1 guard)"""
@@ -620,6 +642,8 @@ class MMLate_Model(object):
                 keys = batch["data_id"].tolist() if (getattr(self.model, "_vcache", None) is not None and "data_id" in batch) else None
                 loss, ncorr = self.train_step(ids.to(self.device), mask.to(self.device), px, batch["labels"], class_weight, lr, weight_decay, step,
                                               vision_keys=keys)
+                if log_every and it % log_every == 0:
+                    self.check_overflow()
                 if log_every and it % log_every == 0 and mmdist.rank() == 0:     # the reference syncs every step (:496-498)
                     n = ids.shape[0]
                     print(f"Got {int(ncorr.item())} / {n} with accuracy {float(ncorr.item()) / n * 100:.2f} loss {loss[0].item():.4f}")
