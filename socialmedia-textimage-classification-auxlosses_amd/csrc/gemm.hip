@@ -616,15 +616,25 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     // and for the narrow long-K text GEMMs (8192 x 768 x 2304/3072), where the role-specialised 256 x 96/128 tiles stay ahead.
     static int nt8 = -1;
     if (nt8 < 0) { const char* e = getenv("MMHIP_NT8"); nt8 = e ? atoi(e) : 1; }
-    if (nt8 && a.M >= 2048 && a.N % 128 == 0 && a.K % 64 == 0) {
+    static int nt8_minm = -1;
+    if (nt8_minm < 0) { const char* e = getenv("MMHIP_NT8_MINM"); nt8_minm = e ? atoi(e) : 2048; }
+    if (nt8 && a.M >= nt8_minm && a.N % 128 == 0 && a.K % 64 == 0) {
         const long tm = (a.M + 255) / 256;
         const long t256 = a.N % 256 == 0 ? tm * (a.N / 256) : 0, t128 = tm * (a.N / 128);
         const double u256 = t256 ? (double)t256 / (double)(((t256 + 255) / 256) * 256) : 0.0;
         const double u128 = (double)t128 / (double)(((t128 + 255) / 256) * 256);
         const bool narrow_long = a.N <= 768 && a.K >= 2048 && a.M <= 8192;
-        if (!narrow_long) {
-            if (u256 >= 0.55 && u256 >= u128 - 0.15) return 15;
-            if (u128 >= 0.70) return 16;
+        // thresholds are overridable for same-box A/B runs inside the training step (MMHIP_NT8_U256 / _U128 / _GAP, in percent)
+        static double th256 = -1, th128 = -1, gap = -1;
+        if (th256 < 0) {
+            const char* e1 = getenv("MMHIP_NT8_U256"); const char* e2 = getenv("MMHIP_NT8_U128"); const char* e3 = getenv("MMHIP_NT8_GAP");
+            th256 = e1 ? atof(e1) / 100.0 : 0.55; th128 = e2 ? atof(e2) / 100.0 : 0.70; gap = e3 ? atof(e3) / 100.0 : 0.15;
+        }
+        static int nl = -1;
+        if (nl < 0) { const char* e = getenv("MMHIP_NT8_NARROW"); nl = e ? atoi(e) : 0; }
+        if (!narrow_long || nl) {
+            if (u256 >= th256 && u256 >= u128 - gap) return 15;
+            if (u128 >= th128) return 16;
         }
     }
     static int rule = -1;

@@ -96,9 +96,13 @@ __device__ __forceinline__ float mm_erf(float x) {
 __device__ __forceinline__ float mm_gelu(float x) { return 0.5f * x * (1.0f + mm_erf(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float mm_qgelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float mm_gelu_grad(float x) {
-    float cdf = 0.5f * (1.0f + mm_erf(x * 0.70710678118654752f));
-    float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    // cdf(x) + x pdf(x).  erf(x / sqrt2) = 1 - poly(t) exp(-x^2 / 2) and pdf(x) = exp(-x^2 / 2) / sqrt(2 pi) share ONE exponential
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float y = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = __expf(-ax * ax);
+    const float cdf = 0.5f * (1.0f + copysignf(1.0f - y * e, x));
+    return cdf + x * (0.3989422804014327f * e);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

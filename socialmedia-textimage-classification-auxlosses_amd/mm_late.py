@@ -245,6 +245,7 @@ class MM_Model(nn.Module):
     def __del__(self):
         try:
             if self._handle is not None:
+                _lib.lib().mmhip_set_nonfinite_counter(None)
                 _lib.lib().mmhip_destroy(self._handle)
         except Exception:
             pass
@@ -502,6 +503,7 @@ class MMLate_Model(object):
         if not m.training:
             m.train()                              # walks ~370 submodules (1.3 ms of host time): only on a mode change
         m._clean_grad()                            # an autograd-path backward before this step left its gradient in the flat buffer
+        lib.mmhip_set_nonfinite_counter(_lib.ptr(m._nonfinite))     # process-wide pointer: (re)claim it for the model that steps
         w_cls, w_itc, w_itm = self.loss_weights()
         onehot = onehot.to(self.device, torch.int64).contiguous()
         cw = None if class_weight is None else class_weight.to(self.device, torch.float32).contiguous()

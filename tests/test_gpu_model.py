@@ -24,15 +24,22 @@ if torch.cuda.is_available():
     from gpu_util import rel_err
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-# "bf16x3" is the strict-parity mode (fp32 activations, every Linear as three bf16 MFMA products of hi/lo-split operands,
-# fp32 attention): the mode in which north_star's 1e-3 on the per-post outputs is asserted.
-TOL_OUT = {"bf16": 2.5e-2, "f16": 3e-3, "bf16x3": 1e-3}
+# Tolerances.  "bf16x3" is the strict-parity mode (fp32 activations, every Linear as three bf16 MFMA products of hi/lo-split
+# operands, fp32 attention): north_star's 1e-3 on the per-post outputs is asserted in it (measured on MI355X: <= 1.8e-5 on all
+# four forward goldens, loss 4e-7, gradients <= 2.8e-5).  The 16-bit modes are bounded at about twice what they measure
+# (round 2, max over the goldens):   bf16  out_cls 8.1e-3  logits_per_text 1.9e-2  out_tim 1.5e-2  mm_features 1.15e-2
+#                                     f16   out_cls 1.6e-3  logits_per_text 2.5e-3  out_tim 1.4e-3  mm_features 1.4e-3
+# i.e. neither 16-bit mode meets 1e-3 on the logits (12 post-LN layers amplify operand rounding); both meet it on the loss.
+TOL_OUT = {"bf16": {"out_cls": 1.6e-2, "logits_per_text": 4e-2, "out_tim": 3e-2, "mm_features": 2.3e-2},
+           "f16": {"out_cls": 3.2e-3, "logits_per_text": 5e-3, "out_tim": 3e-3, "mm_features": 2.8e-3},
+           "bf16x3": {"out_cls": 1e-3, "logits_per_text": 1e-3, "out_tim": 1e-3, "mm_features": 1e-3}}
 TOL_LOSS = {"bf16": 1e-3, "f16": 1e-3, "bf16x3": 1e-4}
-# gradients: relative L2 error of the compared slice / tensor.  Measured on MI355X: attention q/k weight gradients (a
-# difference of soft-max-weighted terms) are the noisiest at 9e-2 (bf16) / 1.4e-2 (f16): the 6.5x ratio between the two
-# dtypes is the mantissa ratio, i.e. rounding noise -- a logic error would not depend on the dtype.  fc_Q / fc_K (soft-max
-# over 197 near-uniform image-token scores: dS is a difference of nearly equal terms) reach 0.2 in bf16, 0.02 in f16.
-TOL_GRAD = {"bf16": 0.35, "f16": 0.05, "bf16x3": 2e-2}
+# gradients: relative L2 error of the compared slice / tensor.  The LOGIC of the backward is pinned in bf16x3 at 1e-3 (measured
+# 2.8e-5).  In the 16-bit modes a tensor's error is rounding noise that depends on how much cancellation its gradient has:
+# measured worst tensor 0.254 (bf16, linear_fusion.bias) / 0.0126 (f16), medians 0.09 / 0.0025 -- bounded at twice the worst
+# per tensor and, against systematic regressions, at TOL_GRAD_MEDIAN over the watched tensors.
+TOL_GRAD = {"bf16": 0.5, "f16": 0.03, "bf16x3": 1e-3}
+TOL_GRAD_MEDIAN = {"bf16": 0.12, "f16": 6e-3, "bf16x3": 1e-4}
 
 
 def load(name):
@@ -73,7 +80,7 @@ def test_forward_matches_reference_golden(name, txt, dtype):
     errs = {k: rel_err(v, t(z, k)) for k, v in (("out_cls", out_cls), ("logits_per_text", lpt), ("out_tim", out_tim), ("mm_features", feats))}
     print(name, dtype, errs)
     for k, e in errs.items():
-        assert e < TOL_OUT[dtype], (k, e)
+        assert e < TOL_OUT[dtype][k], (k, e)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "bf16x3"])
@@ -137,6 +144,7 @@ def test_train_losses_and_grads_match_reference_golden(dtype, path):
         print("GRADERR", dtype, mix, path, {k: float("%.3g" % e) for k, e in worst.items()})
         for k, e in worst.items():
             assert e < TOL_GRAD[dtype], (mix, k, e)
+        assert float(np.median(list(worst.values()))) < TOL_GRAD_MEDIAN[dtype], (mix, sorted(worst.values()))
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "bf16x3"])
@@ -174,6 +182,7 @@ def test_dropout_train_step_matches_oracle_with_replayed_masks(dtype):
         allerr[k] = float("%.3g" % e)
         assert e < TOL_GRAD[dtype], (k, e)
     print("GRADERR", dtype, "dropout_replay", {k: v for k, v in sorted(allerr.items(), key=lambda kv: -kv[1])[:12]})
+    assert float(np.median(list(allerr.values()))) < TOL_GRAD_MEDIAN[dtype], sorted(allerr.values())
 
 
 def build_clip(cfg, dtype, B, T):
@@ -201,7 +210,7 @@ def test_config4_clip_tower_concat_fusion(name, dtype):
     dev = model.device_
     model.train()                                            # dropout p = 0 in this configuration
     out_cls, lpt, out_tim, _, feats = model(ids, mask, pixels, tim_inputs=(tim_ids, tim_mask))
-    assert rel_err(lpt, t(z, "logits_per_text")) < TOL_OUT[dtype], rel_err(lpt, t(z, "logits_per_text"))
+    assert rel_err(lpt, t(z, "logits_per_text")) < TOL_OUT[dtype]["logits_per_text"], rel_err(lpt, t(z, "logits_per_text"))
     loss = O.mix_loss(out_cls, onehot.to(dev), None, lpt, out_tim, lbl.to(dev), True, True)
     loss.backward()
     Pg = {k: v.clone().requires_grad_(O.trainable(k)) for k, v in P.items()}
@@ -212,7 +221,7 @@ def test_config4_clip_tower_concat_fusion(name, dtype):
                                                                ("mm_features", feats, r_feats))}
     print(name, dtype, errs, "loss", loss.item(), ref.item())
     for k, e in errs.items():
-        assert e < TOL_OUT[dtype], (k, e)
+        assert e < TOL_OUT[dtype][k], (k, e)
     assert abs(loss.item() - ref.item()) < TOL_LOSS[dtype] * abs(ref.item())
     named = dict(model.named_parameters())
     for k in ("linear_fusion.weight", "linear_cls.weight", "dual_encoder.visual_projection.weight", "dual_encoder.text_model.encoder.layer.0.output.dense.weight"):
@@ -421,14 +430,14 @@ def test_ragged_shapes_match_oracle(B, T, itm):
     r = O.mm_forward(Pg, ids, mask, pixels, cfg, tim)
     ref = O.mix_loss(r[0], onehot, None, r[1], r[2], lbl, True, itm)
     ref.backward()
-    assert rel_err(out_cls, r[0].detach()) < TOL_OUT["f16"] and rel_err(feats, r[4].detach()) < TOL_OUT["f16"]
+    assert rel_err(out_cls, r[0].detach()) < TOL_OUT["f16"]["out_cls"] and rel_err(feats, r[4].detach()) < TOL_OUT["f16"]["mm_features"]
     assert abs(loss.item() - ref.item()) < 1e-3 * abs(ref.item())
     for k, p in model.named_parameters():
         if Pg[k].grad is None or k.endswith("key.bias") or k == "fc_K.bias":
             assert p.grad is None or k.endswith("key.bias") or k == "fc_K.bias", k
             continue
         e = (p.grad.cpu() - Pg[k].grad).norm().item() / max(Pg[k].grad.norm().item(), 1e-20)
-        assert e < TOL_GRAD["f16"], (k, e)
+        assert e < 0.05, (k, e)            # tiny batches (1-5 posts): more cancellation per tensor than the golden case behind TOL_GRAD
 
 
 def test_capacity_growth_param_updates_and_errors():
