@@ -609,15 +609,16 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     // blocks per CU is as fast as any other tile for every shape of this model; the isolated micro-benchmark gains of the
     // 192-wide tiles (tools/gemm_bench.py) do not survive the cold caches between dependent kernels.  The wider tiles
     // stay selectable (a.tile / MMHIP_NT_TILE) and serve N that only 192 divides.
-    // round 2: the deep-pipelined persistent kernels (gemm8.hip) where they measure faster (tools/gemm8_bench.py on the model's
-    // shapes with the matching epilogue, profiles/r02_gemm8_microbench.txt).  One 256 x BN tile per CU and round: what decides
-    // is how full the last round of the 256 CUs is.  256 x 256 when its rounds are >= 55 % full and not much emptier than the
-    // 256 x 128 rounds (half the LDS fill per FLOP); 256 x 128 when its rounds are >= 70 % full; the round-1 tiles otherwise,
-    // and for the narrow long-K text GEMMs (8192 x 768 x 2304/3072), where the role-specialised 256 x 96/128 tiles stay ahead.
+    // round 2: the deep-pipelined persistent kernels (gemm8.hip).  Warm-cache micro-benchmarks (tools/gemm8_bench.py) put them
+    // 5-25 % ahead on most of the model's shapes, but inside the training step operands are cold (weights come from HBM every
+    // step) and then the many small 128 x 128 blocks of round 1, two per CU, hide the misses better than one 512-thread
+    // workgroup per CU: same-box A/B of the whole step (tools/ab_step.sh, profiles/r02_step_ab.txt) keeps gemm8 for the
+    // image-tower / ITM-sized GEMMs only (M >= 12000 rows, 256 x 256 tiles whenever 256 divides N) and the round-1 tiles for
+    // the 8192-row text GEMMs.  MMHIP_NT8=0 turns gemm8 off; MMHIP_NT8_MINM / _U256 / _U128 / _GAP move the thresholds.
     static int nt8 = -1;
     if (nt8 < 0) { const char* e = getenv("MMHIP_NT8"); nt8 = e ? atoi(e) : 1; }
     static int nt8_minm = -1;
-    if (nt8_minm < 0) { const char* e = getenv("MMHIP_NT8_MINM"); nt8_minm = e ? atoi(e) : 2048; }
+    if (nt8_minm < 0) { const char* e = getenv("MMHIP_NT8_MINM"); nt8_minm = e ? atoi(e) : 12000; }
     if (nt8 && a.M >= nt8_minm && a.N % 128 == 0 && a.K % 64 == 0) {
         const long tm = (a.M + 255) / 256;
         const long t256 = a.N % 256 == 0 ? tm * (a.N / 256) : 0, t128 = tm * (a.N / 128);
@@ -628,7 +629,7 @@ static int choose_nt_tile(const GemmNTArgs& a) {
         static double th256 = -1, th128 = -1, gap = -1;
         if (th256 < 0) {
             const char* e1 = getenv("MMHIP_NT8_U256"); const char* e2 = getenv("MMHIP_NT8_U128"); const char* e3 = getenv("MMHIP_NT8_GAP");
-            th256 = e1 ? atof(e1) / 100.0 : 0.55; th128 = e2 ? atof(e2) / 100.0 : 0.70; gap = e3 ? atof(e3) / 100.0 : 0.15;
+            th256 = e1 ? atof(e1) / 100.0 : 0.30; th128 = e2 ? atof(e2) / 100.0 : 0.70; gap = e3 ? atof(e3) / 100.0 : 1.00;
         }
         static int nl = -1;
         if (nl < 0) { const char* e = getenv("MMHIP_NT8_NARROW"); nl = e ? atoi(e) : 0; }

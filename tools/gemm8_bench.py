@@ -26,7 +26,9 @@ def main():
               ("txt dx_qkv", 8192, 768, 2304), ("vit qkv", 12608, 2304, 768), ("vit ao", 12608, 768, 768), ("vit fc1", 12608, 3072, 768),
               ("vit fc2", 12608, 768, 3072), ("itm qkv", 16384, 2304, 768), ("itm fc1", 16384, 3072, 768), ("itm fc2", 16384, 768, 3072),
               ("fc1 K3072", 8192, 3072, 3072), ("vfc1 K3072", 12608, 3072, 3072), ("square 4096", 4096, 4096, 4096), ("square 8192", 8192, 8192, 8192)]
-    print(f"epilogue={epi} rounds={rounds}")
+    cold = os.environ.get("COLD", "0") == "1"       # evict L2 / Infinity Cache before every timed launch (512 MiB streamed write)
+    flush = torch.empty(128 * 1024 * 1024, device=dev) if cold else None
+    print(f"epilogue={epi} rounds={rounds} cold={cold}")
     print(f"{'shape':12s} {'M':>6} {'N':>5} {'K':>5} | " + " | ".join(f"{n:>16s}" for n, _ in VARIANTS))
     for name, M, N, K in shapes:
         A = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
@@ -56,6 +58,8 @@ def main():
                 if f is None:
                     continue
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if cold:
+                    flush.fill_(1.0)
                 a.record()
                 f()
                 b.record()
