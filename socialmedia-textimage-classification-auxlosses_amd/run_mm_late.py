@@ -59,7 +59,7 @@ def build_parser():
     p.add_argument("--batch_size", type=int, default=None, help="per-GPU batch size (default: the reference's per-task value)")
     p.add_argument("--synthetic", action="store_true", help="synthetic posts instead of the data key / images")
     p.add_argument("--n_synthetic", type=int, default=256, help="synthetic training posts per rank")
-    p.add_argument("--dtype", choices=["bf16", "f16"], default="bf16")
+    p.add_argument("--dtype", choices=["bf16", "f16", "bf16x3"], default="bf16", help="bf16x3 = strict-parity mode (fp32 activations, 3 bf16 MFMA products per Linear)")
     p.add_argument("--results_dir", type=str, default=None, help="default ../results/mm_late/ as in the reference")
     p.add_argument("--arch_layers", type=int, default=None, help="(testing) override encoder depth")
     p.add_argument("--cpu_preprocess", action="store_true", help="resize / normalize images on the host (PIL) instead of the GPU kernels")
