@@ -65,6 +65,8 @@ struct mmhip_engine {
         h_dtpool, h_dprepool, h_loss;
     // state of the last forward --------------------------------------------------------
     int B = 0, T = 0, Bt = 0; bool itm = false, train_mode = false, fwd_done = false, bwd_begun = false;
+    bool skip_itc = false, itc_done = false;   // mmhip_train_step without the ITC loss: the dual-encoder similarity head (text pooler, both projections,
+                                               // normalisation, logits: five launches on the critical path between towers and backward) is not run
     uint64_t seed = 0;
     const float *bd_out_cls = nullptr, *bd_logits = nullptr, *bd_out_tim = nullptr, *bd_feats = nullptr;
     // internal side stream (ViT forward beside the text forward; weight gradients beside the dX chain) -------------
@@ -533,18 +535,22 @@ int heads_forward(mmhip_engine& e, float* out_cls, float* logits, float* out_tim
     const float* W = e.train;
     const char* xt = text_last(e);
     const int cs = e.cls_compact ? H : T * H;           // row stride of the CLS rows of the last hidden state
-    // text pooler (first B posts) and ITC similarity -- HF dual encoder :261-274
-    CHECK_HIP(launch_small_nt(small(xt, cs, W + e.t_pool_w, H, W + e.t_pool_b, e.wsp<float>(e.h_tpool), H, B, H, H, ACT_TANH), dt, s));
-    CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_tpool), H, W + e.tproj_w, H, nullptr, e.wsp<float>(e.h_txt_e), E, B, E, H), DT_F32, s));
-    CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_vpool), Hv, W + e.vproj_w, Hv, nullptr, e.wsp<float>(e.h_img_e), E, B, E, Hv), DT_F32, s));
-    ItcArgs it{e.wsp<float>(e.h_txt_e), e.wsp<float>(e.h_img_e), W + e.logit_scale, e.wsp<float>(e.h_txt_n), e.wsp<float>(e.h_img_n),
-               e.wsp<float>(e.h_txt_inv), e.wsp<float>(e.h_img_inv), e.wsp<float>(e.h_logits), B, E};
-    CHECK_HIP(launch_itc_fwd(it, s));
-    // z = [x_t[:,0] | fused image feature]
+    // z = [x_t CLS | fused image feature]; the fp32 copy of the CLS rows in z[:, :H] is also the A operand of the text pooler and of
+    // fc_Q (the 16-bit rows would send small_gemm down its scalar-load path: 21 us instead of 11)
     float* z = e.wsp<float>(e.h_z);
     CHECK_HIP(launch_gather_rows_f32(xt, (size_t)cs, z, ZW, Bt, H, dt, s));
+    // text pooler (first B posts) and ITC similarity -- HF dual encoder :261-274
+    e.itc_done = !(e.skip_itc && logits == nullptr);
+    if (e.itc_done) {
+        CHECK_HIP(launch_small_nt(small(z, ZW, W + e.t_pool_w, H, W + e.t_pool_b, e.wsp<float>(e.h_tpool), H, B, H, H, ACT_TANH), DT_F32, s));
+        CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_tpool), H, W + e.tproj_w, H, nullptr, e.wsp<float>(e.h_txt_e), E, B, E, H), DT_F32, s));
+        CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_vpool), Hv, W + e.vproj_w, Hv, nullptr, e.wsp<float>(e.h_img_e), E, B, E, Hv), DT_F32, s));
+        ItcArgs it{e.wsp<float>(e.h_txt_e), e.wsp<float>(e.h_img_e), W + e.logit_scale, e.wsp<float>(e.h_txt_n), e.wsp<float>(e.h_img_n),
+                   e.wsp<float>(e.h_txt_inv), e.wsp<float>(e.h_img_inv), e.wsp<float>(e.h_logits), B, E};
+        CHECK_HIP(launch_itc_fwd(it, s));
+    }
     if (c.fusion == MMHIP_FUSION_ATTENTION) {
-        CHECK_HIP(launch_small_nt(small(xt, cs, W + e.fq_w, H, W + e.fq_b, e.wsp<float>(e.h_q), H, Bt, H, H), dt, s));
+        CHECK_HIP(launch_small_nt(small(z, ZW, W + e.fq_w, H, W + e.fq_b, e.wsp<float>(e.h_q), H, Bt, H, H), DT_F32, s));
         CHECK_HIP(launch_small_nn(small(e.wsp<float>(e.h_q), H, W + e.fk_w, H, nullptr, e.wsp<float>(e.h_qk), H, Bt, H, H), s));
         FusionAttnArgs fa{e.wsp<float>(e.h_qk), e.ws + e.v_out, e.wsp<float>(e.h_prob), e.wsp<float>(e.h_xbar), Bt, B, P, H, 1.0f / sqrtf((float)H)};
         CHECK_HIP(launch_fusion_attn_fwd(fa, dt, s));
@@ -561,7 +567,7 @@ int heads_forward(mmhip_engine& e, float* out_cls, float* logits, float* out_tim
     CHECK_HIP(launch_small_nt(small(e.wsp<float>(e.h_featd), H, W + e.cls_w, H, W + e.cls_b, e.wsp<float>(e.h_out_cls), C, B, C, H), DT_F32, s));
     if (e.itm) CHECK_HIP(launch_small_nt(small(feats + (size_t)B * H, H, W + e.tim_w, H, W + e.tim_b, e.wsp<float>(e.h_out_tim), 2, B, 2, H), DT_F32, s));
     if (out_cls) CHECK_HIP(hipMemcpyAsync(out_cls, e.ws + e.h_out_cls, (size_t)B * C * 4, hipMemcpyDeviceToDevice, s));
-    if (logits) CHECK_HIP(hipMemcpyAsync(logits, e.ws + e.h_logits, (size_t)B * B * 4, hipMemcpyDeviceToDevice, s));
+    if (logits && e.itc_done) CHECK_HIP(hipMemcpyAsync(logits, e.ws + e.h_logits, (size_t)B * B * 4, hipMemcpyDeviceToDevice, s));
     if (out_tim && e.itm) CHECK_HIP(hipMemcpyAsync(out_tim, e.ws + e.h_out_tim, (size_t)B * 2 * 4, hipMemcpyDeviceToDevice, s));
     if (feats_out) CHECK_HIP(hipMemcpyAsync(feats_out, feats, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
     return 0;
@@ -946,6 +952,7 @@ int mmhip_loss(mmhip_handle h, const int64_t* onehot, const float* class_w, cons
     if (!onehot) return MMHIP_E_INVALID;
     mmhip_engine& e = *h;
     if (w_itm != 0.f && (!e.itm || !lbl_tim)) return MMHIP_E_INVALID;
+    if (w_itc != 0.f && !e.itc_done) return MMHIP_E_STATE;
     LossArgs a;
     memset(&a, 0, sizeof(a));
     a.out_cls = e.wsp<float>(e.h_out_cls); a.onehot = onehot; a.class_w = class_w;
@@ -1082,8 +1089,11 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
     if (!adam_m || !adam_v || !onehot || step < 1) return MMHIP_E_INVALID;
     if (use_itm && (!tim_ids || !lbl_tim)) return MMHIP_E_INVALID;
     mmhip_engine& e = *h;
-    if (int r = mmhip_forward(h, ids, mask, pixels, use_itm ? tim_ids : nullptr, use_itm ? tim_mask : nullptr, B, T, 1, seed, nullptr, nullptr,
-                              nullptr, nullptr, stream)) return r;
+    e.skip_itc = !use_itc;
+    const int rf = mmhip_forward(h, ids, mask, pixels, use_itm ? tim_ids : nullptr, use_itm ? tim_mask : nullptr, B, T, 1, seed, nullptr, nullptr,
+                                 nullptr, nullptr, stream);
+    e.skip_itc = false;
+    if (rf) return rf;
     if (int r = mmhip_loss(h, onehot, class_w, use_itm ? lbl_tim : nullptr, w_cls, use_itc ? w_itc : 0.f, use_itm ? w_itm : 0.f, loss, n_correct, stream)) return r;
     if (int r = mmhip_backward(h, nullptr, nullptr, nullptr, nullptr, stream)) return r;
     // merged [begin, end) ranges of the active gradient groups, in address order

@@ -26,19 +26,22 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
 // One workgroup per text post.  Each wave takes image tokens j = w, w+4, ...: a lane owns 12 of the 768 columns
 // (three 8-byte loads per token, independent across tokens, so the loads pipeline), dots reduce across the wave,
 // weighted sums accumulate in registers and are combined across the 4 waves through LDS.
+// 8 waves per post: the kernel is a latency chain over 197 x 768 image tokens read twice (300 KB per workgroup, 64-128 workgroups)
+// on the critical path between the towers and the backward; eight waves keep twice the token loads in flight of four (40 KB of LDS partials)
+static constexpr int FA_WAVES = 8, FA_THREADS = FA_WAVES * 64;
 template <typename T>
-__global__ __launch_bounds__(256) void fusion_attn_fwd_kernel(FusionAttnArgs a) {
+__global__ __launch_bounds__(FA_THREADS) void fusion_attn_fwd_kernel(FusionAttnArgs a) {
     __shared__ __attribute__((aligned(16))) float q[1024];
-    __shared__ float sc[256];
-    __shared__ float red[4];
-    __shared__ float part[4][1024];
+    __shared__ float sc[FA_THREADS];
+    __shared__ float red[FA_WAVES];
+    __shared__ float part[FA_WAVES][1024];
     const int bt = blockIdx.x, b = bt % a.B, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < a.H; c += 256) q[c] = a.qk[(size_t)bt * a.H + c];
+    for (int c = threadIdx.x; c < a.H; c += FA_THREADS) q[c] = a.qk[(size_t)bt * a.H + c];
     __syncthreads();
     const T* xv = (const T*)a.xv + (size_t)b * a.P * a.H;
     const int nch = a.H >> 2;                   // 4-element chunks; lane owns chunks lane, lane+64, ...
     // dots of 4 tokens at a time per wave: the four wave reductions interleave, hiding the cross-lane latency
-    for (int j0 = w * 4; j0 < a.P; j0 += 16) {
+    for (int j0 = w * 4; j0 < a.P; j0 += 4 * FA_WAVES) {
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ch = lane; ch < nch; ch += 64) {
             const f32x4 qq = *reinterpret_cast<const f32x4*>(q + ch * 4);
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void fusion_attn_fwd_kernel(FusionAttnArgs a) 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee) acc[t][ee] = 0.f;
-    for (int j = w; j < a.P; j += 4) {
+    for (int j = w; j < a.P; j += FA_WAVES) {
         const float p = sc[j];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -89,20 +92,25 @@ __global__ __launch_bounds__(256) void fusion_attn_fwd_kernel(FusionAttnArgs a) 
 #pragma unroll
             for (int ee = 0; ee < 4; ++ee) part[w][(lane + 64 * t) * 4 + ee] = acc[t][ee];
     __syncthreads();
-    for (int c = threadIdx.x; c < a.H; c += 256) a.xbar[(size_t)bt * a.H + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+    for (int c = threadIdx.x; c < a.H; c += FA_THREADS) {
+        float sres = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < FA_WAVES; ++ww) sres += part[ww][c];
+        a.xbar[(size_t)bt * a.H + c] = sres;
+    }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void fusion_attn_bwd_kernel(FusionAttnBwdArgs a) {
+__global__ __launch_bounds__(FA_THREADS) void fusion_attn_bwd_kernel(FusionAttnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float dxb[1024];
-    __shared__ float ds[256];
-    __shared__ float red[4];
-    __shared__ float part[4][1024];
+    __shared__ float ds[FA_THREADS];
+    __shared__ float red[FA_WAVES];
+    __shared__ float part[FA_WAVES][1024];
     const int bt = blockIdx.x, b = bt % a.B, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < a.H; c += 256) dxb[c] = a.dxbar[(size_t)bt * a.H + c];
+    for (int c = threadIdx.x; c < a.H; c += FA_THREADS) dxb[c] = a.dxbar[(size_t)bt * a.H + c];
     __syncthreads();
     const T* xv = (const T*)a.xv + (size_t)b * a.P * a.H;
     const int nch = a.H >> 2;
-    for (int j0 = w * 4; j0 < a.P; j0 += 16) {
+    for (int j0 = w * 4; j0 < a.P; j0 += 4 * FA_WAVES) {
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ch = lane; ch < nch; ch += 64) {
             const f32x4 qq = *reinterpret_cast<const f32x4*>(dxb + ch * 4);
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256) void fusion_attn_bwd_kernel(FusionAttnBwdArgs 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee) acc[t][ee] = 0.f;
-    for (int j = w; j < a.P; j += 4) {
+    for (int j = w; j < a.P; j += FA_WAVES) {
         const float d = ds[j];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -150,7 +158,12 @@ __global__ __launch_bounds__(256) void fusion_attn_bwd_kernel(FusionAttnBwdArgs 
 #pragma unroll
             for (int ee = 0; ee < 4; ++ee) part[w][(lane + 64 * t) * 4 + ee] = acc[t][ee];
     __syncthreads();
-    for (int c = threadIdx.x; c < a.H; c += 256) a.dqk[(size_t)bt * a.H + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+    for (int c = threadIdx.x; c < a.H; c += FA_THREADS) {
+        float sres = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < FA_WAVES; ++ww) sres += part[ww][c];
+        a.dqk[(size_t)bt * a.H + c] = sres;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ ITC
@@ -363,18 +376,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamWArgs a) {
 // ------------------------------------------------------------------------------------------------ launchers
 hipError_t launch_fusion_attn_fwd(const FusionAttnArgs& a, int dtype, hipStream_t s) {
     if (a.Bt <= 0) return hipSuccess;
-    if (a.P > 256 || a.H > 1024 || a.H % 4) return hipErrorInvalidValue;
-    if (dtype == DT_BF16) hipLaunchKernelGGL(fusion_attn_fwd_kernel<bf16_t>, dim3(a.Bt), dim3(256), 0, s, a);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(fusion_attn_fwd_kernel<f16_t>, dim3(a.Bt), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(fusion_attn_fwd_kernel<float>, dim3(a.Bt), dim3(256), 0, s, a);
+    if (a.P > FA_THREADS || a.H > 1024 || a.H % 4) return hipErrorInvalidValue;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(fusion_attn_fwd_kernel<bf16_t>, dim3(a.Bt), dim3(FA_THREADS), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(fusion_attn_fwd_kernel<f16_t>, dim3(a.Bt), dim3(FA_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(fusion_attn_fwd_kernel<float>, dim3(a.Bt), dim3(FA_THREADS), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_fusion_attn_bwd(const FusionAttnBwdArgs& a, int dtype, hipStream_t s) {
     if (a.Bt <= 0) return hipSuccess;
-    if (a.P > 256 || a.H > 1024 || a.H % 4) return hipErrorInvalidValue;
-    if (dtype == DT_BF16) hipLaunchKernelGGL(fusion_attn_bwd_kernel<bf16_t>, dim3(a.Bt), dim3(256), 0, s, a);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(fusion_attn_bwd_kernel<f16_t>, dim3(a.Bt), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(fusion_attn_bwd_kernel<float>, dim3(a.Bt), dim3(256), 0, s, a);
+    if (a.P > FA_THREADS || a.H > 1024 || a.H % 4) return hipErrorInvalidValue;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(fusion_attn_bwd_kernel<bf16_t>, dim3(a.Bt), dim3(FA_THREADS), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(fusion_attn_bwd_kernel<f16_t>, dim3(a.Bt), dim3(FA_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(fusion_attn_bwd_kernel<float>, dim3(a.Bt), dim3(FA_THREADS), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_itc_fwd(const ItcArgs& a, hipStream_t s) {
