@@ -212,6 +212,8 @@ class MM_Model(nn.Module):
         self._ws = None
         torch.cuda.empty_cache()
         self._ws = torch.empty(lib.mmhip_workspace_bytes(h), dtype=torch.uint8, device=dev)
+        if os.environ.get("MMHIP_POISON_WS"):       # debugging aid: no kernel may read workspace it has not written
+            self._ws.fill_(int(os.environ["MMHIP_POISON_WS"], 0))
         _lib.check(lib.mmhip_bind(h, _lib.ptr(self._flat_frozen), _lib.ptr(self._flat_train), _lib.ptr(self._flat_grad),
                                   _lib.ptr(self._ws), self._ws.numel()), "bind")
         self._stage_ranges = []

@@ -146,31 +146,53 @@ torch.distributed.init_process_group(backend="nccl", init_method="tcp://127.0.0.
 cfg = types.SimpleNamespace(batch_size=4, num_labels=3, use_clip_loss=True, beta_itc=0.1, use_tim_loss=True, beta_itm=0.1, max_length=64, dropout=0.05)
 arch = dict(layers_txt=2, layers_img=1, vocab=300, max_pos=130)
 ids, mask, px, oh = synthetic_batch(300, 3, 4, 64, 77, pad=True)
+os.environ["MMHIP_NATIVE_STEP"] = "0"      # both runs take the staged step, so the gradient can be captured in front of AdamW
 out = []
 for force in ("1", "0"):
     os.environ["MMHIP_FORCE_EXCHANGE"] = force
     tr = MMLate_Model(cfg, "bernice", "vit", "attention", arch=arch, seed=5)
+    m, adamw, snap = tr.model, tr._adamw, {}
+    def hook(*a, **k):
+        # first call of a step = dense ranges (all-reduces waited for), second = word-table rows (row exchange finished)
+        snap["dense" if k.get("rows", True) is False else "rows"] = m._flat_grad.clone()
+        return adamw(*a, **k)
     np.random.seed(30)
+    losses = []
     for step in (1, 2, 3):
+        tr._adamw = hook if step == 1 else adamw
         loss, _ = tr.train_step(ids.cuda(), mask.cuda(), px, oh, None, 1e-3, 0.00025, step)
-    torch.cuda.synchronize()
-    out.append((tr.model._flat_train.clone(), loss.clone(), tr.model._word_row_state.clone()))
-err = (out[0][0] - out[1][0]).abs().max().item()
-print("RCCL_ERR", err, float(out[0][1][0]), float(out[1][1][0]), bool(torch.equal(out[0][2], out[1][2])), torch.distributed.get_backend())
+        torch.cuda.synchronize()
+        if step == 1:
+            w0 = m._word_info["offset"]
+            first = (torch.cat([snap["dense"][:w0], snap["rows"][w0:]]), m._flat_train.clone(), m._word_row_state.clone())
+        losses.append(float(loss[0]))
+    out.append((first, losses))
+(g1, p1, r1), l1 = out[0]
+(g0, p0, r0), l0 = out[1]
+gerr = (g1 - g0).abs().max().item()
+perr = (p1 - p0).abs().max().item()
+lerr = max(abs(a - b) / abs(b) for a, b in zip(l1, l0))
+print("RCCL_ERR", gerr, perr, lerr, bool(torch.equal(r1, r0)), torch.distributed.get_backend(), float(g0.abs().max()))
 torch.distributed.destroy_process_group()
 '''
 
 
 def test_rccl_call_pattern_at_world_size_one(tmp_path):
     """the staged all-reduce / row-sparse all_gather exchange issued through RCCL itself (backend "nccl", one rank, exchange
-    forced): same parameters as the run without any collective -- the one-GPU box cannot host two RCCL ranks, so this pins
-    the backend's call pattern (slices of the flat gradient, async work handles, int64 / fp32 all_gather) and
-    tests/test_dist_cpu.py + the gloo test above pin the arithmetic across ranks"""
+    forced): the gradient AdamW sees is the one of the run without any collective -- the one-GPU box cannot host two RCCL
+    ranks, so this pins the backend's call pattern (slices of the flat gradient, async work handles, int64 / fp32 all_gather)
+    and tests/test_dist_cpu.py + the gloo test above pin the arithmetic across ranks.
+    Compared: the step-1 gradient (the fp32 atomics of the LayerNorm / embedding backward make ANY two runs differ by their
+    summation order, ~3e-8 here), the parameters and row flags after that step, and the 3-step loss trajectory.  Parameters
+    after several steps are not compared at 1e-5: a 1e-8 parameter difference now and then flips one bf16 rounding of a CLS
+    activation, which moves the step-3 loss by 1e-4 and -- through Adam's g / sqrt(v) -- elements with near-zero gradient by
+    up to lr (seen in ~15 % of repeated runs, with or without the exchange: tools/dbg_flaky.py)."""
     script = tmp_path / "rccl.py"
     script.write_text(RCCL_SCRIPT)
     r = run([sys.executable, str(script)], env={"ROOT": ROOT, "PORT": str(29900 + os.getpid() % 90), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_ERR")][0].split()
-    assert float(line[1]) < 2e-5 and line[4] == "True" and line[5] == "nccl", line
+    gerr, perr, lerr, gmax = float(line[1]), float(line[2]), float(line[3]), float(line[6])
+    assert gmax > 1e-2 and gerr < 1e-6 and perr < 2e-5 and lerr < 2e-3 and line[4] == "True" and line[5] == "nccl", line
 
 
 def test_cli_two_ranks_shard_the_real_data(tmp_path):
