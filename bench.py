@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="posts per GPU (default: 64; 32 for config 4)")
     ap.add_argument("--txt_model_name", default="bernice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-shapes", default="", help="append the per-shape table of the timed NT GEMM launches to this file")
     args = ap.parse_args()
     if args.config == 3:
         args.aux = True
@@ -188,6 +189,11 @@ def main():
             step_no += 1
             trainer.train_step(ids, mask, pixels, onehot, None, lr, wd, step_no)
         gms, gl, gf = Ct.c_double(), Ct.c_uint64(), Ct.c_double()
+        if args.gemm_shapes and rank == 0:
+            buf = Ct.create_string_buffer(1 << 16)
+            _lib.check(lib.mmhip_gemm_timing_by_shape(m._handle, buf, len(buf)))
+            with open(args.gemm_shapes, "a") as f:
+                f.write("# NT GEMM launches by shape, side streams %s (2 steps)\n%s\n" % ("on" if mode == 1 else "off", buf.value.decode()))
         _lib.check(lib.mmhip_gemm_timing(m._handle, 0, 1, Ct.byref(gms), Ct.byref(gl), Ct.byref(gf)))
         tf = gf.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
         return tf, gms.value, int(gl.value), gf.value

@@ -177,6 +177,9 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
  * since reset.  enable = 1: the engine keeps its internal side streams (the conditions of a normal step: a launch may share
  * the chip with the other tower / the weight-gradient GEMM); enable = 2: side streams off, every kernel alone on the chip. */
 int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_t* launches, double* flops);
+/* the same launches as a NUL-terminated text table, one line per (M, N, K, epilogue flags, forced tile): count, average
+ * microseconds, TFLOP/s -- call before the reset (diagnostic: bench.py --gemm-shapes) */
+int mmhip_gemm_timing_by_shape(mmhip_handle h, char* out, uint64_t capacity);
 
 /* ---- input pipeline, image leg: decoded RGB bytes -> pixel_values [n,3,S,S] fp32.
  * Replaces the ViT feature extractor call made per item inside the reference's Dataset.__getitem__

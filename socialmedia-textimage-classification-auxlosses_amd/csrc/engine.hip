@@ -81,7 +81,7 @@ struct mmhip_engine {
     int overlap = -1;          // -1 = read MMHIP_OVERLAP on first use
     // GEMM timing ----------------------------------------------------------------------
     int timing = 0;            // 0 off, 1 = events around every NT GEMM with the side streams on, 2 = side streams off
-    struct Ev { hipEvent_t a, b; double flops; };
+    struct Ev { hipEvent_t a, b; double flops; int M, N, K, flags, tile; };
     std::vector<Ev> evs; size_t ev_used = 0;
 
     template <typename U> U* wsp(size_t off) const { return reinterpret_cast<U*>(ws + off); }
@@ -367,6 +367,7 @@ int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
         }
         auto& ev = e.evs[e.ev_used++];
         ev.flops = 2.0 * g.a.M * (double)g.a.N * g.a.K;
+        ev.M = g.a.M; ev.N = g.a.N; ev.K = g.a.K; ev.flags = g.a.flags; ev.tile = g.a.tile;
         CHECK_HIP(hipEventRecord(ev.a, s));
         CHECK_HIP(launch_gemm_nt(g.a, e.dt(), s));
         CHECK_HIP(hipEventRecord(ev.b, s));
@@ -1142,6 +1143,35 @@ int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_
     }
     if (reset) e.ev_used = 0;
     e.timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    return 0;
+}
+
+// per-shape table of the launches timed since the last reset (text, one line per (M, N, K, epilogue flags))
+int mmhip_gemm_timing_by_shape(mmhip_handle h, char* out, uint64_t capacity) {
+    if (!h || !out || capacity < 2) return MMHIP_E_INVALID;
+    mmhip_engine& e = *h;
+    struct Row { int M, N, K, flags, tile; int n; double ms, flops; };
+    std::vector<Row> rows;
+    for (size_t i = 0; i < e.ev_used; ++i) {
+        const auto& ev = e.evs[i];
+        CHECK_HIP(hipEventSynchronize(ev.b));
+        float t = 0;
+        CHECK_HIP(hipEventElapsedTime(&t, ev.a, ev.b));
+        Row* r = nullptr;
+        for (auto& x : rows) if (x.M == ev.M && x.N == ev.N && x.K == ev.K && x.flags == ev.flags && x.tile == ev.tile) { r = &x; break; }
+        if (!r) { rows.push_back(Row{ev.M, ev.N, ev.K, ev.flags, ev.tile, 0, 0.0, 0.0}); r = &rows.back(); }
+        r->n++; r->ms += t; r->flops += ev.flops;
+    }
+    size_t pos = 0;
+    auto put = [&](const char* fmt, auto... a) {
+        if (pos + 1 >= capacity) return;
+        int w = snprintf(out + pos, capacity - pos, fmt, a...);
+        if (w > 0) pos += (size_t)w < capacity - pos ? (size_t)w : capacity - pos - 1;
+    };
+    put("%7s %6s %6s %6s %5s %6s %9s %9s %8s\n", "M", "N", "K", "flags", "tile", "n", "avg_us", "total_ms", "TFLOP/s");
+    for (const auto& r : rows)
+        put("%7d %6d %6d %6d %5d %6d %9.2f %9.3f %8.1f\n", r.M, r.N, r.K, r.flags, r.tile, r.n, 1e3 * r.ms / r.n, r.ms, r.flops / (r.ms * 1e-3) * 1e-12);
+    out[pos < capacity ? pos : capacity - 1] = 0;
     return 0;
 }
 

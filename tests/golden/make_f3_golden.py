@@ -3,6 +3,7 @@
 `models/utils.py:prepare_data` (this container only, behind the shim of make_golden.py):
 the --testing subsample (drawn from numpy's GLOBAL stream seeded like run_mm_late.py:49), the split, the one-hot label
 vectors and sklearn's balanced class weights.  Inputs (a synthetic data-key frame) are stored with the outputs.
+The evaluation loop's dict (mm_late.py:534-638) has its own reference-derived fixture: make_eval_golden.py.
 The reference's metric functions (utils.py:294-335) need torchmetrics, which this container does not have: no
 reference-derived vectors exist for them here (tests check them against scikit-learn instead).
 Run:  python tests/golden/make_f3_golden.py

@@ -600,3 +600,39 @@ def test_loads_huggingface_directories_like_from_vision_text_pretrained(tmp_path
     assert (lpt.cpu() - ref_lpt).abs().max().item() / ref_lpt.abs().max().item() < 2e-3
     assert (out_cls.cpu() - ref[0]).abs().max().item() / ref[0].abs().max().item() < 2e-3
     assert (feats.cpu() - ref[4]).abs().max().item() / ref[4].abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16", "f16"])
+@pytest.mark.parametrize("tag,itc,itm", [("plain", False, False), ("itcitm", True, True)])
+def test_eval_loop_matches_reference_golden(dtype, tag, itc, itm):
+    """MMLate_Model.eval against the dict returned by the REFERENCE's own eval loop (tests/golden/make_eval_golden.py,
+    reference models/mm_late.py:534-638): three ragged batches (4 + 4 + 3 posts), class weights, ITM negatives re-sampled per
+    batch from numpy's global stream: data ids and labels exact, mean loss within the dtype's band, predictions equal wherever
+    the reference's top-2 logit margin exceeds the dtype's logit error"""
+    import types
+    z, cfg = load("eval_small_xlmr.npz")
+    cfgd = types.SimpleNamespace(batch_size=4, num_labels=cfg.num_labels, use_clip_loss=itc, beta_itc=0.1, use_tim_loss=itm, beta_itm=0.1,
+                                 max_length=int(z["T"]), dropout=cfg.p_head)
+    arch = dict(layers_txt=cfg.layers_txt, layers_img=cfg.layers_img, vocab=cfg.vocab, max_pos=cfg.max_pos, type_vocab=cfg.type_vocab,
+                p_hidden=cfg.p_hidden, p_attn=cfg.p_attn)
+    tr = MMLate_Model(cfgd, "bernice", "vit", cfg.fusion, arch=arch, dtype=dtype)
+    load_oracle_params(tr.model, O.make_params(cfg, int(z["seed_w"])))
+    batches, first = [], 5000
+    for B, seed in z["batches"].tolist():
+        ids, mask, pixels, onehot = O.synthetic_batch(cfg, B, int(z["T"]), seed, True)
+        batches.append({"input_ids": ids.unsqueeze(1), "attention_mask": mask.unsqueeze(1), "pixel_values": pixels.unsqueeze(1),
+                        "labels": onehot, "data_id": torch.arange(first, first + B)})
+        first += B
+    np.random.seed(30)
+    res = tr.eval(batches, torch.nn.CrossEntropyLoss(weight=t(z, "class_w")), tim_loss_fn=torch.nn.CrossEntropyLoss() if itm else None)
+    assert not tr.model.training
+    assert np.array_equal(res["data_id"], z[tag + ".data_id"]) and np.array_equal(res["labels"], z[tag + ".labels"])
+    ref_loss = float(z[tag + ".loss"])
+    rel = abs(res["loss"] - ref_loss) / ref_loss
+    top2 = np.sort(z["out_cls"], axis=1)
+    margin = top2[:, -1] - top2[:, -2]
+    sure = margin > 4 * TOL_OUT[dtype]["out_cls"] * np.abs(z["out_cls"]).max()
+    print(tag, dtype, "loss rel err", rel, "sure", int(sure.sum()), "of", len(sure))
+    assert rel < {"bf16x3": 1e-4, "bf16": 5e-3, "f16": 1e-3}[dtype], (res["loss"], ref_loss)
+    assert sure.sum() >= (len(sure) - 2 if dtype == "bf16x3" else 1)
+    assert np.array_equal(res["predictions"][sure], z[tag + ".predictions"][sure])

@@ -132,3 +132,36 @@ def test_hash_dropout_rate():
     assert abs(keep.mean() - 0.9) < 2e-3
     k2 = O.hash_keep_mask(1 << 20, 12345, O.stream_attn(4), 0x1234_5678_9ABC, 0.1)
     assert abs((keep & k2).mean() - 0.81) < 3e-3
+
+
+def eval_loader(cfg, z):
+    """the loader of tests/golden/make_eval_golden.py (items shaped like MM_Dataset's)"""
+    out, first = [], 5000
+    for B, seed in z["batches"].tolist():
+        ids, mask, pixels, onehot = O.synthetic_batch(cfg, B, int(z["T"]), seed, True)
+        out.append({"input_ids": ids.unsqueeze(1), "attention_mask": mask.unsqueeze(1), "pixel_values": pixels.unsqueeze(1),
+                    "labels": onehot, "data_id": torch.arange(first, first + B)})
+        first += B
+    return out
+
+
+@pytest.mark.parametrize("tag,itc,itm", [("plain", False, False), ("itcitm", True, True)])
+def test_eval_loop_matches_reference(golden_dir, tag, itc, itm):
+    """reference MMLate_Model.eval (models/mm_late.py:534-638) restated over the oracle: eval-mode forward, per-batch loss mix
+    with re-sampled ITM negatives, argmax predictions / labels, mean of the per-batch losses"""
+    z, cfg = load(golden_dir, "eval_small_xlmr.npz")
+    P = O.make_params(cfg, int(z["seed_w"]))
+    w = t(z, "class_w")
+    np.random.seed(30)
+    losses, preds, labels, ids_all, logits = [], [], [], [], []
+    with torch.no_grad():
+        for b in eval_loader(cfg, z):
+            ids, mask, px = torch.squeeze(b["input_ids"]), torch.squeeze(b["attention_mask"]), torch.squeeze(b["pixel_values"])
+            tim = O.prepare_itm_inputs(ids, mask) if itm else None
+            out_cls, lpt, out_tim, _, _ = O.mm_forward(P, ids, mask, px, cfg, tim[:2] if tim else None)
+            losses.append(O.mix_loss(out_cls, b["labels"], w, lpt, out_tim, tim[2] if tim else None, itc, itm).item())
+            preds.append(out_cls.argmax(1)); labels.append(b["labels"].argmax(1)); ids_all.append(b["data_id"]); logits.append(out_cls)
+    assert abs(np.mean(losses) - float(z[tag + ".loss"])) < 2e-5 * abs(float(z[tag + ".loss"]))
+    assert torch.equal(torch.cat(preds), t(z, tag + ".predictions")) and torch.equal(torch.cat(labels), t(z, tag + ".labels"))
+    assert torch.equal(torch.cat(ids_all), t(z, tag + ".data_id"))
+    assert (torch.cat(logits) - t(z, "out_cls")).abs().max() < 2e-5 * t(z, "out_cls").abs().max()
