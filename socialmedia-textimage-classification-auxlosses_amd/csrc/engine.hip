@@ -376,6 +376,33 @@ int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
     CHECK_HIP(launch_gemm_nt(g.a, e.dt(), s));
     return 0;
 }
+// two GEMMs of equal N and K (the two towers' same-named GEMM of one layer) in ONE persistent launch; falls back to two launches
+int run_gemm_pair(mmhip_engine& e, G& g0, G& g1, hipStream_t s) {
+    const bool pairable = (e.dt() == DT_BF16 || e.dt() == DT_F16) && g0.a.N == g1.a.N && g0.a.K == g1.a.K;
+    mmhip_engine::Ev* ev = nullptr;
+    if (e.timing && pairable) {
+        if (e.ev_used == e.evs.size()) {
+            mmhip_engine::Ev n;
+            CHECK_HIP(hipEventCreate(&n.a));
+            CHECK_HIP(hipEventCreate(&n.b));
+            e.evs.push_back(n);
+        }
+        ev = &e.evs[e.ev_used];
+        CHECK_HIP(hipEventRecord(ev->a, s));
+    }
+    if (pairable && launch_gemm_nt8_pair(g0.a, g1.a, e.dt(), 0, s)) {
+        CHECK_HIP(hipGetLastError());
+        if (ev) {
+            ev->flops = 2.0 * ((double)g0.a.M + g1.a.M) * (double)g0.a.N * g0.a.K;
+            ev->M = g0.a.M + g1.a.M; ev->N = g0.a.N; ev->K = g0.a.K; ev->flags = g0.a.flags | g1.a.flags; ev->tile = -2;     // -2: a pair
+            CHECK_HIP(hipEventRecord(ev->b, s));
+            e.ev_used++;
+        }
+        return 0;
+    }
+    if (int r = run_gemm(e, g0, s)) return r;
+    return run_gemm(e, g1, s);
+}
 SmallGemmArgs small(const void* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, int act = ACT_NONE, int acc = 0) {
     SmallGemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -524,6 +551,126 @@ int text_forward(mmhip_engine& e, hipStream_t s) {
         e.cls_compact = compact;
         x = e.ws + a.out;
     }
+    return 0;
+}
+
+// Both towers layer by layer on ONE stream, each pair of same-named GEMMs (QKV, attention output, FC1, FC2: equal N and K in
+// ViT-B/16 and the BERT-base-sized text tower) as one persistent launch (gemm8.hip, GemmNTPair): alone, the 256 x 256 tiles of
+// M = 8192 x N = 2304 fill 288 of 512 workgroup slots in two rounds and those of M = 12608 fill 450 of 512; together 738 of 768.
+// Same arithmetic as vit_forward + text_forward (same kernels on the same operands), another launch order.
+// Measured (same box, BASELINE config 2): the paired GEMMs run at 0.276 of the MFMA peak against 0.254 for the separate ones
+// (every kernel alone on the chip), and the step takes 11.2 ms against 12.2 ms with the side streams off -- but 10.4 ms with the
+// image tower on its own stream, where kernels of the two towers share CUs.  Hence opt-in: MMHIP_LOCKSTEP=1.
+bool lockstep_ok(const mmhip_engine& e) {
+    static int on = -1;
+    if (on < 0) { const char* v = getenv("MMHIP_LOCKSTEP"); on = v ? atoi(v) : 0; }
+    return on && (e.dt() == DT_BF16 || e.dt() == DT_F16) && !e.clip() && e.Hv() == e.cfg.hidden && e.Iv() == e.cfg.inter &&
+           e.cfg.layers_txt > 0 && e.cfg.layers_img > 0;
+}
+int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s) {
+    const mmhip_config& c = e.cfg;
+    const int H = c.hidden, I = c.inter, T = e.T, B = e.B, Bt = e.Bt, Mt = Bt * T, P = e.P(), Kpp = e.Kpp(), dt = e.dt();
+    const int Mv = B * P;
+    const float* W = e.train;
+    const float* F = e.frozen;
+    const bool tr = e.train_mode;
+    // ---- embeddings of both towers
+    CHECK_HIP(launch_patchify(pixels, e.ws + e.v_patches, B, c.image, c.patch, Kpp, dt, s));
+    { G g(e.ws + e.v_patches, Kpp, e.ws + e.patch_w16, Kpp, e.ws + e.v_pe, H, B * (P - 1), H, Kpp); g.bias(F + e.v_patch_b); if (int r = run_gemm(e, g, s)) return r; }
+    CHECK_HIP(launch_vit_assemble(e.ws + e.v_pe, F + e.v_cls, F + e.v_pos, e.ws + e.v_x, B, P, H, dt, s));
+    char* xv = e.ws + e.v_x;
+    EmbedArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.ids = e.wsp<int64_t>(e.ids_all); ea.mask = e.wsp<int64_t>(e.mask_all);
+    ea.word = W + e.t_word; ea.pos = W + e.t_pos; ea.type = W + e.t_type; ea.gamma = W + e.t_eln_w; ea.beta = W + e.t_eln_b;
+    ea.x = e.ws + e.x0; ea.xhat = e.ws + e.xhat_emb; ea.rstd = e.wsp<float>(e.rstd_emb); ea.pos_ids = e.wsp<int>(e.pos_ids);
+    ea.maskbias = e.wsp<float>(e.maskbias);
+    ea.posts = Bt; ea.T = T; ea.H = H; ea.xlmr = c.txt_kind == MMHIP_TXT_XLMR; ea.pad_id = c.pad_id; ea.eps = c.ln_eps_txt;
+    ea.drop = make_drop(c.p_hidden, e.seed, STREAM_EMBED, tr);
+    CHECK_HIP(launch_embed_fwd(ea, dt, s));
+    const char* xt = e.ws + e.x0;
+    if (e.cls_only < 0) { const char* v = getenv("MMHIP_CLS_ONLY"); e.cls_only = v ? atoi(v) : 1; }
+    e.cls_compact = false;
+    const int L = c.layers_txt > c.layers_img ? c.layers_txt : c.layers_img;
+    for (int l = 0; l < L; ++l) {
+        const bool ht = l < c.layers_txt, hv = l < c.layers_img;
+        const LayerOff& ot = e.txt[ht ? l : 0];
+        const LayerW16& wt = e.txt_w16[ht ? l : 0];
+        const TextAct& a = e.tact[ht ? l : 0];
+        const LayerOff& ov = e.vit[hv ? l : 0];
+        const LayerW16& wv = e.vit_w16[hv ? l : 0];
+        const bool compact = ht && e.cls_only > 0 && l == c.layers_txt - 1;
+        const int Mr = compact ? Bt : Mt, rs = compact ? T * H : H, rmul = compact ? T : 1;
+        auto both = [&](G& gt, G& gv) -> int {
+            if (ht && hv) return run_gemm_pair(e, gt, gv, s);
+            return run_gemm(e, ht ? gt : gv, s);
+        };
+        // ---- QKV (image tower: pre-LN)
+        if (hv) {
+            LNArgs ln{xv, e.ws + e.v_ln, F + ov.ln1_w, F + ov.ln1_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+            CHECK_HIP(launch_layernorm_fwd(ln, dt, s));
+        }
+        {
+            G gt(xt, H, e.ws + wt.qkv, H, e.ws + a.qkv, 3 * H, Mt, 3 * H, H); gt.bias(W + ot.qkv_b);
+            G gv(e.ws + e.v_ln, H, e.ws + wv.qkv, H, e.ws + e.v_qkv, 3 * H, Mv, 3 * H, H); gv.bias(F + ov.qkv_b);
+            if (int r = both(gt, gv)) return r;
+        }
+        // ---- attention
+        if (ht) {
+            AttnArgs at;
+            memset(&at, 0, sizeof(at));
+            at.qkv = e.ws + a.qkv; at.maskbias = e.wsp<float>(e.maskbias); at.ctx = e.ws + a.ctx; at.lse = e.wsp<float>(a.lse);
+            at.posts = Bt; at.S = T; at.heads = c.heads; at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
+            at.scale = 1.0f / sqrtf((float)(H / c.heads));
+            at.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
+            at.q_tiles = compact ? 1 : 0;
+            CHECK_HIP(launch_attn_fwd(at, dt, s));
+        }
+        if (hv) {
+            AttnArgs at;
+            memset(&at, 0, sizeof(at));
+            at.qkv = e.ws + e.v_qkv; at.ctx = e.ws + e.v_ctx; at.posts = B; at.S = P; at.heads = e.heads_v(); at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
+            at.scale = 1.0f / sqrtf((float)(H / e.heads_v()));
+            CHECK_HIP(launch_attn_fwd(at, dt, s));
+        }
+        // ---- attention output (+ residual)
+        {
+            G gt(e.ws + a.ctx, rs, e.ws + wt.ao, H, e.ws + a.pre1, H, Mr, H, H);
+            gt.bias(W + ot.ao_b).dropout(make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr), rmul).residual(xt, rs);
+            G gv(e.ws + e.v_ctx, H, e.ws + wv.ao, H, xv, H, Mv, H, H); gv.bias(F + ov.ao_b).residual(xv, H);
+            if (int r = both(gt, gv)) return r;
+        }
+        if (ht) {
+            LNArgs ln1{e.ws + a.pre1, e.ws + a.a1, W + ot.ln1_w, W + ot.ln1_b, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), Mr, H, H, H, c.ln_eps_txt};
+            CHECK_HIP(launch_layernorm_fwd(ln1, dt, s));
+        }
+        if (hv) {
+            LNArgs ln2{xv, e.ws + e.v_ln, F + ov.ln2_w, F + ov.ln2_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+            CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
+        }
+        // ---- feed-forward
+        {
+            G gt(e.ws + a.a1, H, e.ws + wt.fc1, H, e.ws + a.h, I, Mr, I, H); gt.bias(W + ot.fc1_b).aux(e.ws + a.u, I).gelu();
+            G gv(e.ws + e.v_ln, H, e.ws + wv.fc1, H, e.ws + e.v_h, I, Mv, I, H); gv.bias(F + ov.fc1_b).gelu();
+            if (int r = both(gt, gv)) return r;
+        }
+        {
+            G gt(e.ws + a.h, I, e.ws + wt.fc2, I, e.ws + a.pre2, H, Mr, H, I);
+            gt.bias(W + ot.fc2_b).dropout(make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr), rmul).residual(e.ws + a.a1, H);
+            G gv(e.ws + e.v_h, I, e.ws + wv.fc2, I, xv, H, Mv, H, I); gv.bias(F + ov.fc2_b).residual(xv, H);
+            if (int r = both(gt, gv)) return r;
+        }
+        if (ht) {
+            LNArgs ln2{e.ws + a.pre2, e.ws + a.out, W + ot.ln2_w, W + ot.ln2_b, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), Mr, H, H, H, c.ln_eps_txt};
+            CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
+            e.cls_compact = compact;
+            xt = e.ws + a.out;
+        }
+    }
+    LNArgs lnf{xv, e.ws + e.v_out, F + e.v_ln_w, F + e.v_ln_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+    CHECK_HIP(launch_layernorm_fwd(lnf, dt, s));
+    SmallGemmArgs sp = small(e.ws + e.v_out, P * H, F + e.v_pool_w, H, F + e.v_pool_b, e.wsp<float>(e.h_vpool), H, B, H, H, ACT_TANH);
+    CHECK_HIP(launch_small_nt(sp, dt, s));
     return 0;
 }
 
@@ -876,7 +1023,10 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
         CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all + nb, tim_mask, nb, hipMemcpyDeviceToDevice, s));
     }
     if (int r = side_init(e)) return r;
-    if (use_side(e)) {
+    if (!imported && lockstep_ok(e)) {
+        e.vit_is_long = false;
+        if (int r = towers_forward_lockstep(e, pixels, s)) return r;
+    } else if (use_side(e)) {
         // the frozen image tower does not depend on the text tower: run it on the side stream, join before the heads
         CHECK_HIP(hipEventRecord(e.ev_fork, s));
         static int force = -2;

@@ -602,7 +602,9 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if (t == 10 && a.N % 96) t = 0;
     if (t == 11 && a.N % 128) t = 0;
     if (t == 12 && a.N % 96) t = 0;
-    if (t >= 13 && t <= 16) return t;
+    if ((t == 17 || t == 18) && a.N % 192) t = 0;
+    if ((t == 19 || t == 20) && a.N % 256) t = 0;
+    if (t >= 13 && t <= 20) return t;
     if (t >= 1 && t <= 12) return t;
     if (a.N % 128 && a.N % 192 == 0 && a.N % 256) { /* only the 192-wide tiles divide N */ }
     // Measured inside the training step (bench.py with MMHIP_NT_TILE forced, profiles/r01_tile_sweep.txt): 128x128 at two
@@ -634,6 +636,14 @@ static int choose_nt_tile(const GemmNTArgs& a) {
         static int nl = -1;
         if (nl < 0) { const char* e = getenv("MMHIP_NT8_NARROW"); nl = e ? atoi(e) : 0; }
         if (!narrow_long || nl) {
+            // 256 x 192 where it fills clearly more of the chip than 256 x 256 (M = 12608, N = 768: 200 tiles instead of 150)
+            static int t192on = -1;
+            if (t192on < 0) { const char* e = getenv("MMHIP_NT8_192"); t192on = e ? atoi(e) : 1; }
+            if (t192on && a.N % 192 == 0) {
+                const long t192 = tm * (a.N / 192);
+                const double u192 = (double)t192 / (double)(((t192 + 255) / 256) * 256);
+                if (u192 >= u256 + 0.1 && u192 >= th256) return t192 > 256 ? 18 : 17;
+            }
             if (u256 >= th256 && u256 >= u128 - gap) return 15;
             if (u128 >= th128) return 16;
         }
@@ -671,7 +681,9 @@ static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
     const int tile = choose_nt_tile(a);
     if (tile >= 13) {      // 13 / 14: deep-pipelined 256x256 / 256x128, one tile per workgroup; 15 / 16: the same, persistent
         const int dt = sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16;
-        if (launch_gemm_nt8(a, dt, (tile == 13 || tile == 15) ? 256 : 128, tile >= 15, s)) return;
+        // 17 / 18: 256x192, one-shot / persistent; 19 / 20: 256x256 with BK = 32 and the deep LDS ring
+        const int bn = tile >= 19 ? 257 : (tile >= 17 ? 192 : ((tile == 13 || tile == 15) ? 256 : 128));
+        if (launch_gemm_nt8(a, dt, bn, tile == 15 || tile == 16 || tile == 18 || tile == 20, s)) return;
     }
     switch (tile >= 13 ? 1 : tile) {
         case 12: launch_nt_t<T, 256, 96, 4, 2, 3, 4>(a, s); break;    // role-specialised, 256 tiles for 8192 x 768: one tile per CU

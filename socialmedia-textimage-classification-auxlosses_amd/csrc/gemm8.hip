@@ -1,6 +1,6 @@
 // Deep-pipelined NT GEMM for gfx950:  C[M,N] = epilogue(A[M,K] . B[N,K]^T), 16-bit operands, fp32 accumulate.
 //
-// One 512-thread workgroup per CU (8 waves = 4 along M x 2 along N), a 256 x BN output tile (BN = 256 or 128), BK = 64.
+// One 512-thread workgroup per CU (8 waves = 4 along M x 2 along N), a 256 x BN output tile (BN = 256, 192 or 128), BK = 64.
 // Structure (cdna_hip_programming.md, "The 256^2 8-phase template", re-derived for this tile family):
 //   * operand K-tiles live in an LDS ring (2 buffers of 64 KB for BN = 256, 3 of 48 KB for BN = 128), filled by LDS-DMA
 //     (global_load_lds_dwordx4, 1 KB pieces = 8 tile rows x 128 B) that stays in flight ACROSS barriers: every wait is a
@@ -35,16 +35,23 @@ struct P8 {
     static constexpr int NBUF = BN == 128 ? 3 : 2;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, KT = A_BYTES + B_BYTES;
     static constexpr int LDS = NBUF * KT;
-    static constexpr int GPP = BN == 128 ? 3 : 2;          // LDS-DMA instructions per wave and phase
-    static constexpr int NSRC = NPH * GPP;
+    static constexpr int GPP = BN == 128 ? 3 : (BN == 192 ? 4 : 2);          // most LDS-DMA instructions per wave in one phase
+    // LDS-DMA instructions per wave in phase p (uniform over the waves: the counted waits rely on it)
+    static constexpr int gpp(int p) { return BN == 192 ? (p == 0 ? 2 : (p == 1 ? 1 : 4)) : GPP; }
 };
 
 // staging plan.  (phase p, slot jj) -> operand, piece index (a function of the wave), target K-tile offset
 //   BN = 256: p=2: A rows 0-127 of K-tile kt+2 | p=3: A rows 128-255 of kt+2 | p=0: B columns of phases 0,1 of kt+1 | p=1: phases 2,3 of kt+1
 //   BN = 128: p=0: A rows 0-127 + B columns of phase 0 of kt+2 | p=1: A rows 128-255 + B columns of phase 1 of kt+2
-template <int BN> __device__ __forceinline__ constexpr bool st_is_b(int p, int jj) { return BN == 256 ? (p < 2) : (jj == 2); }
-template <int BN> __device__ __forceinline__ constexpr int st_ahead(int p) { return BN == 256 ? (p < 2 ? 1 : 2) : 2; }
+//   BN = 192: p=0: B columns of phases 0,1 of kt+1 (2 per wave) | p=1: B columns of phase 2 of kt+1 (1) | p=2: all of A of kt+2 (4)
+//             (A is read in phase 0 only, so its slots are free from phase 2 on; a B slot is restaged >= 2 phases after its read)
+template <int BN> __device__ __forceinline__ constexpr bool st_is_b(int p, int jj) { return BN == 256 ? (p < 2) : (BN == 192 ? (p < 2) : (jj == 2)); }
 template <int BN> __device__ __forceinline__ int st_piece(int p, int jj, int w) {
+    if (BN == 192) {
+        if (p == 0) { const int q = w * 2 + jj; return q < 8 ? q : q + 4; }       // wn = 0: pieces 0-7, wn = 1: 12-19
+        if (p == 1) return w < 4 ? 8 + w : 16 + w;                                  // wn = 0: 8-11, wn = 1: 20-23
+        return w * 4 + jj;
+    }
     if (BN == 256) {
         const int q = w * 2 + jj;
         if (p == 2) return q;
@@ -128,18 +135,74 @@ __device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, 
     }
 }
 
+// epilogue of one 256 x (2 TN) tile from the accumulators: lane holds C[m][n .. n+7], m = m0 + wm*64 + 16 i + (lane&15),
+// n = n0 + wn*TN + 32 j' + 8 (lane>>4); values 0-3 from fragment 2j', 4-7 from fragment 2j'+1
+template <typename T, int FN, int TN, int EPI>
+__device__ __forceinline__ void tile_epilogue8(const GemmNTArgs& a, f32x4 (&acc)[4][FN], int m0, int n0, int wm, int wn, int l15, int kc) {
+    typedef typename Vec<T>::v8 v8;
+        // every load of the epilogue first (bias; residual or mul_in of all the lane's fragments), then compute, then stores.
+        // Rows past M: loads read (clamped) row M-1, stores are masked -- C may alias the residual (x += f(x) in the image tower),
+        // so a duplicate of row M-1 must never be stored: another wave could read it back as residual.
+        const int nb = n0 + wn * TN + 8 * kc;
+        float bias8[FN / 2][8];
+#pragma unroll
+        for (int jp = 0; jp < FN / 2; ++jp) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[jp][e] = 0.f;
+            if (EPI == EP_GELU || (a.flags & GEMM_BIAS)) {
+                f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + nb + 32 * jp), b1 = *reinterpret_cast<const f32x4*>(a.bias + nb + 32 * jp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bias8[jp][e] = b0[e]; bias8[jp][4 + e] = b1[e]; }
+            }
+        }
+        // (BN = 256: two chunks of two fragment-pair columns -- 64 more registers for all sixteen residual fragments would spill)
+#pragma unroll
+        for (int jc = 0; jc < FN / 2; jc += 2) {
+            v8 pre[4][2];
+            const T* pbase = (EPI == EP_MULG) ? (const T*)a.mul_in : (const T*)a.residual;
+            const int pld = (EPI == EP_MULG) ? a.ldmul : a.ldres;
+            const bool want = (EPI == EP_MULG) || ((EPI == EP_PLAIN || EPI == EP_ANY) && (a.flags & GEMM_RESIDUAL));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    if (EPI != EP_GELU && want && jc + j2 < FN / 2) {
+                        const int m = min(m0 + wm * 64 + i * 16 + l15, a.M - 1);
+                        pre[i][j2] = *reinterpret_cast<const v8*>(pbase + (size_t)m * pld + nb + 32 * (jc + j2));
+                    }
+                }
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int jp = jc + j2;
+                if (jp >= FN / 2) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + wm * 64 + i * 16 + l15;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e] + bias8[jp][e]; v[4 + e] = acc[i][2 * jp + 1][e] + bias8[jp][4 + e]; }
+                    if (m < a.M) epilogue8<T, EPI>(a, v, m, nb + 32 * jp, pre[i][j2]);
+                }
+            }
+        }
+}
+
+// One or two problems of equal N and K per launch (GemmNTPair): the tiles of problem 0 come first in the work list, then the
+// tiles of problem 1 -- the two towers' GEMMs of one layer share a launch, so the rounds of 256 workgroups fill up
+// (M = 8192 and M = 12608 at N = 2304: 288 + 450 = 738 tiles = 2.9 rounds instead of 2 + 2).
 template <typename T, int BN, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTArgs a, int persistent) {
+__global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int persistent) {
     using C = P8<BN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1, grp = w >> 2;
-    const int tilesN = a.N / BN, tilesM = (a.M + C::BM - 1) / C::BM, ntiles = tilesN * tilesM;
-    const int nk = a.K / C::BK;
-    const char* __restrict__ Ab = (const char*)a.A;
-    const char* __restrict__ Bb = (const char*)a.B;
+    const int tilesN = g.p[0].N / BN;
+    const int tilesM0 = (g.p[0].M + C::BM - 1) / C::BM, tiles0 = tilesN * tilesM0;
+    const int tilesM1 = g.count > 1 ? (g.p[1].M + C::BM - 1) / C::BM : 0, ntiles = tiles0 + tilesN * tilesM1;
+    const int nk = g.p[0].K / C::BK;
+    const unsigned long long t_start = wall_clock64();
 
     // ---- work list: tiles first, first + stride, ... in the column-group raster (see gemm.hip), XCD-contiguous
     const int nwg = gridDim.x;
@@ -156,12 +219,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTArgs a, int pers
     }
     if (count <= 0) return;
     constexpr int GW = 8;
-    auto tile_origin = [&](int id, int& m0, int& n0) {
-        const int per_group = tilesM * GW;
-        const int g = id / per_group, rem = id - g * per_group;
-        const int gw = min(GW, tilesN - g * GW);
+    // -> problem index; tiles of a problem in the column-group raster
+    auto tile_origin = [&](int id, int& m0, int& n0) -> int {
+        const int which = id >= tiles0 ? 1 : 0;
+        if (which) id -= tiles0;
+        const int per_group = (which ? tilesM1 : tilesM0) * GW;
+        const int cg = id / per_group, rem = id - cg * per_group;
+        const int gw = min(GW, tilesN - cg * GW);
         m0 = (rem / gw) * C::BM;
-        n0 = (g * GW + rem % gw) * BN;
+        n0 = (cg * GW + rem % gw) * BN;
+        return which;
     };
 
     // ---- the DMA stream.  K-tiles are numbered globally over the work list (tile t, K-tile k -> t*nk + k); the staging
@@ -175,9 +242,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTArgs a, int pers
     auto rebase = [&](auto pc_, int id) {
         constexpr int p = decltype(pc_)::value;
         int m0, n0;
-        tile_origin(id, m0, n0);
+        const GemmNTArgs& a = g.p[tile_origin(id, m0, n0)];
+        const char* __restrict__ Ab = (const char*)a.A;
+        const char* __restrict__ Bb = (const char*)a.B;
 #pragma unroll
-        for (int jj = 0; jj < C::GPP; ++jj) {
+        for (int jj = 0; jj < C::gpp(p); ++jj) {
             const int pc = st_piece<BN>(p, jj, w), row = pc * 8 + lrow;
             if (st_is_b<BN>(p, jj)) {
                 const int sw = (lrow & 3) | ((pc & 1) << 2);
@@ -198,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTArgs a, int pers
         }
         char* base = smem + g_buf[p] * C::KT;
 #pragma unroll
-        for (int jj = 0; jj < C::GPP; ++jj) {
+        for (int jj = 0; jj < C::gpp(p); ++jj) {
             const int pc = st_piece<BN>(p, jj, w);
             char* dst = base + (st_is_b<BN>(p, jj) ? C::A_BYTES : 0) + pc * 1024;
             __builtin_amdgcn_global_load_lds(MM_GLB(src[p][jj]), MM_LDS(dst), 16, 0, 0);
@@ -244,12 +313,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTArgs a, int pers
         stage(I2{}); stage(I3{}); stage(I0{}); stage(I1{});
         if (total_kt > 1) { stage(I2{}); stage(I3{}); wait_vm<6>(); }
         else wait_vm<2>();
+    } else if constexpr (BN == 192) {
+        init_group(I2{});
+        stage(I2{}); stage(I0{}); stage(I1{});                       // A(0), B phases 0,1 (0), B phase 2 (0)
+        if (total_kt > 1) { stage(I2{}); wait_vm<5>(); }             // A(1); B phase 2 (0) + A(1) may stay in flight
+        else wait_vm<1>();
     } else {
         stage(I0{}); stage(I1{});
         if (total_kt > 1) { stage(I0{}); stage(I1{}); wait_vm<6>(); }
         else wait_vm<0>();
     }
     raw_barrier();
+    // profiling hook (GEMM_DEBUG_TS, tools/gemm8_ts.py): wave 0 stamps the 100 MHz wall clock at the end of the prologue and, per
+    // tile, after the K loop and after the epilogue's last store was issued
+    unsigned long long* ts = (g.p[0].flags & GEMM_DEBUG_TS) ? (unsigned long long*)g.p[0].aux + (size_t)blockIdx.x * 64 : nullptr;
+    int nts = 0;
+    auto stamp = [&]() { if (ts && tid == 0 && nts < 64) ts[nts++] = wall_clock64(); };
+    if (ts && tid == 0) ts[nts++] = t_start;
+    stamp();
     if (grp == 1) raw_barrier();          // waves 4-7 run one interval behind
 
     int gkt = 0, cbuf = 0;
@@ -277,6 +358,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTArgs a, int pers
                 if (BN == 256) {
                     if (p == 1) { if (gkt + 1 < total_kt) wait_vm<8>(); else wait_vm<0>(); }
                     if (p == 3) { if (gkt + 2 < total_kt) wait_vm<6>(); else if (gkt + 1 < total_kt) wait_vm<2>(); }
+                } else if (BN == 192) {
+                    // p=1: B phase 2 of THIS K-tile must have landed; issued after it: A(kt+1) 4, B01(kt+1) 2, B2(kt+1) 1
+                    if (p == 1) { if (gkt + 1 < total_kt) wait_vm<7>(); else wait_vm<0>(); }
+                    // p=2: A(kt+1) and B01(kt+1) for the next phase 0; issued after them: B2(kt+1) 1, A(kt+2) 4
+                    if (p == 2) { if (gkt + 2 < total_kt) wait_vm<5>(); else if (gkt + 1 < total_kt) wait_vm<1>(); }
                 } else {
                     if (p == 1) { if (gkt + 2 < total_kt) wait_vm<6>(); else if (gkt + 1 < total_kt) wait_vm<0>(); }
                 }
@@ -294,62 +380,188 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTArgs a, int pers
             };
             phase(I0{});
             phase(I1{});
-            if constexpr (C::NPH == 4) {
-                phase(I2{});
-                phase(I3{});
-            }
+            if constexpr (C::NPH >= 3) phase(I2{});
+            if constexpr (C::NPH == 4) phase(I3{});
         }
+        stamp();
         // ---- epilogue of tile t, from registers: lane holds C[m][n .. n+7], m = m0 + wm*64 + 16 i + (lane&15),
         // n = n0 + wn*TN + 32 j' + 8 (lane>>4); values 0-3 from fragment 2j', 4-7 from fragment 2j'+1
         int m0, n0;
-        tile_origin(first + t * stride, m0, n0);
-        // every load of the epilogue first (bias; residual or mul_in of all the lane's fragments), then compute, then stores.
-        // Rows past M: loads read (clamped) row M-1, stores are masked -- C may alias the residual (x += f(x) in the image tower),
-        // so a duplicate of row M-1 must never be stored: another wave could read it back as residual.
-        const int nb = n0 + wn * C::TN + 8 * kc;
-        float bias8[C::FN / 2][8];
+        const GemmNTArgs& a = g.p[tile_origin(first + t * stride, m0, n0)];
+        tile_epilogue8<T, C::FN, C::TN, EPI>(a, acc, m0, n0, wm, wn, l15, kc);
+        zero_acc();
+        stamp();
+    }
+    if (ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); }
+    if (grp == 0) raw_barrier();          // matches the extra interval of waves 4-7
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, BK = 32, NBUF-deep LDS ring (NBUF = 5: 160 KB).  Why: with 12 K-steps per tile (K = 768) and operands that
+// come from beyond the XCD's L2, the kernel above is bound by the LDS-DMA bytes it can keep in flight, not by the matrix pipe --
+// in-kernel stamps (tools/gemm8_ts.py) put its K-step at 1.86 us against 0.85 us of MFMA work, and its two 64 KB buffers allow
+// one K-tile of B / two of A ahead (<= 64-96 KB in flight; MI355X_MICROARCH.md "Indexed rows: gather into LDS": 33 GB/s per
+// CU from the Infinity Cache at 72 KB in flight).  Halving the K-tile and spending all of the LDS on the ring keeps
+// NBUF - 1 = 4 K-tiles = 128 KB in flight per CU.
+//   * K-tile = 32 KB: A 256 rows x 64 B, B 256 rows x 64 B; a row's four 16-byte chunks are stored at chunk ^ g(row), g = (-(row>>2)) & 3:
+//     conflict-free for the 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md LDS table) for both the A rows (16 consecutive) and
+//     the permuted B rows of a fragment pair;
+//   * two phases per K-tile (fragment pairs 2p, 2p+1: 16 MFMA 16x16x32 per wave each), L / C intervals and the one-interval skew of
+//     waves 4-7 as above; phase 0 stages A, phase 1 stages B of K-tile kt + NBUF - 1 (2 LDS-DMA instructions per wave and phase) into
+//     the buffer K-tile kt - 1 has just left (A read in its phase 0, B columns in phases 0 / 1: >= 2 phases ago);
+//   * one counted wait per K-tile (phase 1): everything up to K-tile kt + 1 has landed, 4 (NBUF - 2) instructions stay in flight.
+template <int NBUF_>
+struct P32 {
+    static constexpr int BM = 256, BN = 256, BK = 32, TN = 128, FN = 8, NBUF = NBUF_, AH = NBUF_ - 1;
+    static constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, KT = A_BYTES + B_BYTES;
+    static constexpr int LDS = NBUF * KT;
+};
+template <int N> __device__ __forceinline__ void wait_vm_le(int n) {
+    // wait until at most min(n, N) * 4 vector-memory operations are outstanding (n is wave-uniform)
+    if constexpr (N == 0) { wait_vm<0>(); }
+    else { if (n >= N) wait_vm<4 * N>(); else wait_vm_le<N - 1>(n); }
+}
+
+template <typename T, int NBUF, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt8k32_kernel(GemmNTPair g, int persistent) {
+    using C = P32<NBUF>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Vec<T>::v8 v8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1, grp = w >> 2;
+    const int tilesN = g.p[0].N / C::BN;
+    const int tilesM0 = (g.p[0].M + C::BM - 1) / C::BM, tiles0 = tilesN * tilesM0;
+    const int tilesM1 = g.count > 1 ? (g.p[1].M + C::BM - 1) / C::BM : 0, ntiles = tiles0 + tilesN * tilesM1;
+    const int nk = g.p[0].K / C::BK;
+    const int nwg = gridDim.x;
+    int first, stride, count;
+    if (persistent) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, wpx = (nwg + 7 - x) / 8;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, n_x = q + (x < r ? 1 : 0);
+        first = lo + j; stride = wpx; count = j < n_x ? (n_x - j + wpx - 1) / wpx : 0;
+    } else {
+        first = xcd_remap(blockIdx.x, nwg); stride = 0; count = 1;
+    }
+    if (count <= 0) return;
+    constexpr int GW = 8;
+    auto tile_origin = [&](int id, int& m0, int& n0) -> int {
+        const int which = id >= tiles0 ? 1 : 0;
+        if (which) id -= tiles0;
+        const int per_group = (which ? tilesM1 : tilesM0) * GW;
+        const int cg = id / per_group, rem = id - cg * per_group;
+        const int gw = min(GW, tilesN - cg * GW);
+        m0 = (rem / gw) * C::BM;
+        n0 = (cg * GW + rem % gw) * C::BN;
+        return which;
+    };
+
+    // ---- the DMA stream: group 0 = A (staged in phase 0), group 1 = B (phase 1); piece = 16 rows x 64 B, pieces 2w, 2w+1 of the operand
+    const int prow = lane >> 2, pchunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);      // row in the piece; logical chunk of this lane's LDS position
+    const int total_kt = count * nk;
+    const char* src[2][2];
+    int g_rem[2], g_tile[2], g_buf[2], g_done[2];
+    auto rebase = [&](int grp_, int id) {
+        int m0, n0;
+        const GemmNTArgs& a = g.p[tile_origin(id, m0, n0)];
 #pragma unroll
-        for (int jp = 0; jp < C::FN / 2; ++jp) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[jp][e] = 0.f;
-            if (EPI == EP_GELU || (a.flags & GEMM_BIAS)) {
-                f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + nb + 32 * jp), b1 = *reinterpret_cast<const f32x4*>(a.bias + nb + 32 * jp + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { bias8[jp][e] = b0[e]; bias8[jp][4 + e] = b1[e]; }
-            }
+        for (int jj = 0; jj < 2; ++jj) {
+            const int row = (w * 2 + jj) * 16 + prow;
+            if (grp_) src[1][jj] = (const char*)a.B + ((size_t)(n0 + row) * a.ldb + (size_t)(pchunk * 8)) * 2;
+            else src[0][jj] = (const char*)a.A + ((size_t)min(m0 + row, a.M - 1) * a.lda + (size_t)(pchunk * 8)) * 2;
         }
-        // (BN = 256: two chunks of two fragment-pair columns -- 64 more registers for all sixteen residual fragments would spill)
-#pragma unroll
-        for (int jc = 0; jc < C::FN / 2; jc += 2) {
-            v8 pre[4][2];
-            const T* pbase = (EPI == EP_MULG) ? (const T*)a.mul_in : (const T*)a.residual;
-            const int pld = (EPI == EP_MULG) ? a.ldmul : a.ldres;
-            const bool want = (EPI == EP_MULG) || ((EPI == EP_PLAIN || EPI == EP_ANY) && (a.flags & GEMM_RESIDUAL));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j2 = 0; j2 < 2; ++j2) {
-                    if (EPI != EP_GELU && want) {
-                        const int m = min(m0 + wm * 64 + i * 16 + l15, a.M - 1);
-                        pre[i][j2] = *reinterpret_cast<const v8*>(pbase + (size_t)m * pld + nb + 32 * (jc + j2));
-                    }
-                }
-#pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2) {
-                const int jp = jc + j2;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = m0 + wm * 64 + i * 16 + l15;
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e] + bias8[jp][e]; v[4 + e] = acc[i][2 * jp + 1][e] + bias8[jp][4 + e]; }
-                    if (m < a.M) epilogue8<T, EPI>(a, v, m, nb + 32 * jp, pre[i][j2]);
-                }
-            }
+    };
+    auto stage = [&](auto gc_) {
+        constexpr int gi = decltype(gc_)::value;
+        if (g_done[gi] >= total_kt) return;
+        if (g_rem[gi] == 0) {
+            g_tile[gi] += 1;
+            g_rem[gi] = nk;
+            rebase(gi, first + g_tile[gi] * stride);
         }
+        char* base = smem + g_buf[gi] * C::KT + (gi ? C::A_BYTES : 0);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            __builtin_amdgcn_global_load_lds(MM_GLB(src[gi][jj]), MM_LDS(base + (w * 2 + jj) * 1024), 16, 0, 0);
+            src[gi][jj] += 64;
+        }
+        g_rem[gi] -= 1;
+        g_done[gi] += 1;
+        g_buf[gi] = (g_buf[gi] + 1 == C::NBUF) ? 0 : g_buf[gi] + 1;
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) { g_rem[gi] = nk; g_tile[gi] = 0; g_buf[gi] = 0; g_done[gi] = 0; rebase(gi, first); }
+
+    f32x4 acc[4][C::FN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+
+    // fragment read offsets: A row = wm*64 + 16 i + (lane&15); B row = wn*128 + 32 j' + 8 ((lane&15)>>2) + 4 h + (lane&3);
+    // 16-byte chunk (lane>>4) stored at chunk ^ g(row)
+    const int l15 = lane & 15, kc = lane >> 4;
+    const int a_off = (wm * 64 + l15) * 64 + ((kc ^ ((0 - (l15 >> 2)) & 3)) << 4);
+    int b_off[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = wn * C::TN + 8 * (l15 >> 2) + 4 * h + (lane & 3);
+        b_off[h] = C::A_BYTES + r * 64 + ((kc ^ ((0 - (r >> 2)) & 3)) << 4);
+    }
+    v8 af[4], bf[2][2];
+
+    // ---- prologue: K-tiles 0 .. AH-1
+#pragma unroll
+    for (int i = 0; i < C::AH; ++i) { stage(I0{}); stage(I1{}); }
+    wait_vm_le<C::AH - 1>(min(C::AH, total_kt) - 1);
+    raw_barrier();
+    if (grp == 1) raw_barrier();
+
+    int gkt = 0, cbuf = 0;
+    for (int t = 0; t < count; ++t) {
+#pragma unroll 1
+        for (int k = 0; k < nk; ++k, ++gkt) {
+            const char* Ks = smem + cbuf * C::KT;
+            cbuf = (cbuf + 1 == C::NBUF) ? 0 : cbuf + 1;
+            auto phase = [&](auto pc_) {
+                constexpr int p = decltype(pc_)::value;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) bf[jj][h] = lds_read8<T>(Ks, b_off[h] + (32 * (2 * p + jj)) * 64);
+                if (p == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = lds_read8<T>(Ks, a_off + i * (16 * 64));
+                }
+                stage(pc_);
+                if (p == 1) wait_vm_le<C::AH - 1>(total_kt - gkt - 2);
+                raw_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            acc[i][2 * (2 * p + jj) + h] = mfma16(bf[jj][h], af[i], acc[i][2 * (2 * p + jj) + h]);
+                __builtin_amdgcn_s_setprio(0);
+                raw_barrier();
+            };
+            phase(I0{});
+            phase(I1{});
+        }
+        int m0, n0;
+        const GemmNTArgs& a = g.p[tile_origin(first + t * stride, m0, n0)];
+        tile_epilogue8<T, C::FN, C::TN, EPI>(a, acc, m0, n0, wm, wn, l15, kc);
         zero_acc();
     }
-    if (grp == 0) raw_barrier();          // matches the extra interval of waves 4-7
+    if (grp == 0) raw_barrier();
 }
 
 static bool nt8_ok(const GemmNTArgs& a, int bn) {
@@ -362,28 +574,108 @@ static bool nt8_ok(const GemmNTArgs& a, int bn) {
 }
 
 template <typename T, int BN, int EPI>
-static void launch_nt8_e(const GemmNTArgs& a, int persistent, hipStream_t s) {
+static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
     using C = P8<BN>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<T, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
-    const int ntiles = ((a.M + C::BM - 1) / C::BM) * (a.N / BN);
+    int ntiles = 0;
+    for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / BN);
     const int grid = persistent ? (ntiles < 256 ? ntiles : 256) : ntiles;
-    hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI>), dim3(grid), dim3(512), C::LDS, s, a, persistent && ntiles > 256 ? 1 : 0);
+    hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI>), dim3(grid), dim3(512), C::LDS, s, g, persistent && ntiles > 256 ? 1 : 0);
+}
+template <typename T, int NBUF, int EPI>
+static void launch_nt8k32_e(const GemmNTPair& g, int persistent, hipStream_t s) {
+    using C = P32<NBUF>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8k32_kernel<T, NBUF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
+    int ntiles = 0;
+    for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / C::BN);
+    const int grid = persistent ? (ntiles < 256 ? ntiles : 256) : ntiles;
+    hipLaunchKernelGGL((gemm_nt8k32_kernel<T, NBUF, EPI>), dim3(grid), dim3(512), C::LDS, s, g, persistent && ntiles > 256 ? 1 : 0);
+}
+// epilogue class that covers a flag set (a pair uses the class that covers both)
+static int nt8_class(int f) {
+    f &= ~GEMM_DEBUG_TS;
+    if (f == (GEMM_BIAS | GEMM_GELU) || f == (GEMM_BIAS | GEMM_GELU | GEMM_AUX_PRE)) return EP_GELU;
+    if (f == GEMM_MUL_GELU_GRAD || f == (GEMM_MUL_GELU_GRAD | GEMM_RESIDUAL)) return EP_MULG;
+    if (!(f & ~(GEMM_BIAS | GEMM_DROPOUT | GEMM_RESIDUAL))) return EP_PLAIN;
+    return EP_ANY;
+}
+static int nt8_ring() {          // MMHIP_NT8_RING: K-tiles in the ring of the BK = 32 kernel (4 = 128 KB, 5 = 160 KB)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MMHIP_NT8_RING"); v = e ? atoi(e) : 5; }
+    return v;
+}
+template <typename T>
+static void launch_nt8k32_t(const GemmNTPair& g, int persistent, hipStream_t s) {
+    int c = nt8_class(g.p[0].flags);
+    if (g.count > 1 && nt8_class(g.p[1].flags) != c) c = EP_ANY;
+    if (nt8_ring() == 4) {
+        if (c == EP_GELU) launch_nt8k32_e<T, 4, EP_GELU>(g, persistent, s);
+        else if (c == EP_MULG) launch_nt8k32_e<T, 4, EP_MULG>(g, persistent, s);
+        else if (c == EP_PLAIN) launch_nt8k32_e<T, 4, EP_PLAIN>(g, persistent, s);
+        else launch_nt8k32_e<T, 4, EP_ANY>(g, persistent, s);
+    } else {
+        if (c == EP_GELU) launch_nt8k32_e<T, 5, EP_GELU>(g, persistent, s);
+        else if (c == EP_MULG) launch_nt8k32_e<T, 5, EP_MULG>(g, persistent, s);
+        else if (c == EP_PLAIN) launch_nt8k32_e<T, 5, EP_PLAIN>(g, persistent, s);
+        else launch_nt8k32_e<T, 5, EP_ANY>(g, persistent, s);
+    }
 }
 template <typename T, int BN>
-static void launch_nt8_t(const GemmNTArgs& a, int persistent, hipStream_t s) {
-    const int f = a.flags;
-    if (f == (GEMM_BIAS | GEMM_GELU) || f == (GEMM_BIAS | GEMM_GELU | GEMM_AUX_PRE)) launch_nt8_e<T, BN, EP_GELU>(a, persistent, s);
-    else if (f == GEMM_MUL_GELU_GRAD || f == (GEMM_MUL_GELU_GRAD | GEMM_RESIDUAL)) launch_nt8_e<T, BN, EP_MULG>(a, persistent, s);
-    else if (!(f & ~(GEMM_BIAS | GEMM_DROPOUT | GEMM_RESIDUAL))) launch_nt8_e<T, BN, EP_PLAIN>(a, persistent, s);
-    else launch_nt8_e<T, BN, EP_ANY>(a, persistent, s);
+static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
+    int c = nt8_class(g.p[0].flags);
+    if (g.count > 1 && nt8_class(g.p[1].flags) != c) c = EP_ANY;
+    if (c == EP_GELU) launch_nt8_e<T, BN, EP_GELU>(g, persistent, s);
+    else if (c == EP_MULG) launch_nt8_e<T, BN, EP_MULG>(g, persistent, s);
+    else if (c == EP_PLAIN) launch_nt8_e<T, BN, EP_PLAIN>(g, persistent, s);
+    else launch_nt8_e<T, BN, EP_ANY>(g, persistent, s);
+}
+static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent, hipStream_t s) {
+    if (bn == 257) {             // 256 x 256, BK = 32, deep ring
+        if (dtype == DT_BF16) launch_nt8k32_t<bf16_t>(g, persistent, s);
+        else launch_nt8k32_t<f16_t>(g, persistent, s);
+        return;
+    }
+    if (dtype == DT_BF16) {
+        if (bn == 256) launch_nt8_t<bf16_t, 256>(g, persistent, s);
+        else if (bn == 192) launch_nt8_t<bf16_t, 192>(g, persistent, s);
+        else launch_nt8_t<bf16_t, 128>(g, persistent, s);
+    } else {
+        if (bn == 256) launch_nt8_t<f16_t, 256>(g, persistent, s);
+        else if (bn == 192) launch_nt8_t<f16_t, 192>(g, persistent, s);
+        else launch_nt8_t<f16_t, 128>(g, persistent, s);
+    }
 }
 
-// bn: 256 or 128.  Returns false when the shape rules of the kernel do not hold (caller falls back).
+// bn: 256, 192 or 128; 257 = 256 x 256 with BK = 32 and the deep ring.  Returns false when the shape rules of the kernel do not
+// hold (caller falls back).
 bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hipStream_t s) {
-    if (!nt8_ok(a, bn)) return false;
-    if (dtype == DT_BF16) { if (bn == 256) launch_nt8_t<bf16_t, 256>(a, persistent, s); else launch_nt8_t<bf16_t, 128>(a, persistent, s); }
-    else { if (bn == 256) launch_nt8_t<f16_t, 256>(a, persistent, s); else launch_nt8_t<f16_t, 128>(a, persistent, s); }
+    if ((bn != 257 && bn != 256 && bn != 192 && bn != 128) || !nt8_ok(a, bn == 257 ? 256 : bn)) return false;
+    GemmNTPair g;
+    g.p[0] = a; g.p[1] = a; g.count = 1;
+    launch_nt8_d(g, dtype, bn, persistent, s);
+    return true;
+}
+
+// two problems of equal N and K in one persistent launch; bn = 0 picks the tile that fills the rounds of 256 workgroups best.
+// false = rules not met (caller launches them one by one)
+bool launch_gemm_nt8_pair(const GemmNTArgs& a0, const GemmNTArgs& a1, int dtype, int bn, hipStream_t s) {
+    if (dtype != DT_BF16 && dtype != DT_F16) return false;
+    if (a0.N != a1.N || a0.K != a1.K) return false;
+    if (bn == 0) {
+        double best = 0;
+        for (int cand : {256, 192, 128}) {
+            if (a0.N % cand) continue;
+            const long t = (long)((a0.M + 255) / 256 + (a1.M + 255) / 256) * (a0.N / cand);
+            const double u = (double)t / (double)(((t + 255) / 256) * 256) + (cand == 256 ? 0.04 : (cand == 192 ? 0.02 : 0.0));   // ties -> wider
+            if (u > best) { best = u; bn = cand; }
+        }
+    }
+    if ((bn != 256 && bn != 192 && bn != 128) || !nt8_ok(a0, bn) || !nt8_ok(a1, bn)) return false;
+    GemmNTPair g;
+    g.p[0] = a0; g.p[1] = a1; g.count = 2;
+    launch_nt8_d(g, dtype, bn, 1, s);
     return true;
 }
 

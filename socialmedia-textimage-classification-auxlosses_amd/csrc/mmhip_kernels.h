@@ -20,6 +20,7 @@ enum {
     GEMM_MUL_GELU_GRAD = 64,  // value *= gelu'(mul_in[m][n])
     GEMM_TANH = 128,
     GEMM_QGELU = 256,         // quick-GELU x * sigmoid(1.702 x)   (HF CLIP hidden_act "quick_gelu")
+    GEMM_DEBUG_TS = 1 << 20,  // gemm8.hip only (tools/gemm8_ts.py): workgroup b writes wall-clock stamps to ((u64*)aux)[b*64 ..]
 };
 struct GemmNTArgs {
     const void* A; const void* B; void* C; void* aux; const float* bias; const void* residual; const void* mul_in;
@@ -31,6 +32,7 @@ struct GemmNTArgs {
                               // masks of the full [posts*T, N] tensor
     DropCfg drop;
 };
+struct GemmNTPair { GemmNTArgs p[2]; int count; };      // gemm8.hip: one or two problems of equal N and K per launch
 static constexpr int GEMM_TN_MAX_GROUP = 8;
 struct GemmTNProblem {
     const void* A; const void* B; float* C;
@@ -51,6 +53,8 @@ struct SmallGemmArgs {
 hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s);
 // deep-pipelined 256 x bn tiles (gemm8.hip); false = shape rules not met, nothing launched
 bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hipStream_t s);
+// two problems of equal N and K in one persistent launch (the two towers' GEMMs of one layer); bn = 0: best-filling tile
+bool launch_gemm_nt8_pair(const GemmNTArgs& a0, const GemmNTArgs& a1, int dtype, int bn, hipStream_t s);
 hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha = 1.0f);
 // parity mode (fp32 activations, three bf16 MFMA products of split operands / fp32 attention): csrc/x3.hip
 hipError_t launch_gemm_nt_x3(const GemmNTArgs& a, hipStream_t s);

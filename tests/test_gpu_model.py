@@ -636,3 +636,14 @@ def test_eval_loop_matches_reference_golden(dtype, tag, itc, itm):
     assert rel < {"bf16x3": 1e-4, "bf16": 5e-3, "f16": 1e-3}[dtype], (res["loss"], ref_loss)
     assert sure.sum() >= (len(sure) - 2 if dtype == "bf16x3" else 1)
     assert np.array_equal(res["predictions"][sure], z[tag + ".predictions"][sure])
+
+
+def test_lockstep_forward_of_both_towers_matches_reference_golden():
+    """MMHIP_LOCKSTEP=1 (opt-in): both towers layer by layer on one stream, same-named GEMMs of a layer paired in one persistent
+    launch (csrc/gemm8.hip GemmNTPair) -- same goldens, same bands; the switch is read once per process, hence the subprocess"""
+    import subprocess, sys
+    env = dict(os.environ, MMHIP_LOCKSTEP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "(forward_matches_reference_golden or train_losses_and_grads or ragged_shapes) and not bf16x3 and not lockstep"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -1,8 +1,12 @@
-# same-box A/B of an environment setting: bash tools/ab_env.sh "MMHIP_NT_RULE=8" [bench args]
-SETTING=$1; shift
-for i in 1 2 3; do
-  for which in base with; do
-    if [ $which = with ]; then export $SETTING; else unset ${SETTING%%=*}; fi
-    python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$which', d['ms_per_step'], d['fwd_bwd_ms'], d['roofline']['achieved'])"
+#!/bin/bash
+# usage: ab_env.sh "ENV1=a ENV2=b" "ENV1=c" ...   -- same-box A/B of bench.py under different environments (two rounds)
+for round in 1 2; do
+  for envs in "$@"; do
+    out=$(env $envs python bench.py --no-cpu-baseline ${BENCH_ARGS:-} 2>/dev/null | tail -1)
+    python - "$round" "$envs" "$out" <<'PY'
+import json, sys
+d = json.loads(sys.argv[3])
+print(sys.argv[1], "|", sys.argv[2], "|", d["ms_per_step"], d["fwd_bwd_ms"], d["roofline"]["frac"], d["roofline"]["frac_serial"], flush=True)
+PY
   done
 done

@@ -16,7 +16,7 @@ dev = torch.device("cuda:0")
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 
-VARIANTS = [("r1 auto", 0), ("128x128", 1), ("8ph 256x256", 13), ("8ph 256x128", 14), ("8ph 256x256 P", 15), ("8ph 256x128 P", 16)]
+VARIANTS = [("r1 auto", 0), ("128x128", 1), ("8ph 256x256", 13), ("8ph 256x128", 14), ("8ph 256x256 P", 15), ("8ph 256x128 P", 16), ("8ph 256x192", 17), ("8ph 256x192 P", 18), ("k32 256x256", 19), ("k32 256x256 P", 20)]
 
 
 def main():
@@ -26,6 +26,8 @@ def main():
               ("txt dx_qkv", 8192, 768, 2304), ("vit qkv", 12608, 2304, 768), ("vit ao", 12608, 768, 768), ("vit fc1", 12608, 3072, 768),
               ("vit fc2", 12608, 768, 3072), ("itm qkv", 16384, 2304, 768), ("itm fc1", 16384, 3072, 768), ("itm fc2", 16384, 768, 3072),
               ("fc1 K3072", 8192, 3072, 3072), ("vfc1 K3072", 12608, 3072, 3072), ("square 4096", 4096, 4096, 4096), ("square 8192", 8192, 8192, 8192)]
+    if os.environ.get("SHAPES"):
+        shapes = [s for s in shapes if s[0] in os.environ["SHAPES"].split(",")]
     cold = os.environ.get("COLD", "0") == "1"       # evict L2 / Infinity Cache before every timed launch (512 MiB streamed write)
     flush = torch.empty(128 * 1024 * 1024, device=dev) if cold else None
     print(f"epilogue={epi} rounds={rounds} cold={cold}")
@@ -39,7 +41,7 @@ def main():
         bias = torch.randn(N, device=dev)
         fns = []
         for _, tile in VARIANTS:
-            if tile in (13, 15) and N % 256:
+            if (tile in (13, 15, 19, 20) and N % 256) or (tile in (17, 18) and N % 192):
                 fns.append(None)
                 continue
             if epi == "gelu":
