@@ -75,6 +75,7 @@ struct mmhip_engine {
     bool vit_is_long = false;            // the image tower is the longer forward chain of this call (set by mmhip_forward)
     hipStream_t side_vit[2] = {nullptr, nullptr};     // image tower of the forward: [0] normal, [1] high priority
     hipEvent_t ev_fork = nullptr, ev_vit = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_tn[2] = {nullptr, nullptr};
+    hipEvent_t ev_layer[2] = {nullptr, nullptr}, ev_opt = nullptr;      // mmhip_train_step: per-layer AdamW on the side stream
     bool tn_pending[2] = {false, false};
     int cls_only = -1;         // -1 = read MMHIP_CLS_ONLY on first use; 1: the last text layer runs its post-attention part on CLS rows only
     bool cls_compact = false;  // state of the last forward
@@ -428,7 +429,7 @@ int side_init(mmhip_engine& e) {
         CHECK_HIP(hipStreamCreateWithFlags(&e.side_vit[0], hipStreamNonBlocking));
         CHECK_HIP(hipStreamCreateWithPriority(&e.side_vit[1], hipStreamNonBlocking, greatest));
     }
-    hipEvent_t* evs[6] = {&e.ev_fork, &e.ev_vit, &e.ev_ready[0], &e.ev_ready[1], &e.ev_tn[0], &e.ev_tn[1]};
+    hipEvent_t* evs[9] = {&e.ev_fork, &e.ev_vit, &e.ev_ready[0], &e.ev_ready[1], &e.ev_tn[0], &e.ev_tn[1], &e.ev_layer[0], &e.ev_layer[1], &e.ev_opt};
     for (auto ev : evs) CHECK_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     return 0;
 }
@@ -961,7 +962,7 @@ void mmhip_destroy(mmhip_handle h) {
     if (!h) return;
     if (h->side) {
         (void)hipStreamSynchronize(h->side);
-        for (hipEvent_t ev : {h->ev_fork, h->ev_vit, h->ev_ready[0], h->ev_ready[1], h->ev_tn[0], h->ev_tn[1]})
+        for (hipEvent_t ev : {h->ev_fork, h->ev_vit, h->ev_ready[0], h->ev_ready[1], h->ev_tn[0], h->ev_tn[1], h->ev_layer[0], h->ev_layer[1], h->ev_opt})
             if (ev) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(h->side);
         for (auto sv : h->side_vit) if (sv) (void)hipStreamDestroy(sv);
@@ -1246,8 +1247,34 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
     e.skip_itc = false;
     if (rf) return rf;
     if (int r = mmhip_loss(h, onehot, class_w, use_itm ? lbl_tim : nullptr, w_cls, use_itc ? w_itc : 0.f, use_itm ? w_itm : 0.f, loss, n_correct, stream)) return r;
-    if (int r = mmhip_backward(h, nullptr, nullptr, nullptr, nullptr, stream)) return r;
-    // merged [begin, end) ranges of the active gradient groups, in address order
+    // Backward.  With the side stream on, each text layer's AdamW and 16-bit weight refresh follow its weight-gradient GEMM on the
+    // SIDE stream, beside the activation-gradient chain of the layers below (an HBM-bound kernel next to MFMA-bound ones) instead
+    // of after the whole backward; the layer's fp32 LayerNorm weights and transposed 16-bit copies are read by its own backward
+    // kernels on the caller's stream, so the side stream first waits for the event recorded behind them.
+    hipStream_t s = (hipStream_t)stream;
+    static int early = -1;
+    if (early < 0) { const char* v = getenv("MMHIP_EARLY_ADAMW"); early = v ? atoi(v) : 1; }
+    if (int r = mmhip_backward_begin(h, nullptr, nullptr, nullptr, nullptr, stream)) return r;
+    const int L = e.cfg.layers_txt;
+    const bool layer_opt = early && use_side(e);
+    bool opt_pending = false;
+    for (int st = 0; st < L + 2; ++st) {
+        if (int r = mmhip_backward_stage(h, st, stream)) return r;
+        if (layer_opt && st >= 1 && st <= L) {
+            const int l = L - st, set = l & 1;
+            const LayerOff& o = e.txt[l];
+            CHECK_HIP(hipEventRecord(e.ev_layer[set], s));
+            CHECK_HIP(hipStreamWaitEvent(e.side, e.ev_layer[set], 0));
+            if (int r = mmhip_adamw(e.train + o.begin, e.grad + o.begin, adam_m + o.begin, adam_v + o.begin, o.end - o.begin, lr, beta1, beta2, eps,
+                                    weight_decay, step, grad_scale, 1, e.side)) return r;
+            if (int r = refresh_layer(e, e.train, o, e.txt_w16[l], true, e.side, e.cfg.hidden, e.cfg.inter)) return r;
+            CHECK_HIP(hipEventRecord(e.ev_opt, e.side));
+            opt_pending = true;
+        }
+    }
+    if (int r = mmhip_backward_finish(h, stream)) return r;
+    if (opt_pending) CHECK_HIP(hipStreamWaitEvent(s, e.ev_opt, 0));
+    // merged [begin, end) ranges of the active gradient groups, in address order (text layers already stepped: skipped)
     bool act[6] = {false, use_itc != 0, use_itm != 0, e.cfg.fusion == MMHIP_FUSION_ATTENTION, true, false};
     const uint64_t w0 = e.t_word, V = (uint64_t)e.cfg.vocab, H = (uint64_t)e.cfg.hidden;
     uint64_t rb = 0, re = 0;
@@ -1265,15 +1292,20 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
         }
         return 0;
     };
+    auto in_layer = [&](uint64_t off) {
+        if (!opt_pending) return false;
+        for (int l = 0; l < L; ++l) if (off >= e.txt[l].begin && off < e.txt[l].end) return true;
+        return false;
+    };
     for (const auto& p : e.params) {
-        if (p.buffer != 1 || !act[p.group]) continue;
+        if (p.buffer != 1 || !act[p.group] || in_layer(p.offset)) continue;
         const uint64_t b = p.offset, en = p.offset + ((p.numel + 3) & ~(uint64_t)3);
         if (open && b == re) { re = en; continue; }
         if (int r = flush()) return r;
         rb = b; re = en; open = true;
     }
     if (int r = flush()) return r;
-    return mmhip_refresh_weights(h, 2, stream);
+    return opt_pending ? 0 : mmhip_refresh_weights(h, 2, stream);
 }
 
 int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_t* launches, double* flops) {

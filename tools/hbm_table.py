@@ -17,9 +17,15 @@ alg = {   # kernel-name fragment -> (what, algorithmic bytes per launch)
 }
 rows = list(csv.DictReader(open(sys.argv[1])))
 print("| kernel | algorithmic bytes / launch | avg µs | GB/s | of 8 TB/s |\n|---|---|---|---|---|")
+steps = next((int(r["Calls"]) for r in rows if "adamw_rows_kernel" in r["Name"]), 1)
 for frag, (what, nbytes) in alg.items():
     for r in rows:
         if frag in r["Name"] and not (frag == "adamw_kernel" and "rows" in r["Name"]):
             us = float(r["AverageNs"]) / 1e3
+            if frag == "adamw_kernel":      # one launch per text layer + the rest: bytes of a whole step over the launches of a step
+                us = float(r["TotalDurationNs"]) / 1e3 / steps
+                what += f" ({int(r['Calls']) // steps} launches per step, summed)"
+            if frag == "cast_dual_kernel":
+                pass
             print(f"| `{frag}` — {what} | {nbytes / 1e6:.1f} MB | {us:.1f} | {nbytes / us / 1e3:.0f} | {nbytes / us / 1e3 / 8000:.0%} |")
             break
