@@ -7,7 +7,7 @@ Mt, Mv = B * T, B * P
 dense = 283856649 - V * H                                    # trainable parameters outside the word table
 alg = {   # kernel-name fragment -> (what, algorithmic bytes per launch)
     "adamw_kernel": ("dense AdamW: p,g,m,v read + p,m,v,g written, fp32", dense * 32),
-    "adamw_rows_kernel": ("word table, row-lazy AdamW: p read + written (untouched rows)", V * H * 8),
+    "adamw_rows_kernel": ("word table, row-lazy AdamW: only rows with a gradient or moments are touched (<= B*T rows of 32 B/param; rows that only decay by exactly 1.0f are skipped)", min(V, Mt) * H * 32),
     "ln_fwd_kernel": ("LayerNorm fwd: x read, y written (16-bit), text rows", Mt * H * 4),
     "ln_bwd_kernel": ("LayerNorm bwd: dy, x read; dx (+ dropout copy) written", Mt * H * 8),
     "cast_dual_kernel": ("weight refresh of a layer: fp32 read, 16-bit copy + transposed copy written", 7087872 * 8),

@@ -19,18 +19,16 @@ def main():
     name_k = "Kernel_Name" if "Kernel_Name" in keys else [k for k in keys if "ame" in k][0]
     q_k = "Queue_Id" if "Queue_Id" in keys else None
     ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[name_k], r[q_k] if q_k else "0") for r in rows))
-    # steps are delimited by the dense AdamW kernel (one per step)
-    marks = [i for i, e in enumerate(ev) if "adamw_kernel" in e[2]]
+    # steps are delimited by the word-table AdamW kernel (one per step, the last optimizer kernel on the main queue)
+    marks = [i for i, e in enumerate(ev) if "adamw_rows_kernel" in e[2]]
     which = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     a, b = marks[-which - 1], marks[-which]
-    # step = from the first kernel after the previous step's weight refresh to this step's last refresh kernel
     seg = ev[a + 1: b + 1]
-    # extend to the cast kernels that follow this AdamW
+    # weight-refresh kernels that follow this step's last AdamW belong to it; the previous step's do not
     j = b + 1
-    while j < len(ev) and ("cast" in ev[j][2] or "adamw_rows" in ev[j][2]):
+    while j < len(ev) and "cast" in ev[j][2]:
         seg.append(ev[j]); j += 1
-    # drop the previous step's trailing cast / rows kernels at the head
-    while seg and ("cast" in seg[0][2] or "adamw_rows" in seg[0][2]):
+    while seg and "cast" in seg[0][2]:
         seg.pop(0)
     t0, t1 = seg[0][0], max(e[1] for e in seg)
     print("step span %.3f ms, %d kernels" % ((t1 - t0) / 1e6, len(seg)))
@@ -64,7 +62,7 @@ def main():
     # phases on the main queue (the one with most kernels)
     mq = max(byq, key=lambda q: len(byq[q]))
     first_bwd = next((s for s, e, n in byq[mq] if "bwd" in n or "loss" in n), None)
-    first_opt = next((s for s, e, n in byq[mq] if "adamw" in n), None)
+    first_opt = next((s for s, e, n in byq[mq] if "adamw" in n), None)      # first optimizer kernel on the main queue (heads / embeddings)
     if first_bwd and first_opt:
         print("  forward %.3f ms | backward %.3f ms | optimizer + refresh %.3f ms" % ((first_bwd - t0) / 1e6, (first_opt - first_bwd) / 1e6, (t1 - first_opt) / 1e6))
     for q, v in byq.items():
