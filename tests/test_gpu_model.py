@@ -647,3 +647,36 @@ def test_lockstep_forward_of_both_towers_matches_reference_golden():
                         "(forward_matches_reference_golden or train_losses_and_grads or ragged_shapes) and not bf16x3 and not lockstep"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_gemm_timing_counts_the_steps_nt_launches():
+    """mmhip_gemm_timing / mmhip_gemm_timing_by_shape (bench.py's roofline source): events around every NT GEMM launch of a step,
+    both stream configurations; launches, FLOPs and the per-shape table must agree with the architecture"""
+    import ctypes as C
+    import types
+    from smtc_amd import _lib
+    cfgd = types.SimpleNamespace(batch_size=8, num_labels=3, use_clip_loss=False, beta_itc=0.1, use_tim_loss=False, beta_itm=0.1, max_length=64, dropout=0.05)
+    Lt, Lv, H, I = 2, 1, 768, 3072
+    tr = MMLate_Model(cfgd, "bernice", "vit", "attention", arch=dict(layers_txt=Lt, layers_img=Lv, vocab=500, max_pos=130), seed=3)
+    ocfg = O.OracleConfig(layers_txt=Lt, layers_img=Lv, vocab=500, max_pos=130, num_labels=3)
+    ids, mask, pixels, onehot = O.synthetic_batch(ocfg, 8, 64, 5, False)
+    lib, h = _lib.lib(), tr.model._handle
+    for mode in (1, 2):
+        _lib.check(lib.mmhip_gemm_timing(h, mode, 1, None, None, None))
+        tr.train_step(ids.cuda(), mask.cuda(), pixels, onehot, None, 1e-3, 0.00025, 1)
+        buf = C.create_string_buffer(1 << 14)
+        _lib.check(lib.mmhip_gemm_timing_by_shape(h, buf, len(buf)))
+        ms, n, fl = C.c_double(), C.c_uint64(), C.c_double()
+        _lib.check(lib.mmhip_gemm_timing(h, 0, 1, C.byref(ms), C.byref(n), C.byref(fl)))
+        # forward: patch embedding + 4 per image layer + 4 per text layer; backward: 4 activation-gradient GEMMs per text layer
+        assert n.value == 1 + 4 * Lv + 4 * Lt + 4 * Lt, n.value
+        Mt, Mv, P = 8 * 64, 8 * 197, 197
+        per_layer = lambda M: 2.0 * M * (3 * H * H + H * H + 2 * H * I)
+        # the last text layer runs QKV (forward) and d QKV (backward) on all rows, everything else on the 8 CLS rows
+        last = 2 * (2.0 * Mt * 3 * H * H) + 2 * (2.0 * 8 * (H * H + 2 * H * I))
+        want = 2.0 * 8 * (P - 1) * H * 768 + Lv * per_layer(Mv) + 2 * (Lt - 1) * per_layer(Mt) + last
+        assert abs(fl.value - want) < 1e-6 * want, (fl.value, want)
+        assert ms.value > 0
+        rows = [l.split() for l in buf.value.decode().strip().splitlines()[1:]]
+        assert sum(int(r[5]) for r in rows) == n.value and all(float(r[8]) > 0 for r in rows)
+        assert {(int(r[0]), int(r[1]), int(r[2])) for r in rows} >= {(Mv, 3 * H, H), (Mv, H, I), (Mt, 3 * H, H), (Mt, I, H)}
