@@ -137,9 +137,10 @@ __device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, 
 
 // epilogue of one 256 x (2 TN) tile from the accumulators: lane holds C[m][n .. n+7], m = m0 + wm*64 + 16 i + (lane&15),
 // n = n0 + wn*TN + 32 j' + 8 (lane>>4); values 0-3 from fragment 2j', 4-7 from fragment 2j'+1
-template <typename T, int FN, int TN, int EPI>
-__device__ __forceinline__ void tile_epilogue8(const GemmNTArgs& a, f32x4 (&acc)[4][FN], int m0, int n0, int wm, int wn, int l15, int kc) {
+template <typename T, int FN, int TN, int EPI, int NI = 4>
+__device__ __forceinline__ void tile_epilogue8(const GemmNTArgs& a, f32x4 (&acc)[NI][FN], int m0, int n0, int wm, int wn, int l15, int kc) {
     typedef typename Vec<T>::v8 v8;
+    constexpr int WROWS = 16 * NI;              // rows of the tile owned by one wave
         // every load of the epilogue first (bias; residual or mul_in of all the lane's fragments), then compute, then stores.
         // Rows past M: loads read (clamped) row M-1, stores are masked -- C may alias the residual (x += f(x) in the image tower),
         // so a duplicate of row M-1 must never be stored: another wave could read it back as residual.
@@ -158,16 +159,16 @@ __device__ __forceinline__ void tile_epilogue8(const GemmNTArgs& a, f32x4 (&acc)
         // (BN = 256: two chunks of two fragment-pair columns -- 64 more registers for all sixteen residual fragments would spill)
 #pragma unroll
         for (int jc = 0; jc < FN / 2; jc += 2) {
-            v8 pre[4][2];
+            v8 pre[NI][2];
             const T* pbase = (EPI == EP_MULG) ? (const T*)a.mul_in : (const T*)a.residual;
             const int pld = (EPI == EP_MULG) ? a.ldmul : a.ldres;
             const bool want = (EPI == EP_MULG) || ((EPI == EP_PLAIN || EPI == EP_ANY) && (a.flags & GEMM_RESIDUAL));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j2 = 0; j2 < 2; ++j2) {
                     if (EPI != EP_GELU && want && jc + j2 < FN / 2) {
-                        const int m = min(m0 + wm * 64 + i * 16 + l15, a.M - 1);
+                        const int m = min(m0 + wm * WROWS + i * 16 + l15, a.M - 1);
                         pre[i][j2] = *reinterpret_cast<const v8*>(pbase + (size_t)m * pld + nb + 32 * (jc + j2));
                     }
                 }
@@ -176,8 +177,8 @@ __device__ __forceinline__ void tile_epilogue8(const GemmNTArgs& a, f32x4 (&acc)
                 const int jp = jc + j2;
                 if (jp >= FN / 2) continue;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = m0 + wm * 64 + i * 16 + l15;
+                for (int i = 0; i < NI; ++i) {
+                    const int m = m0 + wm * WROWS + i * 16 + l15;
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e] + bias8[jp][e]; v[4 + e] = acc[i][2 * jp + 1][e] + bias8[jp][4 + e]; }
@@ -564,6 +565,159 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8k32_kernel(GemmNTPair g, int p
     if (grp == 0) raw_barrier();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile on FOUR waves (one per SIMD), each owning a 128 x 128 register tile (8 x 8 fragments of 16 x 16, 256 accumulator
+// registers): the shape the vendor library runs on these GEMMs (rocprofv3 of hipBLASLt: MT256x256x64, 256 threads, MIWT 8x8).
+// Against the eight-wave kernel above: every operand fragment read from LDS feeds 8 MFMAs instead of 4 (32 ds_read_b128 per
+// wave and K-tile for 128 MFMAs), ONE barrier per K-tile instead of eight, no partner wave -- the wave overlaps its own LDS reads
+// with its own MFMAs: the fragments of the second K-half are requested in front of the MFMAs of the first, those of the next
+// K-tile's first half in front of the MFMAs of the second.
+//   K-tile kt lives in buffer kt & 1 (2 x 64 KB, layout and swizzle of the eight-wave kernel).  In the middle of K-tile kt every
+//   wave has all its fragments of buffer kt & 1 in registers and its own DMA pieces of K-tile kt+1 have landed (vmcnt(0)); after
+//   the barrier the buffer is free and K-tile kt+1 is complete: issue the 16 LDS-DMA pieces of K-tile kt+2 into it, request the
+//   first-half fragments of K-tile kt+1, run the second half's MFMAs.
+template <int FN_>
+struct P4 {          // FN_ = 8: 256 x 256 tile (all 256 accumulator registers); 6: 256 x 192 (192, leaves the allocator room)
+    static constexpr int BM = 256, FN = FN_, TN = 16 * FN_, BN = 2 * TN, BK = 64, NI = 8, NPB = BN / 32;   // NPB: B pieces per wave
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, KT = A_BYTES + B_BYTES, LDS = 2 * KT;
+};
+
+template <typename T, int FN_, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt4_kernel(GemmNTPair g, int persistent) {
+    using C = P4<FN_>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Vec<T>::v8 v8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int tilesN = g.p[0].N / C::BN;
+    const int tilesM0 = (g.p[0].M + C::BM - 1) / C::BM, tiles0 = tilesN * tilesM0;
+    const int tilesM1 = g.count > 1 ? (g.p[1].M + C::BM - 1) / C::BM : 0, ntiles = tiles0 + tilesN * tilesM1;
+    const int nk = g.p[0].K / C::BK;
+    const int nwg = gridDim.x;
+    int first, stride, count;
+    if (persistent) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, wpx = (nwg + 7 - x) / 8;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, n_x = q + (x < r ? 1 : 0);
+        first = lo + j; stride = wpx; count = j < n_x ? (n_x - j + wpx - 1) / wpx : 0;
+    } else {
+        first = xcd_remap(blockIdx.x, nwg); stride = 0; count = 1;
+    }
+    if (count <= 0) return;
+    constexpr int GW = 8;
+    auto tile_origin = [&](int id, int& m0, int& n0) -> int {
+        const int which = id >= tiles0 ? 1 : 0;
+        if (which) id -= tiles0;
+        const int per_group = (which ? tilesM1 : tilesM0) * GW;
+        const int cg = id / per_group, rem = id - cg * per_group;
+        const int gw = min(GW, tilesN - cg * GW);
+        m0 = (rem / gw) * C::BM;
+        n0 = (cg * GW + rem % gw) * C::BN;
+        return which;
+    };
+
+    // ---- the DMA stream: 64 pieces of 1 KB (8 rows x 128 B) per K-tile, 16 per wave: A pieces 8w .. 8w+7, B pieces 8w .. 8w+7
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int total_kt = count * nk;
+    const char* srcA[8];
+    const char* srcB[C::NPB];
+    int d_rem = nk, d_tile = 0, d_done = 0;
+    auto rebase = [&](int id) {
+        int m0, n0;
+        const GemmNTArgs& a = g.p[tile_origin(id, m0, n0)];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int row = (w * 8 + jj) * 8 + lrow;
+            srcA[jj] = (const char*)a.A + ((size_t)min(m0 + row, a.M - 1) * a.lda + (size_t)((lslot ^ lrow) * 8)) * 2;
+        }
+#pragma unroll
+        for (int jj = 0; jj < C::NPB; ++jj) {
+            const int pc = w * C::NPB + jj, row = pc * 8 + lrow;
+            const int sw = (lrow & 3) | ((pc & 1) << 2);
+            srcB[jj] = (const char*)a.B + ((size_t)(n0 + row) * a.ldb + (size_t)((lslot ^ sw) * 8)) * 2;
+        }
+    };
+    auto stage = [&]() {                       // the next K-tile of the stream into buffer (d_done & 1)
+        if (d_done >= total_kt) return;
+        if (d_rem == 0) { d_tile += 1; d_rem = nk; rebase(first + d_tile * stride); }
+        char* base = smem + (d_done & 1) * C::KT;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            __builtin_amdgcn_global_load_lds(MM_GLB(srcA[jj]), MM_LDS(base + (w * 8 + jj) * 1024), 16, 0, 0);
+            srcA[jj] += 128;
+        }
+#pragma unroll
+        for (int jj = 0; jj < C::NPB; ++jj) {
+            __builtin_amdgcn_global_load_lds(MM_GLB(srcB[jj]), MM_LDS(base + C::A_BYTES + (w * C::NPB + jj) * 1024), 16, 0, 0);
+            srcB[jj] += 128;
+        }
+        d_rem -= 1;
+        d_done += 1;
+    };
+    rebase(first);
+
+    f32x4 acc[C::NI][C::FN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i)
+#pragma unroll
+            for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+
+    const int l15 = lane & 15, kc = lane >> 4, sw7 = lane & 7;
+    const int a_row_off = (wm * 128 + l15) * 128;
+    const int b_row_off = C::A_BYTES + (wn * C::TN + 8 * (l15 >> 2) + (lane & 3)) * 128;
+    const int ch[2] = {((0 * 4 + kc) ^ sw7) << 4, ((1 * 4 + kc) ^ sw7) << 4};
+    v8 af[2][8], bf[2][C::FN / 2][2];
+    auto read_half = [&](const char* Ks, int kk, int set) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[set][i] = lds_read8<T>(Ks, a_row_off + i * (16 * 128) + ch[kk]);
+#pragma unroll
+        for (int jp = 0; jp < C::FN / 2; ++jp)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) bf[set][jp][h] = lds_read8<T>(Ks, b_row_off + (32 * jp + 4 * h) * 128 + ch[kk]);
+    };
+    auto mma_half = [&](int set) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int jp = 0; jp < C::FN / 2; ++jp)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i][2 * jp + h] = mfma16(bf[set][jp][h], af[set][i], acc[i][2 * jp + h]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: K-tiles 0 and 1 on their way, K-tile 0 landed, its first-half fragments requested
+    stage();
+    stage();
+    if (total_kt > 1) wait_vm<8 + C::NPB>(); else wait_vm<0>();
+    raw_barrier();
+    read_half(smem, 0, 0);
+
+    int gkt = 0;
+    for (int t = 0; t < count; ++t) {
+#pragma unroll 1
+        for (int k = 0; k < nk; ++k, ++gkt) {
+            const char* Ks = smem + (gkt & 1) * C::KT;
+            read_half(Ks, 1, 1);                       // second-half fragments, in flight under the first half's MFMAs
+            mma_half(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave holds every fragment of the buffer
+            wait_vm<0>();                              // and its pieces of K-tile gkt + 1 have landed
+            raw_barrier();
+            stage();                                   // K-tile gkt + 2 -> the buffer just left
+            if (gkt + 1 < total_kt) read_half(smem + ((gkt + 1) & 1) * C::KT, 0, 0);
+            mma_half(1);
+        }
+        int m0, n0;
+        const GemmNTArgs& a = g.p[tile_origin(first + t * stride, m0, n0)];
+        tile_epilogue8<T, C::FN, C::TN, EPI, C::NI>(a, acc, m0, n0, wm, wn, l15, kc);
+        zero_acc();
+    }
+}
+
 static bool nt8_ok(const GemmNTArgs& a, int bn) {
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     return a.N % bn == 0 && a.K % 64 == 0 && a.K >= 64 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&
@@ -573,6 +727,18 @@ static bool nt8_ok(const GemmNTArgs& a, int bn) {
            (!(a.flags & GEMM_BIAS) || al(a.bias)) && a.M > 0;
 }
 
+// workgroups of a persistent launch: one per CU, or (MMHIP_NT8_BALANCE=1) as many as give every workgroup the same number
+// of tiles -- 450 tiles: 225 workgroups x 2 instead of 194 x 2 + 62 x 1 (same two tile times, fewer CUs on the memory path)
+static int nt8_grid(int ntiles) {
+    static int bal = -1;
+    if (bal < 0) { const char* e = getenv("MMHIP_NT8_BALANCE"); bal = e ? atoi(e) : 0; }
+    if (ntiles <= 256) return ntiles;
+    if (!bal) return 256;
+    const int rounds = (ntiles + 255) / 256;
+    int g = (ntiles + rounds - 1) / rounds;
+    g = (g + 7) & ~7;                      // whole XCDs
+    return g > 256 ? 256 : g;
+}
 template <typename T, int BN, int EPI>
 static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
     using C = P8<BN>;
@@ -580,7 +746,7 @@ static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
     if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<T, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
     int ntiles = 0;
     for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / BN);
-    const int grid = persistent ? (ntiles < 256 ? ntiles : 256) : ntiles;
+    const int grid = persistent ? nt8_grid(ntiles) : ntiles;
     hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI>), dim3(grid), dim3(512), C::LDS, s, g, persistent && ntiles > 256 ? 1 : 0);
 }
 template <typename T, int NBUF, int EPI>
@@ -592,6 +758,16 @@ static void launch_nt8k32_e(const GemmNTPair& g, int persistent, hipStream_t s) 
     for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / C::BN);
     const int grid = persistent ? (ntiles < 256 ? ntiles : 256) : ntiles;
     hipLaunchKernelGGL((gemm_nt8k32_kernel<T, NBUF, EPI>), dim3(grid), dim3(512), C::LDS, s, g, persistent && ntiles > 256 ? 1 : 0);
+}
+template <typename T, int FN, int EPI>
+static void launch_nt4_e(const GemmNTPair& g, int persistent, hipStream_t s) {
+    using C = P4<FN>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt4_kernel<T, FN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
+    int ntiles = 0;
+    for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / C::BN);
+    const int grid = persistent ? (ntiles < 256 ? ntiles : 256) : ntiles;
+    hipLaunchKernelGGL((gemm_nt4_kernel<T, FN, EPI>), dim3(grid), dim3(256), C::LDS, s, g, persistent && ntiles > 256 ? 1 : 0);
 }
 // epilogue class that covers a flag set (a pair uses the class that covers both)
 static int nt8_class(int f) {
@@ -631,7 +807,21 @@ static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
     else if (c == EP_PLAIN) launch_nt8_e<T, BN, EP_PLAIN>(g, persistent, s);
     else launch_nt8_e<T, BN, EP_ANY>(g, persistent, s);
 }
+template <typename T, int FN>
+static void launch_nt4_t(const GemmNTPair& g, int persistent, hipStream_t s) {
+    int c = nt8_class(g.p[0].flags);
+    if (g.count > 1 && nt8_class(g.p[1].flags) != c) c = EP_ANY;
+    if (c == EP_GELU) launch_nt4_e<T, FN, EP_GELU>(g, persistent, s);
+    else if (c == EP_MULG) launch_nt4_e<T, FN, EP_MULG>(g, persistent, s);
+    else if (c == EP_PLAIN) launch_nt4_e<T, FN, EP_PLAIN>(g, persistent, s);
+    else launch_nt4_e<T, FN, EP_ANY>(g, persistent, s);
+}
 static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent, hipStream_t s) {
+    if (bn == 258 || bn == 194) {             // four waves: 256 x 256 (128 x 128 register tile per wave) / 256 x 192 (128 x 96)
+        if (dtype == DT_BF16) { if (bn == 258) launch_nt4_t<bf16_t, 8>(g, persistent, s); else launch_nt4_t<bf16_t, 6>(g, persistent, s); }
+        else { if (bn == 258) launch_nt4_t<f16_t, 8>(g, persistent, s); else launch_nt4_t<f16_t, 6>(g, persistent, s); }
+        return;
+    }
     if (bn == 257) {             // 256 x 256, BK = 32, deep ring
         if (dtype == DT_BF16) launch_nt8k32_t<bf16_t>(g, persistent, s);
         else launch_nt8k32_t<f16_t>(g, persistent, s);
@@ -648,10 +838,10 @@ static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent,
     }
 }
 
-// bn: 256, 192 or 128; 257 = 256 x 256 with BK = 32 and the deep ring.  Returns false when the shape rules of the kernel do not
+// bn: 256, 192 or 128; 257 = 256 x 256 with BK = 32 and the deep ring; 258 = 256 x 256 on four waves.  Returns false when the shape rules of the kernel do not
 // hold (caller falls back).
 bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hipStream_t s) {
-    if ((bn != 257 && bn != 256 && bn != 192 && bn != 128) || !nt8_ok(a, bn == 257 ? 256 : bn)) return false;
+    if ((bn != 258 && bn != 257 && bn != 256 && bn != 194 && bn != 192 && bn != 128) || !nt8_ok(a, bn >= 257 ? 256 : (bn == 194 ? 192 : bn))) return false;
     GemmNTPair g;
     g.p[0] = a; g.p[1] = a; g.count = 1;
     launch_nt8_d(g, dtype, bn, persistent, s);
