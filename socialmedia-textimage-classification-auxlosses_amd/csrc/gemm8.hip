@@ -329,7 +329,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
     // tile, after the K loop and after the epilogue's last store was issued
     unsigned long long* ts = (g.p[0].flags & GEMM_DEBUG_TS) ? (unsigned long long*)g.p[0].aux + (size_t)blockIdx.x * 64 : nullptr;
     int nts = 0;
-    auto stamp = [&]() { if (ts && tid == 0 && nts < 64) ts[nts++] = wall_clock64(); };
+    auto stamp = [&]() { if (ts && tid == 0 && nts < 48) ts[nts++] = wall_clock64(); };
+    long long cyc[4] = {0, 0, 0, 0};
+    const bool cyc_on = ts && (g.p[0].flags & GEMM_DEBUG_CYC);      // second hook: where the cycles of a phase go (intrusive)
     if (ts && tid == 0) ts[nts++] = t_start;
     stamp();
     if (grp == 1) raw_barrier();          // waves 4-7 run one interval behind
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
                     }
                 }
                 stage(pc_);
+                const long long c0 = cyc_on ? clock64() : 0;
                 if (BN == 256) {
                     if (p == 1) { if (gkt + 1 < total_kt) wait_vm<8>(); else wait_vm<0>(); }
                     if (p == 3) { if (gkt + 2 < total_kt) wait_vm<6>(); else if (gkt + 1 < total_kt) wait_vm<2>(); }
@@ -367,7 +370,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
                 } else {
                     if (p == 1) { if (gkt + 2 < total_kt) wait_vm<6>(); else if (gkt + 1 < total_kt) wait_vm<0>(); }
                 }
+                const long long c1 = cyc_on ? clock64() : 0;
                 raw_barrier();
+                const long long c2 = cyc_on ? clock64() : 0;
                 // ---- C interval
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -377,7 +382,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
 #pragma unroll
                         for (int h = 0; h < 2; ++h) acc[i][2 * p + h] = mfma16(bf[h][kk], af[i][kk], acc[i][2 * p + h]);
                 __builtin_amdgcn_s_setprio(0);
+                const long long c3 = cyc_on ? clock64() : 0;
                 raw_barrier();
+                if (cyc_on) { const long long c4 = clock64(); cyc[0] += c1 - c0; cyc[1] += c2 - c1; cyc[2] += c3 - c2; cyc[3] += c4 - c3; }
             };
             phase(I0{});
             phase(I1{});
@@ -394,6 +401,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
         stamp();
     }
     if (ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); }
+    // shader-clock cycles of wave 0 and wave 4 spent in: counted DMA wait | barrier after the L interval | MFMAs (incl. waiting for
+    // the fragments) | barrier after the C interval; slots 48.. of the workgroup's stamp row.  Intrusive: every clock read waits
+    // for the wave's outstanding LDS reads (s_memtime returns through lgkmcnt) -- read the split, not the total
+    if (cyc_on && lane == 0 && (w == 0 || w == 4)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ts[48 + (w >> 2) * 4 + i] = (unsigned long long)cyc[i];
+        if (w == 0) ts[56] = (unsigned long long)total_kt * C::NPH;
+    }
     if (grp == 0) raw_barrier();          // matches the extra interval of waves 4-7
 }
 
@@ -771,7 +786,7 @@ static void launch_nt4_e(const GemmNTPair& g, int persistent, hipStream_t s) {
 }
 // epilogue class that covers a flag set (a pair uses the class that covers both)
 static int nt8_class(int f) {
-    f &= ~GEMM_DEBUG_TS;
+    f &= ~(GEMM_DEBUG_TS | GEMM_DEBUG_CYC);
     if (f == (GEMM_BIAS | GEMM_GELU) || f == (GEMM_BIAS | GEMM_GELU | GEMM_AUX_PRE)) return EP_GELU;
     if (f == GEMM_MUL_GELU_GRAD || f == (GEMM_MUL_GELU_GRAD | GEMM_RESIDUAL)) return EP_MULG;
     if (!(f & ~(GEMM_BIAS | GEMM_DROPOUT | GEMM_RESIDUAL))) return EP_PLAIN;
