@@ -31,7 +31,7 @@ python3 $R/tools/pmc_mfma.py /tmp/pmc_m > $O/mfma_busy.txt
 step diagnostics
 cd $R
 python3 tools/vendor_gemm_bench.py > $O/vendor_gemm.txt 2>/dev/null
-{ python3 tools/gemm8_ts.py 12608 2304 768 15; python3 tools/gemm8_ts.py 12608 768 3072 17 resid; python3 tools/gemm8_ts.py 8192 8192 8192 15; } > $O/gemm8_stamps.txt 2>/dev/null
+{ python3 tools/gemm8_ts.py 12608 2304 768 15; python3 tools/gemm8_ts.py 12608 768 3072 17 resid; python3 tools/gemm8_ts.py 8192 8192 8192 15; python3 tools/gemm8_ts.py 12608 2304 768 15 cycles; python3 tools/gemm8_ts.py 8192 8192 8192 15 cycles; } > $O/gemm8_stamps.txt 2>/dev/null
 { tools/pmc_l2.sh 12608 2304 768 15 5 cold; tools/pmc_l2.sh 12608 2304 768 1 5 cold; tools/pmc_l2.sh 12608 2304 768 20 5 cold; tools/pmc_l2.sh 8192 8192 8192 15 3; } > $O/l2_hit.txt 2>/dev/null
 { tools/ab_env.sh "MMHIP_LOCKSTEP=0" "MMHIP_LOCKSTEP=1" "MMHIP_EARLY_ADAMW=0" "MMHIP_NT8_192=0" "MMHIP_VIT_PRIO=0" "MMHIP_OVERLAP=0"; BENCH_ARGS="--config 3" tools/ab_env.sh "MMHIP_EARLY_ADAMW=1" "MMHIP_EARLY_ADAMW=0"; } > $O/step_ab2.txt 2>/dev/null
 python3 -m pytest tests/test_gpu_model.py -q -s -k "train_losses_and_grads or dropout_train_step or forward_matches or config4 or eval_loop" 2>&1 | grep -v "^$" > $O/parity.txt
