@@ -40,10 +40,19 @@ struct NTCfg {
     static constexpr int LPS = AI + BI;                             // LDS-DMA instructions per wave per stage
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, int NL = 0>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int NL = 0, bool SK = false>
 __global__ __launch_bounds__((WM * WN + NL) * 64, (NTCfg<BM, BN, WM, WN, NS, NL>::BLOCKS_PER_CU * (WM * WN + NL)) / 4)
 void gemm_nt_kernel(GemmNTArgs a) {
     using C = NTCfg<BM, BN, WM, WN, NS, NL>;
+    if constexpr (SK) {      // split-K: slice blockIdx.y of K, plain fp32 partial products [slice][M][N] (launch_nt_splitk)
+        const int z = blockIdx.y, Ks = a.K / (int)gridDim.y;
+        a.A = (const T*)a.A + (size_t)z * Ks;
+        a.B = (const T*)a.B + (size_t)z * Ks;
+        a.K = Ks;
+        a.C = a.splitk_ws + (size_t)z * a.M * a.N;
+        a.ldc = a.N;
+        a.flags = GEMM_OUT_F32;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -588,6 +597,23 @@ static void launch_nt_t(const GemmNTArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN, NS, NL>), dim3(grid), dim3(C::NTHR), C::LDS, s, a);
 }
 
+// few rows, long K: K / 384 slices side by side, then the epilogue over their sum (two launches instead of one 128-row block per
+// 128 columns walking all of K: 64 x 768 x 3072 took 54 us)
+static int splitk_slices(const GemmNTArgs& a) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MMHIP_SPLITK"); on = e ? atoi(e) : 1; }
+    if (!on || !a.splitk_ws || a.tile || a.M > 128 || a.K < 1536 || a.K % 384 || a.N % 128 || (a.flags & (GEMM_TANH | GEMM_QGELU))) return 0;
+    return a.K / 384;
+}
+template <typename T>
+static void launch_nt_splitk(const GemmNTArgs& a, int slices, hipStream_t s) {
+    using C = NTCfg<128, 128, 2, 2, 2, 0>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, 128, 128, 2, 2, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
+    const int grid = ((a.M + 127) / 128) * (a.N / 128);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 128, 2, 2, 2, 0, true>), dim3(grid, slices), dim3(C::NTHR), C::LDS, s, a);
+}
+
 // tile choice: explicit (a.tile: 1 = 128x128 2-stage, 2 = 256x128 2-stage, 3 = 256x256 2-stage, 4 = 128x128 4-stage ring,
 // 5 = 256x128 3-stage ring, 6 = 128x192 2-stage, 7 = 256x192 2-stage, 8 = 128x128 role-specialised (4 MFMA + 4 loader
 // waves, 4-stage ring), 9 = 256x128 role-specialised (8 + 4 waves, 3-stage ring)) or measured rules
@@ -713,6 +739,11 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if (dtype == DT_F32) return launch_gemm_nt_x3(a, s);
     if (nt_fast_ok(a) && !a.force_slow && !debug_force_slow()) {
+        if (const int slices = splitk_slices(a)) {
+            if (dtype == DT_BF16) launch_nt_splitk<bf16_t>(a, slices, s);
+            else launch_nt_splitk<f16_t>(a, slices, s);
+            return launch_splitk_finish(a, dtype, slices, s);
+        }
         if (dtype == DT_BF16) launch_nt_d<bf16_t>(a, s);
         else launch_nt_d<f16_t>(a, s);
     } else {

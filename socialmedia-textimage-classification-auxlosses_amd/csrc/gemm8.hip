@@ -733,6 +733,42 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(GemmNTPair g, int persist
     }
 }
 
+// split-K finish (launch_nt_splitk in gemm.hip): thread = 8 consecutive columns of one row; sums the slices' fp32 partial products,
+// adds the bias and runs the run-time epilogue of the fused kernels (aux, GELU, gelu', dropout, residual, output type)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(GemmNTArgs a, int slices) {
+    typedef typename Vec<T>::v8 v8;
+    const int per_row = a.N >> 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.M * per_row) return;
+    const int m = idx / per_row, n = (idx - m * per_row) << 3;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int z = 0; z < slices; ++z) {
+        const float* p = a.splitk_ws + ((size_t)z * a.M + m) * a.N + n;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(p), x1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += x0[e]; v[4 + e] += x1[e]; }
+    }
+    if (a.flags & GEMM_BIAS) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + n), b1 = *reinterpret_cast<const f32x4*>(a.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+    }
+    v8 pre;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pre[e] = from_f<T>(0.f);
+    if (a.flags & GEMM_RESIDUAL) pre = *reinterpret_cast<const v8*>((const T*)a.residual + (size_t)m * a.ldres + n);
+    epilogue8<T, EP_ANY>(a, v, m, n, pre);
+}
+hipError_t launch_splitk_finish(const GemmNTArgs& a, int dtype, int slices, hipStream_t s) {
+    const int threads = a.M * (a.N >> 3);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, dim3((threads + 255) / 256), dim3(256), 0, s, a, slices);
+    else hipLaunchKernelGGL(splitk_finish_kernel<f16_t>, dim3((threads + 255) / 256), dim3(256), 0, s, a, slices);
+    return hipGetLastError();
+}
+
 static bool nt8_ok(const GemmNTArgs& a, int bn) {
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     return a.N % bn == 0 && a.K % 64 == 0 && a.K >= 64 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&

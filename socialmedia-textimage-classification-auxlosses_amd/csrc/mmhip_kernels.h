@@ -32,6 +32,8 @@ struct GemmNTArgs {
     int drop_row_mul;         // dropout element index uses row m * drop_row_mul (0 = 1): compact CLS-row GEMMs keep the
                               // masks of the full [posts*T, N] tensor
     DropCfg drop;
+    float* splitk_ws;         // optional fp32 scratch [K/384][M][N]: a GEMM of <= 128 rows with K >= 1536 (the CLS-row GEMMs of the last
+                              // text layer) is cut along K into slices that run side by side; a second kernel sums them and applies the epilogue
 };
 struct GemmNTPair { GemmNTArgs p[2]; int count; };      // gemm8.hip: one or two problems of equal N and K per launch
 static constexpr int GEMM_TN_MAX_GROUP = 8;
@@ -55,6 +57,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s);
 // deep-pipelined 256 x bn tiles (gemm8.hip); false = shape rules not met, nothing launched
 bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hipStream_t s);
 // two problems of equal N and K in one persistent launch (the two towers' GEMMs of one layer); bn = 0: best-filling tile
+// split-K finish: C = epilogue(sum over `slices` partial products in a.splitk_ws), same flags as the fused epilogue
+hipError_t launch_splitk_finish(const GemmNTArgs& a, int dtype, int slices, hipStream_t s);
 bool launch_gemm_nt8_pair(const GemmNTArgs& a0, const GemmNTArgs& a1, int dtype, int bn, hipStream_t s);
 hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha = 1.0f);
 // parity mode (fp32 activations, three bf16 MFMA products of split operands / fp32 attention): csrc/x3.hip
