@@ -165,3 +165,39 @@ def test_eval_loop_matches_reference(golden_dir, tag, itc, itm):
     assert torch.equal(torch.cat(preds), t(z, tag + ".predictions")) and torch.equal(torch.cat(labels), t(z, tag + ".labels"))
     assert torch.equal(torch.cat(ids_all), t(z, tag + ".data_id"))
     assert (torch.cat(logits) - t(z, "out_cls")).abs().max() < 2e-5 * t(z, "out_cls").abs().max()
+
+
+def test_lxmert_oracle_matches_reference(golden_dir):
+    """groundwork for BASELINE config 5 (early-fusion LXMERT; the HIP path for it does not exist yet): oracle/lxmert_oracle.py
+    against the reference's own mm_early.Lxmert module (tests/golden/make_lxmert_golden.py) -- four outputs, ITC logits, three loss
+    mixes, gradients of the ITC + ITM mix (one cross-attention module used in both directions, detached text embedding)"""
+    import ast as _ast
+    from oracle import lxmert_oracle as L
+    z = np.load(os.path.join(golden_dir, "lxmert_small.npz"), allow_pickle=False)
+    c = L.LxmertConfig(**_ast.literal_eval(str(z["cfg"])))
+    P = L.make_params(c, int(z["seed_w"]))
+    ids, mask, tt, feats, boxes, onehot = L.synthetic_batch(c, int(z["B"]), int(z["T"]), int(z["seed_x"]))
+    assert torch.equal(ids, t(z, "ids")) and torch.equal(mask, t(z, "mask")) and abs(feats.double().sum().item() - float(z["feats_sum"])) < 1e-6
+    tim = (t(z, "tim_ids"), t(z, "tim_mask"), torch.zeros_like(ids))
+    rel = lambda a, b: (a - b).abs().max().item() / b.abs().max().item()
+    with torch.no_grad():
+        out, et, ev, otim = L.early_forward(P, ids, mask, tt, feats, boxes, c, tim)
+        for got, key in ((out, "out_cls"), (et, "emb_t"), (ev, "emb_v"), (otim, "out_tim"), (L.logits_per_text(P, et, ev), "logits_per_text")):
+            assert rel(got, t(z, key)) < 2e-5, (key, rel(got, t(z, key)))
+    w, lbl = t(z, "class_w"), t(z, "lbl_tim")
+    for tag, itc, itm in (("cls", False, False), ("itc", True, False), ("itcitm", True, True)):
+        Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        out, et, ev, otim = L.early_forward(Pg, ids, mask, tt, feats, boxes, c, tim if itm else None)
+        loss = L.mix_loss(Pg, out, onehot, w, et, ev, otim, lbl, itc, itm)
+        assert abs(loss.item() - float(z["loss." + tag])) < 2e-5 * abs(float(z["loss." + tag])), tag
+        if tag == "itcitm":
+            loss.backward()
+            for k in [f[5:] for f in z.files if f.startswith("grad.")]:
+                g, ref = Pg[k].grad, t(z, "grad." + k)
+                got = g[:4] if g.dim() == 2 else g
+                assert rel(got, ref) < 2e-4, (k, rel(got, ref))
+                assert abs(g.double().norm().item() - float(z["gradnorm." + k])) < 2e-4 * float(z["gradnorm." + k]), k
+            # the pooler is not on the path (mm_early.py:132 takes the CLS row itself): no gradient, in the reference either
+            assert sorted(str(k) for k in z["no_grad"]) == sorted(k for k, v in Pg.items() if v.grad is None) == ["model.pooler.dense.bias", "model.pooler.dense.weight"]
+            # padding_idx=0 on all three embedding tables: position 0 and token type 0 receive no gradient
+            assert not Pg["model.embeddings.position_embeddings.weight"].grad[0].any() and not Pg["model.embeddings.token_type_embeddings.weight"].grad[0].any()
