@@ -63,13 +63,65 @@ def cpu_baseline(seconds_budget=25.0):
             "sample": f"{n} fwd+bwd steps of B={B} posts (T=128, 224x224), fp32 torch CPU oracle, optimizer excluded"}
 
 
+def bench_early(args):
+    """BASELINE config 5 (LXMERT early fusion, mm_early.py): first version -- the HIP operators chained by torch autograd, one GPU.
+    Step = forward (+ the second full encoder pass of ITM with --aux) + loss + backward + AdamW.  FLOPs per post: every Linear of the
+    9 language / 5 relational / 5 cross-modality layers on T = 128 tokens and 36 boxes, x3 for forward + backward."""
+    import types
+    import numpy as np
+    import torch
+    import smtc_amd  # noqa: F401
+    from smtc_amd.mm_early import MMEarly_Model
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("config 5 is single-GPU in this round (the early-fusion path has no gradient exchange yet)")
+    B, T, NB, H, I, C = args.batch, 128, 36, 768, 3072, 3
+    cfg = types.SimpleNamespace(batch_size=B, num_labels=C, use_clip_loss=args.aux, beta_itc=0.1, use_tim_loss=args.aux, beta_itm=0.1, max_length=T, dropout=0.05)
+    tr = MMEarly_Model(cfg, "lxmert", dtype=args.dtype, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    ids = torch.randint(1, 30522, (B, T), generator=g).cuda()
+    mask = torch.ones(B, T, dtype=torch.int64).cuda()
+    tt = torch.zeros_like(ids)
+    feats = (torch.rand(B, NB, 2048, generator=g) * 2).cuda()
+    boxes = torch.rand(B, NB, 4, generator=g).cuda()
+    onehot = torch.nn.functional.one_hot(torch.randint(0, C, (B,), generator=g), C).cuda()
+    np.random.seed(30)
+    step = 0
+    for _ in range(args.warmup):
+        step += 1
+        tr.train_step(ids, mask, tt, feats, boxes, onehot, None, 1e-5, 0.00025, step)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step += 1
+        loss = tr.train_step(ids, mask, tt, feats, boxes, onehot, None, 1e-5, 0.00025, step)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    layer = 2.0 * (4 * H * H + 2 * H * I)                       # Linear FLOPs per token of a BERT-shaped layer
+    xlayer = 2.0 * (8 * H * H + 2 * H * I)                      # cross-modality layer: cross + self attention blocks, feed-forward
+    fwd = (9 * layer + 5 * xlayer) * T + (5 * layer + 5 * xlayer) * NB + 2.0 * NB * (2048 + 4) * H
+    gf_post = 3 * fwd * (2 if args.aux else 1) / 1e9
+    tf = B * args.steps / el * gf_post / 1e3
+    out = {"metric": "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion, bs=64", "value": round(B * args.steps / el, 1), "unit": "posts/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "BASELINE config 5: LXMERT early fusion (mm_early.py), 36 x 2048 ROI features, bs=32/GPU" + (", ITC + ITM" if args.aux else ""),
+                      "implementation": "first version: HIP operators (GEMM / LayerNorm / attention / AdamW) chained by torch autograd; launch-bound",
+                      "gf_per_post": round(gf_post, 1), "posts_per_gpu": B, "text_tokens": T, "boxes": NB, "parallelism": "dp1", "weights": "random-init at true shapes"},
+           "final_loss": round(float(loss), 5),
+           "roofline": {"bound": "mfma", "kernel": "whole step (no per-kernel timing on this path)", "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / PEAK_TFLOPS, 4), "traffic": None},
+           "cpu_baseline": None}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--aux", action="store_true", help="BASELINE config 3: ITC + ITM auxiliary losses")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4], help="BASELINE.json config index (3 = --aux; 4 = CLIP-ViT-L/14 + concat, bs=32)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json config index (3 = --aux; 4 = CLIP-ViT-L/14 + concat, bs=32; 5 = LXMERT early fusion, bs=32, single GPU, first version)")
     ap.add_argument("--image", type=int, default=224, choices=[224, 336], help="config 4: image size (257 / 577 image tokens)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "bf16x3"])
     ap.add_argument("--batch", type=int, default=0, help="posts per GPU (default: 64; 32 for config 4)")
@@ -80,7 +132,9 @@ def main():
     if args.config == 3:
         args.aux = True
     if not args.batch:
-        args.batch = 32 if args.config == 4 else 64
+        args.batch = 32 if args.config in (4, 5) else 64
+    if args.config == 5:
+        return bench_early(args)
     img_name = "vit" if args.config != 4 else ("clip" if args.image == 224 else "clip336")
     fusion = "concat" if args.config == 4 else "attention"
 

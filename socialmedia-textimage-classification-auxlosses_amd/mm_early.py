@@ -1,0 +1,447 @@
+"""Early-fusion LXMERT (BASELINE config 5) -- reference models/mm_early.py:105-172 (class Lxmert) and :175-520 (MMEarly_Model).
+
+FIRST VERSION (round 2): every matrix product, LayerNorm and attention of the model runs on the library's HIP kernels through
+its operator-level C ABI (`mmhip_op_gemm_nt / _gemm_tn / _layernorm_* / _attn_*`, `mmhip_adamw`), chained by torch autograd
+(one `autograd.Function` per operator; residual adds, GELU, dropout, embedding gathers, max-pooling and the small losses are torch
+tensor ops on the GPU).  It is not a fused engine like mm_late.py: the step is launch-bound and there is no weight-gradient /
+optimizer overlap.  There is no CPU path: the operators raise when the HIP library is missing.
+
+Cross attention (queries and keys of different lengths: T tokens x 36 boxes) runs on the self-attention kernels: Q, K and V are
+separate column blocks of one packed [rows, 3H] tensor, so row i carries query i and row j carries key / value j of the OTHER
+stream; S = max(T, 36) rows per post, keys past the context length masked, query rows past the query length discarded (their
+upstream gradient is zero).  S <= 128 (the attention backward's limit) covers the reference's max_length = 128.
+
+State-dict keys are the reference module's (`model.*` = HF LxmertModel 4.25.1 naming, `linear_fusion`, `linear`, `linear_tim`,
+`logit_scale`).  Parity: tests/test_gpu_early.py against tests/golden/lxmert_small.npz (the reference's own module) and the oracle.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .utils import clip_loss
+
+_DT = {"bf16": (_lib.BF16, torch.bfloat16), "f16": (_lib.F16, torch.float16), "bf16x3": (_lib.F32, torch.float32)}
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return _lib.stream_ptr()
+
+
+class _Ctx:
+    """per-model operator context: activation dtype, 16-bit (or fp32) copies of the weights keyed by parameter version, dropout seeds"""
+
+    def __init__(self, dtype):
+        self.code, self.tdt = _DT[dtype]
+        self.cache = {}
+        self.calls = 0
+        self.seed = 0x5DEECE66D
+
+    def weight(self, w, transpose=False):
+        """activation-typed copy of an fp32 [N,K] weight ([K,N] when transpose), refreshed when the parameter changed"""
+        key = (id(w), transpose)
+        hit = self.cache.get(key)
+        if hit is not None and hit[0] == w._version:
+            return hit[1]
+        N, K = w.shape
+        if self.tdt == torch.float32:
+            out = w.detach().t().contiguous() if transpose else w.detach()
+        else:
+            out = torch.empty((K, N) if transpose else (N, K), dtype=self.tdt, device=w.device)
+            _lib.check(_lib.lib().mmhip_op_cast(self.code, _p(w.detach()), _p(out), N * K, N if transpose else 0, K if transpose else 0, _s()), "cast")
+        self.cache[key] = (w._version, out)
+        return out
+
+    def next_seed(self):
+        self.calls += 1
+        return (self.seed * 0x9E3779B97F4A7C15 + self.calls) & 0xFFFFFFFFFFFFFFFF
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b on gemm_nt; dx = dy W (gemm_nt on the transposed copy), dW = dy^T x and db = column sums of dy (one gemm_tn)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, oc):
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, dtype=oc.tdt, device=x.device)
+        _lib.check(_lib.lib().mmhip_op_gemm_nt(oc.code, _p(x), K, _p(oc.weight(w)), K, _p(y), N, M, N, K, _p(b), 0, None, 0, None, 0, 0.0, 0, 0,
+                                               None, 0, 0, 0, _s()), "gemm_nt")
+        ctx.save_for_backward(x, w)
+        ctx.oc, ctx.has_b = oc, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        oc, lib = ctx.oc, _lib.lib()
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=oc.tdt, device=x.device)
+            _lib.check(lib.mmhip_op_gemm_nt(oc.code, _p(dy), N, _p(oc.weight(w, True)), N, _p(dx), K, M, K, N, None, 0, None, 0, None, 0, 0.0, 0, 0,
+                                            None, 0, 0, 0, _s()), "gemm_nt dx")
+        dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
+        fused_db = ctx.has_b and N % 4 == 0                  # the column-sum leg of gemm_tn wants 4-element columns; the 3- / 2-wide heads sum in torch
+        db = torch.zeros(N, dtype=torch.float32, device=x.device) if fused_db else None
+        _lib.check(lib.mmhip_op_gemm_tn(oc.code, _p(dy), N, _p(x), K, _p(dw), K, M, N, K, 0, 0, _p(db), _s()), "gemm_tn")
+        if ctx.has_b and not fused_db:
+            db = dy.float().sum(0)
+        return dx, dw, db, None
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps, oc):
+        rows, width = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mmhip_op_layernorm_fwd(oc.code, _p(x), _p(y), _p(g), _p(b), _p(mean), _p(rstd), rows, width, eps, _s()), "ln_fwd")
+        ctx.save_for_backward(x, g, mean, rstd)
+        ctx.oc = oc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, rstd = ctx.saved_tensors
+        oc = ctx.oc
+        rows, width = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.zeros(width, dtype=torch.float32, device=x.device)
+        db = torch.zeros(width, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mmhip_op_layernorm_bwd(oc.code, _p(dy), _p(x), _p(g), _p(mean), _p(rstd), _p(dx), None, _p(dg), _p(db), rows, width, _s()), "ln_bwd")
+        return dx, dg, db, None, None
+
+
+class _Attention(torch.autograd.Function):
+    """softmax(Q K^T / 8 + maskbias) V per (post, head) on packed [posts*S, 3H] rows; hash dropout on the probabilities"""
+
+    @staticmethod
+    def forward(ctx, qkv, maskbias, posts, S, heads, p_drop, seed, oc):
+        H = heads * 64
+        out = torch.empty(posts * S, H, dtype=oc.tdt, device=qkv.device)
+        lse = torch.empty(posts * heads * S, dtype=torch.float32, device=qkv.device)
+        _lib.check(_lib.lib().mmhip_op_attn_fwd(oc.code, _p(qkv), _p(maskbias), _p(out), _p(lse), posts, S, heads, p_drop, seed, 7, _s()), "attn_fwd")
+        ctx.save_for_backward(qkv, maskbias, out, lse)
+        ctx.cfg = (posts, S, heads, p_drop, seed, oc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        qkv, maskbias, out, lse = ctx.saved_tensors
+        posts, S, heads, p_drop, seed, oc = ctx.cfg
+        dqkv = torch.empty_like(qkv)
+        _lib.check(_lib.lib().mmhip_op_attn_bwd(oc.code, _p(qkv), _p(maskbias), _p(out), _p(dctx.contiguous()), _p(lse), _p(dqkv), posts, S, heads,
+                                                p_drop, seed, 7, _s()), "attn_bwd")
+        return dqkv, None, None, None, None, None, None, None
+
+
+class _Node(nn.Module):
+    pass
+
+
+class Lxmert(nn.Module):
+    """reference models/mm_early.py:105-172.  `arch`: l_layers / r_layers / x_layers / vocab / max_pos / type_vocab (defaults: HF
+    lxmert-base-uncased: 9 / 5 / 5 / 30522 / 512 / 2); weights are random-init unless `model_dir` holds a saved LxmertModel."""
+
+    def __init__(self, model_dir, num_labels, max_length=None, dropout=0.1, logit_scale_init_value=2.6592, arch=None, dtype="bf16", seed=0):
+        super().__init__()
+        a = dict(hidden=768, heads=12, inter=3072, l_layers=9, r_layers=5, x_layers=5, vocab=30522, max_pos=512, type_vocab=2, feat_dim=2048,
+                 pos_dim=4, p_hidden=0.1, p_attn=0.1, ln_eps=1e-12)
+        a.update(arch or {})
+        if a["hidden"] != a["heads"] * 64:
+            raise ValueError("the attention kernels serve 64-wide heads")
+        if not torch.cuda.is_available():
+            raise RuntimeError("mm_early.Lxmert runs on the HIP kernels only (no CPU path)")
+        self.arch, self.num_labels, self.p_head, self.dtype_name = a, num_labels, dropout, dtype
+        self.oc = _Ctx(dtype)
+        self.device_ = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for name, shape in self.param_shapes(a, num_labels).items():
+            if name == "logit_scale":
+                val = torch.ones([]) * logit_scale_init_value
+            elif name.endswith("LayerNorm.weight") or name.endswith("layer_norm.weight"):
+                val = torch.ones(shape)
+            elif name.endswith(".bias"):
+                val = torch.zeros(shape)
+            else:
+                val = torch.randn(shape, generator=g) * 0.02
+            node, parts = self, name.split(".")
+            for part in parts[:-1]:
+                if part not in node._modules:
+                    node.add_module(part, _Node())
+                node = node._modules[part]
+            node.register_parameter(parts[-1], nn.Parameter(val.to(self.device_)))
+        if model_dir and os.path.isdir(model_dir):
+            self._load_hf(model_dir)
+
+    @staticmethod
+    def param_shapes(a, num_labels):
+        H, I = a["hidden"], a["inter"]
+        s = {}
+
+        def lin(n, o, i):
+            s[n + ".weight"], s[n + ".bias"] = (o, i), (o,)
+
+        def ln(n):
+            s[n + ".weight"], s[n + ".bias"] = (H,), (H,)
+
+        def att_block(n, inner):
+            for p in ("query", "key", "value"):
+                lin(f"{n}.{inner}.{p}", H, H)
+            lin(f"{n}.output.dense", H, H)
+            ln(f"{n}.output.LayerNorm")
+
+        def ffn(i_, o_):
+            lin(i_ + ".dense", I, H)
+            lin(o_ + ".dense", H, I)
+            ln(o_ + ".LayerNorm")
+
+        e = "model.embeddings."
+        s[e + "word_embeddings.weight"] = (a["vocab"], H)
+        s[e + "position_embeddings.weight"] = (a["max_pos"], H)
+        s[e + "token_type_embeddings.weight"] = (a["type_vocab"], H)
+        ln(e + "LayerNorm")
+        v = "model.encoder.visn_fc."
+        lin(v + "visn_fc", H, a["feat_dim"]); ln(v + "visn_layer_norm")
+        lin(v + "box_fc", H, a["pos_dim"]); ln(v + "box_layer_norm")
+        for kind, n in (("layer", a["l_layers"]), ("r_layers", a["r_layers"])):
+            for i in range(n):
+                b = f"model.encoder.{kind}.{i}."
+                att_block(b + "attention", "self")
+                ffn(b + "intermediate", b + "output")
+        for i in range(a["x_layers"]):
+            b = f"model.encoder.x_layers.{i}."
+            att_block(b + "visual_attention", "att")
+            att_block(b + "lang_self_att", "self")
+            att_block(b + "visn_self_att", "self")
+            ffn(b + "lang_inter", b + "lang_output")
+            ffn(b + "visn_inter", b + "visn_output")
+        lin("model.pooler.dense", H, H)
+        lin("linear_fusion", H, H)
+        lin("linear", num_labels, H)
+        lin("linear_tim", 2, H)
+        s["logit_scale"] = ()
+        return s
+
+    def _load_hf(self, model_dir):
+        """a saved LxmertModel directory (LxmertModel.from_pretrained layout): safetensors or pytorch_model.bin"""
+        sd = None
+        st = os.path.join(model_dir, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        elif os.path.exists(os.path.join(model_dir, "pytorch_model.bin")):
+            sd = torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu")
+        if sd is None:
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin in {model_dir!r}")
+        sd = {("model." + k[len("lxmert."):] if k.startswith("lxmert.") else ("model." + k)): v for k, v in sd.items()}
+        own = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k in own and tuple(own[k].shape) == tuple(v.shape):
+                    own[k].copy_(v.to(own[k].device, torch.float32))
+
+    # ---- operators
+    def _P(self, name):
+        node = self
+        for part in name.split("."):
+            node = node._parameters[part] if part in node._parameters else node._modules[part]
+        return node
+
+    def _lin(self, x, n):
+        """Linear on [rows, K]; the fast GEMM wants N, K multiples of 8 (the 3- / 2-wide heads and the 4-wide box input take the generic kernel)"""
+        return _Linear.apply(x.contiguous(), self._P(n + ".weight"), self._P(n + ".bias"), self.oc)
+
+    def _ln(self, x, n):
+        return _LayerNorm.apply(x.contiguous(), self._P(n + ".weight"), self._P(n + ".bias"), self.arch["ln_eps"], self.oc)
+
+    def _drop(self, x, p):
+        return F.dropout(x, p, self.training) if p > 0 else x
+
+    def _attend(self, q_in, ctx_in, ctx_bias, n, B, Sq, Sk):
+        """LxmertAttention(q_in, ctx_in): q_in [B*Sq, H], ctx_in [B*Sk, H], ctx_bias [B, Sk] additive key mask -> [B*Sq, H]"""
+        H, nh = self.arch["hidden"], self.arch["heads"]
+        S = max(Sq, Sk)
+        q = self._lin(q_in, n + ".query").view(B, Sq, H)
+        k = self._lin(ctx_in, n + ".key").view(B, Sk, H)
+        v = self._lin(ctx_in, n + ".value").view(B, Sk, H)
+        pad = lambda t, L: t if L == S else F.pad(t, (0, 0, 0, S - L))
+        qkv = torch.cat([pad(q, Sq), pad(k, Sk), pad(v, Sk)], dim=2).view(B * S, 3 * H)
+        bias = ctx_bias if Sk == S else F.pad(ctx_bias, (0, S - Sk), value=float("-inf"))
+        p = self.arch["p_attn"] if self.training else 0.0
+        out = _Attention.apply(qkv, bias.contiguous(), B, S, nh, p, self.oc.next_seed() if p > 0 else 0, self.oc)
+        return out.view(B, S, H)[:, :Sq].reshape(B * Sq, H)
+
+    def _att_block(self, n, inner, x, ctx, ctx_bias, B, Sq, Sk):
+        a = self._attend(x, ctx, ctx_bias, f"{n}.{inner}", B, Sq, Sk)
+        return self._ln(self._drop(self._lin(a, n + ".output.dense"), self.arch["p_hidden"]) + x, n + ".output.LayerNorm")
+
+    def _ffn(self, i_, o_, x):
+        h = F.gelu(self._lin(x, i_ + ".dense"))
+        return self._ln(self._drop(self._lin(h, o_ + ".dense"), self.arch["p_hidden"]) + x, o_ + ".LayerNorm")
+
+    def encode(self, ids, mask, token_type_ids, features, boxes):
+        """HF LxmertModel.forward -> (language_output [B,T,H], vision_output [B,36,H])"""
+        a, oc = self.arch, self.oc
+        B, T = ids.shape
+        Nb = features.shape[1]
+        if max(T, Nb) > 128:
+            raise ValueError("max(text length, boxes) <= 128 (attention backward)")
+        e = "model.embeddings."
+        tt = torch.zeros_like(ids) if token_type_ids is None else token_type_ids
+        emb = lambda n, idx: F.embedding(idx, self._P(e + n), padding_idx=0)      # HF: padding_idx=0 on all three tables
+        x = emb("word_embeddings.weight", ids) + emb("position_embeddings.weight", torch.arange(T, device=ids.device))[None] + emb("token_type_embeddings.weight", tt)
+        lang = self._drop(self._ln(x.to(oc.tdt).view(B * T, -1), e + "LayerNorm"), a["p_hidden"])
+        v = "model.encoder.visn_fc."
+        f = self._ln(self._lin(features.to(oc.tdt).reshape(B * Nb, -1).contiguous(), v + "visn_fc"), v + "visn_layer_norm")
+        bx = self._ln(self._lin(boxes.to(oc.tdt).reshape(B * Nb, -1).contiguous(), v + "box_fc"), v + "box_layer_norm")
+        visn = self._drop((f + bx) / 2, a["p_hidden"])
+        lbias = torch.where(mask.bool(), 0.0, float("-inf")).to(torch.float32).contiguous()
+        vbias = torch.zeros(B, Nb, dtype=torch.float32, device=ids.device)
+        for i in range(a["l_layers"]):
+            b = f"model.encoder.layer.{i}."
+            lang = self._ffn(b + "intermediate", b + "output", self._att_block(b + "attention", "self", lang, lang, lbias, B, T, T))
+        for i in range(a["r_layers"]):
+            b = f"model.encoder.r_layers.{i}."
+            visn = self._ffn(b + "intermediate", b + "output", self._att_block(b + "attention", "self", visn, visn, vbias, B, Nb, Nb))
+        for i in range(a["x_layers"]):
+            b = f"model.encoder.x_layers.{i}."
+            la = self._att_block(b + "visual_attention", "att", lang, visn, vbias, B, T, Nb)      # ONE module, both directions
+            va = self._att_block(b + "visual_attention", "att", visn, lang, lbias, B, Nb, T)
+            la = self._att_block(b + "lang_self_att", "self", la, la, lbias, B, T, T)
+            va = self._att_block(b + "visn_self_att", "self", va, va, vbias, B, Nb, Nb)
+            lang = self._ffn(b + "lang_inter", b + "lang_output", la)
+            visn = self._ffn(b + "visn_inter", b + "visn_output", va)
+        return lang.view(B, T, -1), visn.view(B, Nb, -1)
+
+    def forward(self, ids, mask, token_type_ids, features, normalized_boxes, tim_inputs=None):
+        """reference :121-163 -> (linear_output, max_embeddings_t, max_embeddings_v, out_tim), fp32"""
+        dev = self.device_
+        ids, mask = ids.to(dev), mask.to(dev)
+        tt = None if token_type_ids is None else token_type_ids.to(dev)
+        features, boxes = features.to(dev, torch.float32), normalized_boxes.to(dev, torch.float32)
+        x_t, x_v = self.encode(ids, mask, tt, features, boxes)
+        xt = torch.relu(self._lin(x_t[:, 0].contiguous(), "linear_fusion"))
+        out = self._lin(self._drop(xt, self.p_head).contiguous(), "linear").float()
+        last = x_t.detach().float().clone()                        # :139-143: no gradient into the text embedding
+        last[mask.unsqueeze(-1).expand(last.shape) == 0] = -1e9
+        emb_t = last.max(1)[0]
+        emb_v = x_v.float().max(1)[0]
+        out_tim = None
+        if tim_inputs is not None:
+            t_ids, t_mask, t_tt = tim_inputs
+            x_t2, _ = self.encode(t_ids.to(dev), t_mask.to(dev), None if t_tt is None else t_tt.to(dev), features, boxes)
+            out_tim = self._lin(x_t2[:, 0].contiguous(), "linear_tim").float()
+        return out, emb_t, emb_v, out_tim
+
+    def get_logits_per_text(self, text_embeds, image_embeds):
+        """reference :165-172"""
+        image_embeds = image_embeds / image_embeds.norm(p=2, dim=-1, keepdim=True)
+        text_embeds = text_embeds / text_embeds.norm(p=2, dim=-1, keepdim=True)
+        return torch.matmul(text_embeds, image_embeds.t()) * self._P("logit_scale").exp()
+
+
+class MMEarly_Model(object):
+    """reference models/mm_early.py:175-520, LXMERT branch: loss mixing :366-379, ITM sampling (same numpy stream as mm_late),
+    AdamW over every parameter that received a gradient (the pooler never does: torch skips `grad is None`)."""
+
+    def __init__(self, config, model_name="lxmert", multilabel=False, **model_kw):
+        if model_name != "lxmert":
+            raise NotImplementedError("early fusion: only the LXMERT branch (BASELINE config 5); ViLT is out of scope (SURVEY.md 2)")
+        if multilabel:
+            raise NotImplementedError("multilabel BCE branch: no task enables it in the reference")
+        self.batch_size, self.num_labels = config.batch_size, config.num_labels
+        self.use_clip_loss, self.beta_itc = config.use_clip_loss, config.beta_itc
+        self.use_tim_loss, self.beta_itm = config.use_tim_loss, config.beta_itm
+        self.max_length = config.max_length
+        self.model = Lxmert(model_kw.pop("model_dir", None), self.num_labels, self.max_length, dropout=config.dropout, **model_kw)
+        self.device = self.model.device_
+        self._opt = {}
+
+    def prepare_itm_inputs(self, ids, mask, token_type_ids=None):
+        """reference :300-330 (same draws as mm_late.prepare_itm_inputs, plus the token type ids of the swapped rows)"""
+        B = ids.shape[0]
+        src, labels = list(range(B)), [1] * B
+        if B > 1:
+            for idx in range(B):
+                if np.random.choice(2) == 0:
+                    labels[idx] = 0
+                    j = int(np.random.choice(B - 1))
+                    src[idx] = j if j < idx else j + 1
+        sel = torch.tensor(src, device=ids.device)
+        tt = None if token_type_ids is None else token_type_ids.index_select(0, sel)
+        return ids.index_select(0, sel), mask.index_select(0, sel), tt, torch.tensor(labels, device=self.device)
+
+    def loss(self, out, onehot, class_weight, emb_t, emb_v, out_tim, lbl_tim):
+        """reference :366-379"""
+        label = onehot.to(out.device).type_as(out)
+        lc = F.cross_entropy(out, label, weight=None if class_weight is None else class_weight.to(out.device, torch.float32))
+        bi = self.beta_itc if self.use_clip_loss else 0.0
+        bm = self.beta_itm if self.use_tim_loss else 0.0
+        total = (1 - (bi + bm)) * lc
+        if self.use_clip_loss:
+            total = total + bi * clip_loss(self.model.get_logits_per_text(emb_t, emb_v))
+        if self.use_tim_loss:
+            total = total + bm * F.cross_entropy(out_tim, lbl_tim)
+        return total
+
+    def train_step(self, ids, mask, token_type_ids, features, boxes, onehot, class_weight, lr, weight_decay, step):
+        m = self.model
+        m.train()
+        dev = self.device
+        ids, mask = ids.to(dev), mask.to(dev)
+        tt = None if token_type_ids is None else token_type_ids.to(dev)
+        tim, lbl = None, None
+        if self.use_tim_loss:
+            t_ids, t_mask, t_tt, lbl = self.prepare_itm_inputs(ids, mask, tt)
+            tim = (t_ids, t_mask, t_tt)
+        out, et, ev, otim = m(ids, mask, tt, features, boxes, tim_inputs=tim)
+        loss = self.loss(out, onehot, class_weight, et, ev, otim, lbl)
+        loss.backward()
+        lib = _lib.lib()
+        for name, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            st = self._opt.get(name)
+            if st is None:
+                st = self._opt[name] = (torch.zeros_like(p), torch.zeros_like(p))
+            g = p.grad.contiguous()
+            _lib.check(lib.mmhip_adamw(_p(p.data), _p(g), _p(st[0]), _p(st[1]), p.numel(), lr, 0.9, 0.999, 1e-8, weight_decay, step, 1.0, 0, _s()), "adamw")
+            p.grad = None
+        m.oc.cache.clear()                                     # the kernels updated the weights through raw pointers: drop the 16-bit copies
+        return loss.detach()
+
+    def eval(self, batches, class_weight=None):
+        """reference :430-520 for the LXMERT branch: eval-mode forward, loss mix with re-sampled ITM negatives, argmax"""
+        m = self.model
+        m.eval()
+        preds, labels, ids_all, losses = [], [], [], []
+        with torch.no_grad():
+            for b in batches:
+                ids, mask = b["input_ids"].squeeze(1).to(self.device), b["attention_mask"].squeeze(1).to(self.device)
+                tt = b["token_type_ids"].squeeze(1).to(self.device) if "token_type_ids" in b else None
+                tim, lbl = None, None
+                if self.use_tim_loss:
+                    t_ids, t_mask, t_tt, lbl = self.prepare_itm_inputs(ids, mask, tt)
+                    tim = (t_ids, t_mask, t_tt)
+                out, et, ev, otim = m(ids, mask, tt, b["features"], b["normalized_boxes"], tim_inputs=tim)
+                losses.append(float(self.loss(out, b["labels"], class_weight, et, ev, otim, lbl)))
+                preds.append(out.argmax(1).cpu()); labels.append(b["labels"].argmax(1).cpu())
+                if "data_id" in b:
+                    ids_all.append(b["data_id"])
+        return {"data_id": torch.cat(ids_all).numpy() if ids_all else np.zeros(0, dtype=np.int64), "loss": float(np.mean(losses)),
+                "predictions": torch.cat(preds).numpy(), "labels": torch.cat(labels).numpy()}
