@@ -45,6 +45,7 @@ class _Ctx:
         self.cache = {}
         self.calls = 0
         self.seed = 0x5DEECE66D
+        self.gview = {}            # id(parameter) -> its slice of the flat gradient buffer: the operators accumulate there directly
 
     def weight(self, w, transpose=False):
         """activation-typed copy of an fp32 [N,K] weight ([K,N] when transpose), refreshed when the parameter changed"""
@@ -59,6 +60,23 @@ class _Ctx:
             out = torch.empty((K, N) if transpose else (N, K), dtype=self.tdt, device=w.device)
             _lib.check(_lib.lib().mmhip_op_cast(self.code, _p(w.detach()), _p(out), N * K, N if transpose else 0, K if transpose else 0, _s()), "cast")
         self.cache[key] = (w._version, out)
+        return out
+
+    def weight_cat(self, ws, transpose=False):
+        """activation-typed copy of the row-wise concatenation of fp32 [N_i, K] weights (fused Q / K / V projection)"""
+        key = (tuple(id(w) for w in ws), transpose)
+        ver = tuple(w._version for w in ws)
+        hit = self.cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        cat = torch.cat([w.detach() for w in ws], dim=0)
+        N, K = cat.shape
+        if self.tdt == torch.float32:
+            out = cat.t().contiguous() if transpose else cat
+        else:
+            out = torch.empty((K, N) if transpose else (N, K), dtype=self.tdt, device=cat.device)
+            _lib.check(_lib.lib().mmhip_op_cast(self.code, _p(cat), _p(out), N * K, N if transpose else 0, K if transpose else 0, _s()), "cast")
+        self.cache[key] = (ver, out)
         return out
 
     def next_seed(self):
@@ -77,7 +95,7 @@ class _Linear(torch.autograd.Function):
         _lib.check(_lib.lib().mmhip_op_gemm_nt(oc.code, _p(x), K, _p(oc.weight(w)), K, _p(y), N, M, N, K, _p(b), 0, None, 0, None, 0, 0.0, 0, 0,
                                                None, 0, 0, 0, _s()), "gemm_nt")
         ctx.save_for_backward(x, w)
-        ctx.oc, ctx.has_b = oc, b is not None
+        ctx.oc, ctx.has_b, ctx.b = oc, b is not None, b
         return y
 
     @staticmethod
@@ -92,13 +110,81 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty(M, K, dtype=oc.tdt, device=x.device)
             _lib.check(lib.mmhip_op_gemm_nt(oc.code, _p(dy), N, _p(oc.weight(w, True)), N, _p(dx), K, M, K, N, None, 0, None, 0, None, 0, 0.0, 0, 0,
                                             None, 0, 0, 0, _s()), "gemm_nt dx")
-        dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
+        # weight / bias gradients are ADDED into the parameters' slices of the flat gradient buffer (zeroed by AdamW); autograd gets None
+        gw, gb = oc.gview[id(w)], (oc.gview[id(ctx.b)] if ctx.has_b else None)
         fused_db = ctx.has_b and N % 4 == 0                  # the column-sum leg of gemm_tn wants 4-element columns; the 3- / 2-wide heads sum in torch
-        db = torch.zeros(N, dtype=torch.float32, device=x.device) if fused_db else None
-        _lib.check(lib.mmhip_op_gemm_tn(oc.code, _p(dy), N, _p(x), K, _p(dw), K, M, N, K, 0, 0, _p(db), _s()), "gemm_tn")
+        _lib.check(lib.mmhip_op_gemm_tn(oc.code, _p(dy), N, _p(x), K, _p(gw), K, M, N, K, 1, 0, _p(gb) if fused_db else None, _s()), "gemm_tn")
         if ctx.has_b and not fused_db:
-            db = dy.float().sum(0)
-        return dx, dw, db, None
+            gb.add_(dy.float().sum(0))
+        return dx, None, None, None
+
+
+class _LinearQKV(torch.autograd.Function):
+    """[q | k | v] = x [Wq; Wk; Wv]^T + [bq | bk | bv] in ONE gemm_nt (self-attention: the packed rows the attention kernels read);
+    backward: one gemm_nt for dx, one gemm_tn for the three weight gradients and their bias gradients"""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, oc):
+        M, K = x.shape
+        N = wq.shape[0] + wk.shape[0] + wv.shape[0]
+        y = torch.empty(M, N, dtype=oc.tdt, device=x.device)
+        b = torch.cat([bq.detach(), bk.detach(), bv.detach()])
+        _lib.check(_lib.lib().mmhip_op_gemm_nt(oc.code, _p(x), K, _p(oc.weight_cat((wq, wk, wv))), K, _p(y), N, M, N, K, _p(b), 0, None, 0, None, 0, 0.0, 0, 0,
+                                               None, 0, 0, 0, _s()), "gemm_nt qkv")
+        ctx.save_for_backward(x, wq, wk, wv)
+        ctx.oc, ctx.bs = oc, (bq, bk, bv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq, wk, wv = ctx.saved_tensors
+        oc, lib = ctx.oc, _lib.lib()
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = dy.shape[1]
+        dx = torch.empty(M, K, dtype=oc.tdt, device=x.device)
+        _lib.check(lib.mmhip_op_gemm_nt(oc.code, _p(dy), N, _p(oc.weight_cat((wq, wk, wv), True)), N, _p(dx), K, M, K, N, None, 0, None, 0, None, 0, 0.0, 0, 0,
+                                        None, 0, 0, 0, _s()), "gemm_nt dx")
+        n = wq.shape[0]
+        for i, (w, b) in enumerate(((wq, ctx.bs[0]), (wk, ctx.bs[1]), (wv, ctx.bs[2]))):      # column block i of dy against x, added into the flat gradient
+            _lib.check(lib.mmhip_op_gemm_tn(oc.code, C.c_void_p(dy.data_ptr() + i * n * dy.element_size()), N, _p(x), K, _p(oc.gview[id(w)]), K, M, n, K, 1, 0,
+                                            _p(oc.gview[id(b)]), _s()), "gemm_tn qkv")
+        return dx, None, None, None, None, None, None, None
+
+
+class _FFN(torch.autograd.Function):
+    """y = GELU(x W1^T + b1) W2^T + b2: GELU and the pre-activation stash in the first GEMM's epilogue; backward: gelu' in the
+    epilogue of the dh GEMM (the same fused epilogues mm_late's engine uses)"""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, oc):
+        M, K = x.shape
+        I = w1.shape[0]
+        lib = _lib.lib()
+        h = torch.empty(M, I, dtype=oc.tdt, device=x.device)
+        u = torch.empty(M, I, dtype=oc.tdt, device=x.device)
+        _lib.check(lib.mmhip_op_gemm_nt(oc.code, _p(x), K, _p(oc.weight(w1)), K, _p(h), I, M, I, K, _p(b1), 1, _p(u), I, None, 0, 0.0, 0, 0, None, 0, 0, 0, _s()), "ffn fc1")
+        y = torch.empty(M, K, dtype=oc.tdt, device=x.device)
+        _lib.check(lib.mmhip_op_gemm_nt(oc.code, _p(h), I, _p(oc.weight(w2)), I, _p(y), K, M, K, I, _p(b2), 0, None, 0, None, 0, 0.0, 0, 0, None, 0, 0, 0, _s()), "ffn fc2")
+        ctx.save_for_backward(x, w1, w2, h, u)
+        ctx.oc, ctx.bs = oc, (b1, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, h, u = ctx.saved_tensors
+        oc, lib = ctx.oc, _lib.lib()
+        dy = dy.contiguous()
+        M, K = x.shape
+        I = w1.shape[0]
+        du = torch.empty(M, I, dtype=oc.tdt, device=x.device)          # (dy W2) * gelu'(u)
+        _lib.check(lib.mmhip_op_gemm_nt(oc.code, _p(dy), K, _p(oc.weight(w2, True)), K, _p(du), I, M, I, K, None, 0, None, 0, _p(u), I, 0.0, 0, 0, None, 0, 0, 0, _s()), "ffn du")
+        dx = torch.empty(M, K, dtype=oc.tdt, device=x.device)
+        _lib.check(lib.mmhip_op_gemm_nt(oc.code, _p(du), I, _p(oc.weight(w1, True)), I, _p(dx), K, M, K, I, None, 0, None, 0, None, 0, 0.0, 0, 0, None, 0, 0, 0, _s()), "ffn dx")
+        g = oc.gview
+        _lib.check(lib.mmhip_op_gemm_tn(oc.code, _p(dy), K, _p(h), I, _p(g[id(w2)]), I, M, K, I, 1, 0, _p(g[id(ctx.bs[1])]), _s()), "ffn dW2")
+        _lib.check(lib.mmhip_op_gemm_tn(oc.code, _p(du), I, _p(x), K, _p(g[id(w1)]), K, M, I, K, 1, 0, _p(g[id(ctx.bs[0])]), _s()), "ffn dW1")
+        return dx, None, None, None, None, None
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -110,7 +196,7 @@ class _LayerNorm(torch.autograd.Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().mmhip_op_layernorm_fwd(oc.code, _p(x), _p(y), _p(g), _p(b), _p(mean), _p(rstd), rows, width, eps, _s()), "ln_fwd")
         ctx.save_for_backward(x, g, mean, rstd)
-        ctx.oc = oc
+        ctx.oc, ctx.b = oc, b
         return y
 
     @staticmethod
@@ -120,10 +206,9 @@ class _LayerNorm(torch.autograd.Function):
         rows, width = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dg = torch.zeros(width, dtype=torch.float32, device=x.device)
-        db = torch.zeros(width, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().mmhip_op_layernorm_bwd(oc.code, _p(dy), _p(x), _p(g), _p(mean), _p(rstd), _p(dx), None, _p(dg), _p(db), rows, width, _s()), "ln_bwd")
-        return dx, dg, db, None, None
+        _lib.check(_lib.lib().mmhip_op_layernorm_bwd(oc.code, _p(dy), _p(x), _p(g), _p(mean), _p(rstd), _p(dx), None, _p(oc.gview[id(g)]), _p(oc.gview[id(ctx.b)]),
+                                                     rows, width, _s()), "ln_bwd")       # d gamma / d beta are added into the flat gradient
+        return dx, None, None, None, None
 
 
 class _Attention(torch.autograd.Function):
@@ -170,7 +255,17 @@ class Lxmert(nn.Module):
         self.oc = _Ctx(dtype)
         self.device_ = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
         g = torch.Generator(device="cpu").manual_seed(seed)
-        for name, shape in self.param_shapes(a, num_labels).items():
+        shapes = self.param_shapes(a, num_labels)
+        # one flat fp32 buffer for the parameters, one for the gradients (every parameter 16-byte aligned): AdamW is a few launches
+        # over flat ranges, and the operators add weight gradients straight into the gradient slices
+        offs, total = {}, 0
+        for name, shape in shapes.items():
+            offs[name] = total
+            total += (int(np.prod(shape, dtype=np.int64)) if shape else 1) + 3 & ~3
+        self._flat = torch.zeros(total, dtype=torch.float32, device=self.device_)
+        self._flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device_)
+        self._offs, self._shapes = offs, shapes
+        for name, shape in shapes.items():
             if name == "logit_scale":
                 val = torch.ones([]) * logit_scale_init_value
             elif name.endswith("LayerNorm.weight") or name.endswith("layer_norm.weight"):
@@ -179,14 +274,47 @@ class Lxmert(nn.Module):
                 val = torch.zeros(shape)
             else:
                 val = torch.randn(shape, generator=g) * 0.02
+            n = val.numel()
+            view = self._flat[offs[name]: offs[name] + n].view(shape)
+            view.copy_(val)
             node, parts = self, name.split(".")
             for part in parts[:-1]:
                 if part not in node._modules:
                     node.add_module(part, _Node())
                 node = node._modules[part]
-            node.register_parameter(parts[-1], nn.Parameter(val.to(self.device_)))
+            node.register_parameter(parts[-1], nn.Parameter(view))
+        self._attach_grads()
         if model_dir and os.path.isdir(model_dir):
             self._load_hf(model_dir)
+
+    def _attach_grads(self):
+        """every parameter's .grad is its slice of the flat gradient buffer (autograd accumulates in place for the few parameters torch ops
+        consume: embeddings, logit_scale; the HIP operators add into the slices themselves)"""
+        self.oc.gview = {}
+        for name, p in self.named_parameters():
+            n = p.numel()
+            gv = self._flat_grad[self._offs[name]: self._offs[name] + n].view(p.shape)
+            p.grad = gv
+            self.oc.gview[id(p)] = gv
+
+    def zero_grad(self, set_to_none=False):
+        self._flat_grad.zero_()
+        self._attach_grads()
+
+    def grad_ranges(self, use_itc, use_itm):
+        """[begin, end) element ranges of the flat buffers that receive a gradient for this flag set: never the pooler (mm_early.py:132
+        takes the CLS row itself), linear_tim only with ITM, logit_scale only with ITC -- torch's AdamW skips `grad is None` tensors"""
+        out = []
+        for name, shape in self._shapes.items():
+            if name.startswith("model.pooler.") or (name.startswith("linear_tim.") and not use_itm) or (name == "logit_scale" and not use_itc):
+                continue
+            b = self._offs[name]
+            e = b + ((int(np.prod(shape, dtype=np.int64)) if shape else 1) + 3 & ~3)
+            if out and out[-1][1] == b:
+                out[-1][1] = e
+            else:
+                out.append([b, e])
+        return out
 
     @staticmethod
     def param_shapes(a, num_labels):
@@ -276,13 +404,17 @@ class Lxmert(nn.Module):
         """LxmertAttention(q_in, ctx_in): q_in [B*Sq, H], ctx_in [B*Sk, H], ctx_bias [B, Sk] additive key mask -> [B*Sq, H]"""
         H, nh = self.arch["hidden"], self.arch["heads"]
         S = max(Sq, Sk)
+        p = self.arch["p_attn"] if self.training else 0.0
+        if q_in is ctx_in:                                   # self-attention: one GEMM writes the packed [rows, 3H] tensor
+            qkv = _LinearQKV.apply(q_in.contiguous(), self._P(n + ".query.weight"), self._P(n + ".query.bias"), self._P(n + ".key.weight"),
+                                   self._P(n + ".key.bias"), self._P(n + ".value.weight"), self._P(n + ".value.bias"), self.oc)
+            return _Attention.apply(qkv, ctx_bias.contiguous(), B, S, nh, p, self.oc.next_seed() if p > 0 else 0, self.oc)
         q = self._lin(q_in, n + ".query").view(B, Sq, H)
         k = self._lin(ctx_in, n + ".key").view(B, Sk, H)
         v = self._lin(ctx_in, n + ".value").view(B, Sk, H)
         pad = lambda t, L: t if L == S else F.pad(t, (0, 0, 0, S - L))
         qkv = torch.cat([pad(q, Sq), pad(k, Sk), pad(v, Sk)], dim=2).view(B * S, 3 * H)
         bias = ctx_bias if Sk == S else F.pad(ctx_bias, (0, S - Sk), value=float("-inf"))
-        p = self.arch["p_attn"] if self.training else 0.0
         out = _Attention.apply(qkv, bias.contiguous(), B, S, nh, p, self.oc.next_seed() if p > 0 else 0, self.oc)
         return out.view(B, S, H)[:, :Sq].reshape(B * Sq, H)
 
@@ -291,8 +423,8 @@ class Lxmert(nn.Module):
         return self._ln(self._drop(self._lin(a, n + ".output.dense"), self.arch["p_hidden"]) + x, n + ".output.LayerNorm")
 
     def _ffn(self, i_, o_, x):
-        h = F.gelu(self._lin(x, i_ + ".dense"))
-        return self._ln(self._drop(self._lin(h, o_ + ".dense"), self.arch["p_hidden"]) + x, o_ + ".LayerNorm")
+        y = _FFN.apply(x.contiguous(), self._P(i_ + ".dense.weight"), self._P(i_ + ".dense.bias"), self._P(o_ + ".dense.weight"), self._P(o_ + ".dense.bias"), self.oc)
+        return self._ln(self._drop(y, self.arch["p_hidden"]) + x, o_ + ".LayerNorm")
 
     def encode(self, ids, mask, token_type_ids, features, boxes):
         """HF LxmertModel.forward -> (language_output [B,T,H], vision_output [B,36,H])"""
@@ -370,7 +502,7 @@ class MMEarly_Model(object):
         self.max_length = config.max_length
         self.model = Lxmert(model_kw.pop("model_dir", None), self.num_labels, self.max_length, dropout=config.dropout, **model_kw)
         self.device = self.model.device_
-        self._opt = {}
+        self._opt = None
 
     def prepare_itm_inputs(self, ids, mask, token_type_ids=None):
         """reference :300-330 (same draws as mm_late.prepare_itm_inputs, plus the token type ids of the swapped rows)"""
@@ -413,15 +545,12 @@ class MMEarly_Model(object):
         loss = self.loss(out, onehot, class_weight, et, ev, otim, lbl)
         loss.backward()
         lib = _lib.lib()
-        for name, p in m.named_parameters():
-            if p.grad is None:
-                continue
-            st = self._opt.get(name)
-            if st is None:
-                st = self._opt[name] = (torch.zeros_like(p), torch.zeros_like(p))
-            g = p.grad.contiguous()
-            _lib.check(lib.mmhip_adamw(_p(p.data), _p(g), _p(st[0]), _p(st[1]), p.numel(), lr, 0.9, 0.999, 1e-8, weight_decay, step, 1.0, 0, _s()), "adamw")
-            p.grad = None
+        if self._opt is None or not isinstance(self._opt, tuple):
+            self._opt = (torch.zeros_like(m._flat), torch.zeros_like(m._flat))
+        at = lambda t, el: C.c_void_p(t.data_ptr() + el * 4)
+        for b, e in m.grad_ranges(self.use_clip_loss, self.use_tim_loss):
+            _lib.check(lib.mmhip_adamw(at(m._flat, b), at(m._flat_grad, b), at(self._opt[0], b), at(self._opt[1], b), e - b, lr, 0.9, 0.999, 1e-8,
+                                       weight_decay, step, 1.0, 1, _s()), "adamw")          # zero_grad fused: the slices are clean for the next step
         m.oc.cache.clear()                                     # the kernels updated the weights through raw pointers: drop the 16-bit copies
         return loss.detach()
 
