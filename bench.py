@@ -72,46 +72,66 @@ def bench_early(args):
     import torch
     import smtc_amd  # noqa: F401
     from smtc_amd.mm_early import MMEarly_Model
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        raise SystemExit("config 5 is single-GPU in this round (the early-fusion path has no gradient exchange yet)")
+    from smtc_amd import dist as mmdist
+    mmdist.init_from_env()
+    world, rank = mmdist.world_size(), mmdist.rank()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
     B, T, NB, H, I, C = args.batch, 128, 36, 768, 3072, 3
     cfg = types.SimpleNamespace(batch_size=B, num_labels=C, use_clip_loss=args.aux, beta_itc=0.1, use_tim_loss=args.aux, beta_itm=0.1, max_length=T, dropout=0.05)
     tr = MMEarly_Model(cfg, "lxmert", dtype=args.dtype, seed=0)
-    g = torch.Generator().manual_seed(1234)
+    g = torch.Generator().manual_seed(1234 + rank)
     ids = torch.randint(1, 30522, (B, T), generator=g).cuda()
     mask = torch.ones(B, T, dtype=torch.int64).cuda()
     tt = torch.zeros_like(ids)
     feats = (torch.rand(B, NB, 2048, generator=g) * 2).cuda()
     boxes = torch.rand(B, NB, 4, generator=g).cuda()
     onehot = torch.nn.functional.one_hot(torch.randint(0, C, (B,), generator=g), C).cuda()
-    np.random.seed(30)
+    np.random.seed(30 + rank)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
     step = 0
     for _ in range(args.warmup):
         step += 1
         tr.train_step(ids, mask, tt, feats, boxes, onehot, None, 1e-5, 0.00025, step)
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step += 1
         loss = tr.train_step(ids, mask, tt, feats, boxes, onehot, None, 1e-5, 0.00025, step)
-    torch.cuda.synchronize()
+    sync()
     el = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([el], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        el = float(tmax.item())
     layer = 2.0 * (4 * H * H + 2 * H * I)                       # Linear FLOPs per token of a BERT-shaped layer
     xlayer = 2.0 * (8 * H * H + 2 * H * I)                      # cross-modality layer: cross + self attention blocks, feed-forward
     fwd = (9 * layer + 5 * xlayer) * T + (5 * layer + 5 * xlayer) * NB + 2.0 * NB * (2048 + 4) * H
     gf_post = 3 * fwd * (2 if args.aux else 1) / 1e9
-    tf = B * args.steps / el * gf_post / 1e3
-    out = {"metric": "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion, bs=64", "value": round(B * args.steps / el, 1), "unit": "posts/s", "n_gpus": 1,
+    tf = B * args.steps / el * gf_post / 1e3                     # per GPU
+    out = {"metric": "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion, bs=64", "value": round(world * B * args.steps / el, 1), "unit": "posts/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "BASELINE config 5: LXMERT early fusion (mm_early.py), 36 x 2048 ROI features, bs=32/GPU" + (", ITC + ITM" if args.aux else ""),
                       "implementation": "first version: HIP operators (GEMM / LayerNorm / attention / AdamW) chained by torch autograd; launch-bound",
-                      "gf_per_post": round(gf_post, 1), "posts_per_gpu": B, "text_tokens": T, "boxes": NB, "parallelism": "dp1", "weights": "random-init at true shapes"},
+                      "gf_per_post": round(gf_post, 1), "posts_per_gpu": B, "text_tokens": T, "boxes": NB, "parallelism": f"dp{world}", "weights": "random-init at true shapes"},
            "final_loss": round(float(loss), 5),
            "roofline": {"bound": "mfma", "kernel": "whole step (no per-kernel timing on this path)", "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / PEAK_TFLOPS, 4), "traffic": None},
            "cpu_baseline": None}
-    print(json.dumps(out))
+    if world > 1:
+        out["multi_gpu"] = "one all-reduce of the flat gradient per step (unmeasured on hardware: the development box has one GPU)"
+        torch.distributed.barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def main():

@@ -24,7 +24,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .utils import clip_loss
+from . import dist as mmdist
+from .utils import clip_loss, agg_metrics_val
+from .config import metric_names
 
 _DT = {"bf16": (_lib.BF16, torch.bfloat16), "f16": (_lib.F16, torch.float16), "bf16x3": (_lib.F32, torch.float32)}
 
@@ -545,24 +547,67 @@ class MMEarly_Model(object):
         loss = self.loss(out, onehot, class_weight, et, ev, otim, lbl)
         loss.backward()
         lib = _lib.lib()
+        world = mmdist.world_size()
+        if world > 1:                                          # data parallel: one all-reduce of the flat gradient (RCCL: backend "nccl"); AdamW averages
+            torch.distributed.all_reduce(m._flat_grad)
         if self._opt is None or not isinstance(self._opt, tuple):
             self._opt = (torch.zeros_like(m._flat), torch.zeros_like(m._flat))
         at = lambda t, el: C.c_void_p(t.data_ptr() + el * 4)
         for b, e in m.grad_ranges(self.use_clip_loss, self.use_tim_loss):
             _lib.check(lib.mmhip_adamw(at(m._flat, b), at(m._flat_grad, b), at(self._opt[0], b), at(self._opt[1], b), e - b, lr, 0.9, 0.999, 1e-8,
-                                       weight_decay, step, 1.0, 1, _s()), "adamw")          # zero_grad fused: the slices are clean for the next step
+                                       weight_decay, step, 1.0 / world, 1, _s()), "adamw")  # zero_grad fused: the slices are clean for the next step
         m.oc.cache.clear()                                     # the kernels updated the weights through raw pointers: drop the 16-bit copies
         return loss.detach()
 
-    def eval(self, batches, class_weight=None):
+    def load_saved_model(self, model_path):
+        self.model.load_state_dict(torch.load(model_path, map_location=self.device))
+
+    def save_model(self, model_path):
+        torch.save(self.model.state_dict(), model_path)
+
+    def train(self, dataloader, val_dataloader, epochs, loss_fn=None, lr=1e-5, weight_decay=0.00025, tim_loss_fn=None, te_dataloader=None,
+              model_path=None, val_filename=None, te_filename=None, class_weight=None, log_every=50):
+        """reference :332-428 (LXMERT branch): epochs of train steps, validation / test metrics CSVs every even epoch and at the end,
+        checkpoint = plain state_dict with the reference's keys"""
+        import pandas as pd
+        if class_weight is None and loss_fn is not None and getattr(loss_fn, "weight", None) is not None:
+            class_weight = loss_fn.weight
+        res_val, res_te, step = [], [], 0
+        for epoch in range(epochs):
+            if mmdist.rank() == 0:
+                print("Epoch:", epoch + 1)
+            if hasattr(getattr(dataloader, "sampler", None), "set_epoch"):
+                dataloader.sampler.set_epoch(epoch)
+            for it, b in enumerate(dataloader):
+                step += 1
+                sq = lambda t: t.squeeze(1) if t.dim() == 3 else t
+                loss = self.train_step(sq(b["input_ids"]), sq(b["attention_mask"]), sq(b["token_type_ids"]) if "token_type_ids" in b else None,
+                                       b["features"], b["normalized_boxes"], b["labels"], class_weight, lr, weight_decay, step)
+                if log_every and it % log_every == 0 and mmdist.rank() == 0:
+                    print(f"loss {float(loss):.4f}")
+            for loader, store, fname in ((val_dataloader, res_val, val_filename), (te_dataloader, res_te, te_filename)):
+                if loader is None:
+                    continue
+                r = self.eval(loader, class_weight=class_weight)
+                r["epoch"] = epoch
+                store.append(r)
+                if fname is not None and (epoch % 2 == 0 or epoch == epochs - 1) and mmdist.rank() == 0:
+                    pd.DataFrame(agg_metrics_val(store, metric_names, self.num_labels)).to_csv(fname, index=False)
+        if model_path is not None and mmdist.rank() == 0:
+            self.save_model(model_path)
+
+    def eval(self, batches, loss_fn=None, tim_loss_fn=None, class_weight=None):
         """reference :430-520 for the LXMERT branch: eval-mode forward, loss mix with re-sampled ITM negatives, argmax"""
         m = self.model
+        if class_weight is None and loss_fn is not None and getattr(loss_fn, "weight", None) is not None:
+            class_weight = loss_fn.weight
         m.eval()
         preds, labels, ids_all, losses = [], [], [], []
+        sq = lambda t: t.squeeze(1) if t.dim() == 3 else t
         with torch.no_grad():
             for b in batches:
-                ids, mask = b["input_ids"].squeeze(1).to(self.device), b["attention_mask"].squeeze(1).to(self.device)
-                tt = b["token_type_ids"].squeeze(1).to(self.device) if "token_type_ids" in b else None
+                ids, mask = sq(b["input_ids"]).to(self.device), sq(b["attention_mask"]).to(self.device)
+                tt = sq(b["token_type_ids"]).to(self.device) if "token_type_ids" in b else None
                 tim, lbl = None, None
                 if self.use_tim_loss:
                     t_ids, t_mask, t_tt, lbl = self.prepare_itm_inputs(ids, mask, tt)

@@ -111,3 +111,79 @@ def test_train_steps_reduce_the_loss_and_leave_the_pooler_alone():
     res = tr.eval([{"input_ids": ids.unsqueeze(1), "attention_mask": mask.unsqueeze(1), "token_type_ids": tt.unsqueeze(1), "features": feats,
                     "normalized_boxes": boxes, "labels": onehot, "data_id": torch.arange(8)}])
     assert res["predictions"].shape == (8,) and np.isfinite(res["loss"]) and np.array_equal(res["labels"], onehot.argmax(1).numpy())
+
+
+def test_cli_synthetic_run_writes_the_reference_files(tmp_path):
+    """run_mm_early.py mirror on synthetic posts: metrics CSVs (reference layout), checkpoint with the reference's keys, predictions"""
+    import subprocess, sys
+    import pandas as pd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = str(tmp_path) + "/"
+    r = subprocess.run([sys.executable, "-m", "smtc_amd.run_mm_early", "--model", "lxmert", "--task", "3", "--epochs", "1", "--use_clip_loss", "--use_tim_loss",
+                        "--synthetic", "--n_synthetic", "32", "--batch_size", "8", "--arch_layers", "1", "--results_dir", res, "--save_model", "--evaltest"],
+                       cwd=root, env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    stem = res + "lxmert_task3_seed30_itc0.1itm0.1_"
+    mv = pd.read_csv(stem + "metrics_val.csv")
+    assert list(mv.columns) == ["metric", "epoch-1"] and np.isfinite(mv["epoch-1"]).all()
+    assert list(pd.read_csv(stem + "preds.csv").columns) == ["data_id", "label", "prediction"]
+    sd = torch.load(stem + "net.pth", map_location="cpu")
+    assert "model.encoder.x_layers.0.visual_attention.att.query.weight" in sd and "linear_fusion.weight" in sd and "logit_scale" in sd
+
+
+DP_EARLY = r'''
+import os, sys, types, numpy as np, torch
+sys.path.insert(0, os.environ["ROOT"])
+import smtc_amd
+from smtc_amd import dist as mmdist
+from smtc_amd.mm_early import MMEarly_Model
+from oracle import lxmert_oracle as L
+os.environ["LOCAL_RANK"] = "0"
+mmdist.init_from_env(backend="gloo")
+rank, world = mmdist.rank(), mmdist.world_size()
+cfg = types.SimpleNamespace(batch_size=4, num_labels=3, use_clip_loss=True, beta_itc=0.1, use_tim_loss=False, beta_itm=0.1, max_length=20, dropout=0.0)
+arch = dict(l_layers=1, r_layers=1, x_layers=1, vocab=300, max_pos=64, p_hidden=0.0, p_attn=0.0)
+c = L.LxmertConfig(l_layers=1, r_layers=1, x_layers=1, vocab=300, max_pos=64, num_labels=3)
+ids, mask, tt, feats, boxes, onehot = L.synthetic_batch(c, 8, 20, 5)
+tr = MMEarly_Model(cfg, "lxmert", arch=arch, seed=5, dtype="bf16x3")
+sl = slice(rank * 4, rank * 4 + 4)
+tr.train_step(ids[sl], mask[sl], tt[sl], feats[sl], boxes[sl], onehot[sl], None, 1e-3, 0.00025, 1)
+torch.save(tr.model._flat.cpu(), os.environ["OUT"] + f"/p{rank}.pt")
+torch.distributed.barrier()
+if rank == 0:
+    ref = MMEarly_Model(cfg, "lxmert", arch=arch, seed=5, dtype="bf16x3")
+    m = ref.model
+    m.train(); g = torch.zeros_like(m._flat_grad)
+    for r in range(world):
+        s2 = slice(r * 4, r * 4 + 4)
+        m.zero_grad()
+        out, et, ev, _ = m(ids[s2], mask[s2], tt[s2], feats[s2], boxes[s2])
+        ref.loss(out, onehot[s2], None, et, ev, None, None).backward()
+        g += m._flat_grad
+    m._flat_grad.copy_(g / world)
+    from smtc_amd import _lib
+    import ctypes as C
+    mom = (torch.zeros_like(m._flat), torch.zeros_like(m._flat))
+    at = lambda t, el: C.c_void_p(t.data_ptr() + el * 4)
+    for b, e in m.grad_ranges(True, False):
+        _lib.check(_lib.lib().mmhip_adamw(at(m._flat, b), at(m._flat_grad, b), at(mom[0], b), at(mom[1], b), e - b, 1e-3, 0.9, 0.999, 1e-8, 0.00025, 1, 1.0, 1, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    p0, p1 = torch.load(os.environ["OUT"] + "/p0.pt"), torch.load(os.environ["OUT"] + "/p1.pt")
+    print("DP_EARLY", (p0 - m._flat.cpu()).abs().max().item(), torch.equal(p0, p1))
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_two_rank_step_equals_averaged_single_process(tmp_path):
+    """data parallelism of the early-fusion step: two ranks on the one card (gloo), each on its half of the batch, one all-reduce of the flat
+    gradient -> identical replicas, equal to one process stepping on the averaged gradients"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_early.py"
+    script.write_text(DP_EARLY)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                        str(29300 + os.getpid() % 300), str(script)], cwd=root,
+                       env=dict(os.environ, PYTHONPATH=root, ROOT=root, OUT=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("DP_EARLY")][0].split()
+    assert float(line[1]) < 2e-6 and line[2] == "True", line
