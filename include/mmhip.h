@@ -213,6 +213,15 @@ int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, 
  * with a weight gradient, from the same operand tiles */
 int mmhip_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int Nn, int Nc,
                      int accumulate, int force_slow, float* colsum, void* stream);
+/* many such products in few launches (the kernel takes up to 8 problems per launch and fills the chip with their tiles together:
+ * a single 768 x 768 weight gradient is 18 tiles).  Used by the early-fusion path, which queues the weight gradients of a whole
+ * backward pass. */
+typedef struct mmhip_tn_problem {
+    const void* A; const void* B; float* C;
+    int32_t M, Nn, Nc, lda, ldb, ldc;
+    float* colsum;
+} mmhip_tn_problem;
+int mmhip_op_gemm_tn_group(int dtype, const mmhip_tn_problem* problems, int count, int accumulate, void* stream);
 int mmhip_op_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                            int rows, int width, float eps, void* stream);
 int mmhip_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,

@@ -29,6 +29,11 @@ class ParamInfo(C.Structure):
                 ("offset", C.c_uint64), ("numel", C.c_uint64)]
 
 
+class TNProblem(C.Structure):        # include/mmhip.h: mmhip_tn_problem
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("M", C.c_int32), ("Nn", C.c_int32), ("Nc", C.c_int32),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("colsum", C.c_void_p)]
+
+
 class MMHipError(RuntimeError):
     pass
 
@@ -71,6 +76,7 @@ _SIGS = {
     "mmhip_gemm_timing_by_shape": (I, [P, C.c_char_p, U64]),
     "mmhip_op_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, P, I, F, U64, U32, P, I, I, I, P]),
     "mmhip_op_gemm_tn": (I, [I, P, I, P, I, P, I, I, I, I, I, I, P, P]),
+    "mmhip_op_gemm_tn_group": (I, [I, P, I, I, P]),
     "mmhip_op_layernorm_fwd": (I, [I, P, P, P, P, P, P, I, I, F, P]),
     "mmhip_op_layernorm_bwd": (I, [I, P, P, P, P, P, P, P, P, P, I, I, P]),
     "mmhip_op_attn_fwd": (I, [I, P, P, P, P, I, I, I, F, U64, U32, P]),

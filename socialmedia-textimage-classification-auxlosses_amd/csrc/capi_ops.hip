@@ -2,6 +2,7 @@
 #include <cstring>
 #include <cmath>
 #include "mmhip_common.h"
+#include <vector>
 #include "mmhip_kernels.h"
 #include "../../include/mmhip.h"
 
@@ -113,6 +114,18 @@ int mmhip_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, 
     if (!A || !B || !C || M < 1 || Nn < 1 || Nc < 1 || (dtype != MMHIP_BF16 && dtype != MMHIP_F16 && dtype != MMHIP_F32)) return MMHIP_E_INVALID;
     GemmTNProblem p{A, B, C, M, Nn, Nc, lda, ldb, ldc, 0, colsum};
     CHECK_HIP(launch_gemm_tn(&p, 1, accumulate, dtype, force_slow, (hipStream_t)stream));
+    return 0;
+}
+
+int mmhip_op_gemm_tn_group(int dtype, const mmhip_tn_problem* problems, int count, int accumulate, void* stream) {
+    if (!problems || count < 0 || (dtype != MMHIP_BF16 && dtype != MMHIP_F16 && dtype != MMHIP_F32)) return MMHIP_E_INVALID;
+    std::vector<GemmTNProblem> ps((size_t)count);
+    for (int i = 0; i < count; ++i) {
+        const mmhip_tn_problem& q = problems[i];
+        if (!q.A || !q.B || !q.C || q.M < 1 || q.Nn < 1 || q.Nc < 1) return MMHIP_E_INVALID;
+        ps[i] = GemmTNProblem{q.A, q.B, q.C, q.M, q.Nn, q.Nc, q.lda, q.ldb, q.ldc, 0, q.colsum};
+    }
+    if (count) CHECK_HIP(launch_gemm_tn(ps.data(), count, accumulate, dtype, 0, (hipStream_t)stream));
     return 0;
 }
 

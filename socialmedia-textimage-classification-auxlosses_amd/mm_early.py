@@ -32,11 +32,23 @@ _DT = {"bf16": (_lib.BF16, torch.bfloat16), "f16": (_lib.F16, torch.float16), "b
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    # plain integers: the argtypes (c_void_p) convert them; building a c_void_p object per argument was a third of the step's host time
+    return None if t is None else t.data_ptr()
+
+
+_STREAM = [None]
 
 
 def _s():
-    return _lib.stream_ptr()
+    """raw handle of the stream the operators launch on: torch's current stream, looked up once per forward / step
+    (torch.cuda.current_stream() costs ~8 us; the step makes ~3000 launches)"""
+    if _STREAM[0] is None:
+        _STREAM[0] = torch.cuda.current_stream().cuda_stream
+    return _STREAM[0]
+
+
+def _refresh_stream():
+    _STREAM[0] = torch.cuda.current_stream().cuda_stream
 
 
 class _Ctx:
@@ -48,6 +60,22 @@ class _Ctx:
         self.calls = 0
         self.seed = 0x5DEECE66D
         self.gview = {}            # id(parameter) -> its slice of the flat gradient buffer: the operators accumulate there directly
+        self.tn_queue = []         # weight-gradient products of the running backward pass (dy, x, C, colsum, M, Nn, Nc, lda, A address)
+
+    def tn(self, dy, x, gw, gb, M, Nn, Nc, lda=None, a_ptr=None):
+        """queue C[Nn,Nc] += dy[:, block]^T x (+ column sums into gb): all weight gradients of a backward pass leave in a few grouped launches
+        (flush_tn): one 768 x 768 gradient alone is 18 tiles on a 256-CU chip"""
+        self.tn_queue.append((dy, x, gw, gb, M, Nn, Nc, lda if lda is not None else Nn, a_ptr if a_ptr is not None else dy.data_ptr()))
+
+    def flush_tn(self):
+        q = self.tn_queue
+        if not q:
+            return
+        arr = (_lib.TNProblem * len(q))()
+        for i, (dy, x, gw, gb, M, Nn, Nc, lda, a_ptr) in enumerate(q):
+            arr[i] = _lib.TNProblem(a_ptr, x.data_ptr(), gw.data_ptr(), M, Nn, Nc, lda, Nc, Nc, None if gb is None else gb.data_ptr())
+        _lib.check(_lib.lib().mmhip_op_gemm_tn_group(self.code, C.cast(arr, C.c_void_p), len(q), 1, _s()), "gemm_tn_group")
+        self.tn_queue = []
 
     def weight(self, w, transpose=False):
         """activation-typed copy of an fp32 [N,K] weight ([K,N] when transpose), refreshed when the parameter changed"""
@@ -115,7 +143,7 @@ class _Linear(torch.autograd.Function):
         # weight / bias gradients are ADDED into the parameters' slices of the flat gradient buffer (zeroed by AdamW); autograd gets None
         gw, gb = oc.gview[id(w)], (oc.gview[id(ctx.b)] if ctx.has_b else None)
         fused_db = ctx.has_b and N % 4 == 0                  # the column-sum leg of gemm_tn wants 4-element columns; the 3- / 2-wide heads sum in torch
-        _lib.check(lib.mmhip_op_gemm_tn(oc.code, _p(dy), N, _p(x), K, _p(gw), K, M, N, K, 1, 0, _p(gb) if fused_db else None, _s()), "gemm_tn")
+        oc.tn(dy, x, gw, gb if fused_db else None, M, N, K)
         if ctx.has_b and not fused_db:
             gb.add_(dy.float().sum(0))
         return dx, None, None, None
@@ -149,8 +177,7 @@ class _LinearQKV(torch.autograd.Function):
                                         None, 0, 0, 0, _s()), "gemm_nt dx")
         n = wq.shape[0]
         for i, (w, b) in enumerate(((wq, ctx.bs[0]), (wk, ctx.bs[1]), (wv, ctx.bs[2]))):      # column block i of dy against x, added into the flat gradient
-            _lib.check(lib.mmhip_op_gemm_tn(oc.code, C.c_void_p(dy.data_ptr() + i * n * dy.element_size()), N, _p(x), K, _p(oc.gview[id(w)]), K, M, n, K, 1, 0,
-                                            _p(oc.gview[id(b)]), _s()), "gemm_tn qkv")
+            oc.tn(dy, x, oc.gview[id(w)], oc.gview[id(b)], M, n, K, lda=N, a_ptr=dy.data_ptr() + i * n * dy.element_size())
         return dx, None, None, None, None, None, None, None
 
 
@@ -184,8 +211,8 @@ class _FFN(torch.autograd.Function):
         dx = torch.empty(M, K, dtype=oc.tdt, device=x.device)
         _lib.check(lib.mmhip_op_gemm_nt(oc.code, _p(du), I, _p(oc.weight(w1, True)), I, _p(dx), K, M, K, I, None, 0, None, 0, None, 0, 0.0, 0, 0, None, 0, 0, 0, _s()), "ffn dx")
         g = oc.gview
-        _lib.check(lib.mmhip_op_gemm_tn(oc.code, _p(dy), K, _p(h), I, _p(g[id(w2)]), I, M, K, I, 1, 0, _p(g[id(ctx.bs[1])]), _s()), "ffn dW2")
-        _lib.check(lib.mmhip_op_gemm_tn(oc.code, _p(du), I, _p(x), K, _p(g[id(w1)]), K, M, I, K, 1, 0, _p(g[id(ctx.bs[0])]), _s()), "ffn dW1")
+        oc.tn(dy, h, g[id(w2)], g[id(ctx.bs[1])], M, K, I)
+        oc.tn(du, x, g[id(w1)], g[id(ctx.bs[0])], M, I, K)
         return dx, None, None, None, None, None
 
 
@@ -299,6 +326,10 @@ class Lxmert(nn.Module):
             p.grad = gv
             self.oc.gview[id(p)] = gv
 
+    def finish_backward(self):
+        """launch the weight-gradient products queued by the backward pass (call after loss.backward(), before reading gradients)"""
+        self.oc.flush_tn()
+
     def zero_grad(self, set_to_none=False):
         self._flat_grad.zero_()
         self._attach_grads()
@@ -306,6 +337,10 @@ class Lxmert(nn.Module):
     def grad_ranges(self, use_itc, use_itm):
         """[begin, end) element ranges of the flat buffers that receive a gradient for this flag set: never the pooler (mm_early.py:132
         takes the CLS row itself), linear_tim only with ITM, logit_scale only with ITC -- torch's AdamW skips `grad is None` tensors"""
+        key = (bool(use_itc), bool(use_itm))
+        cached = getattr(self, "_ranges", {}).get(key)
+        if cached is not None:
+            return cached
         out = []
         for name, shape in self._shapes.items():
             if name.startswith("model.pooler.") or (name.startswith("linear_tim.") and not use_itm) or (name == "logit_scale" and not use_itc):
@@ -316,6 +351,9 @@ class Lxmert(nn.Module):
                 out[-1][1] = e
             else:
                 out.append([b, e])
+        if not hasattr(self, "_ranges"):
+            object.__setattr__(self, "_ranges", {})
+        self._ranges[key] = out
         return out
 
     @staticmethod
@@ -387,10 +425,11 @@ class Lxmert(nn.Module):
 
     # ---- operators
     def _P(self, name):
-        node = self
-        for part in name.split("."):
-            node = node._parameters[part] if part in node._parameters else node._modules[part]
-        return node
+        try:
+            return self._pcache[name]
+        except (AttributeError, KeyError):
+            object.__setattr__(self, "_pcache", dict(self.named_parameters()))
+            return self._pcache[name]
 
     def _lin(self, x, n):
         """Linear on [rows, K]; the fast GEMM wants N, K multiples of 8 (the 3- / 2-wide heads and the 4-wide box input take the generic kernel)"""
@@ -465,6 +504,7 @@ class Lxmert(nn.Module):
     def forward(self, ids, mask, token_type_ids, features, normalized_boxes, tim_inputs=None):
         """reference :121-163 -> (linear_output, max_embeddings_t, max_embeddings_v, out_tim), fp32"""
         dev = self.device_
+        _refresh_stream()
         ids, mask = ids.to(dev), mask.to(dev)
         tt = None if token_type_ids is None else token_type_ids.to(dev)
         features, boxes = features.to(dev, torch.float32), normalized_boxes.to(dev, torch.float32)
@@ -535,7 +575,8 @@ class MMEarly_Model(object):
 
     def train_step(self, ids, mask, token_type_ids, features, boxes, onehot, class_weight, lr, weight_decay, step):
         m = self.model
-        m.train()
+        if not m.training:
+            m.train()                                          # walks ~1500 submodules: only on a mode change
         dev = self.device
         ids, mask = ids.to(dev), mask.to(dev)
         tt = None if token_type_ids is None else token_type_ids.to(dev)
@@ -546,13 +587,14 @@ class MMEarly_Model(object):
         out, et, ev, otim = m(ids, mask, tt, features, boxes, tim_inputs=tim)
         loss = self.loss(out, onehot, class_weight, et, ev, otim, lbl)
         loss.backward()
+        m.finish_backward()
         lib = _lib.lib()
         world = mmdist.world_size()
         if world > 1:                                          # data parallel: one all-reduce of the flat gradient (RCCL: backend "nccl"); AdamW averages
             torch.distributed.all_reduce(m._flat_grad)
         if self._opt is None or not isinstance(self._opt, tuple):
             self._opt = (torch.zeros_like(m._flat), torch.zeros_like(m._flat))
-        at = lambda t, el: C.c_void_p(t.data_ptr() + el * 4)
+        at = lambda t, el: t.data_ptr() + el * 4
         for b, e in m.grad_ranges(self.use_clip_loss, self.use_tim_loss):
             _lib.check(lib.mmhip_adamw(at(m._flat, b), at(m._flat_grad, b), at(self._opt[0], b), at(self._opt[1], b), e - b, lr, 0.9, 0.999, 1e-8,
                                        weight_decay, step, 1.0 / world, 1, _s()), "adamw")  # zero_grad fused: the slices are clean for the next step

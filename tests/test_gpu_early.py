@@ -78,6 +78,7 @@ def test_loss_mixes_and_gradients_match_reference_golden(dtype):
         print("lxmert loss", dtype, tag, e)
         assert e < {"bf16x3": 1e-4, "f16": 2e-3, "bf16": 1e-2}[dtype], (tag, e)
     loss.backward()
+    m.finish_backward()
     named = dict(m.named_parameters())
     errs = {}
     for k in [f[5:] for f in z.files if f.startswith("grad.")]:
@@ -159,6 +160,7 @@ if rank == 0:
         m.zero_grad()
         out, et, ev, _ = m(ids[s2], mask[s2], tt[s2], feats[s2], boxes[s2])
         ref.loss(out, onehot[s2], None, et, ev, None, None).backward()
+        m.finish_backward()
         g += m._flat_grad
     m._flat_grad.copy_(g / world)
     from smtc_amd import _lib
