@@ -200,8 +200,9 @@ uint64_t mmhip_image_plan_tmp_bytes(const int32_t* plan_host);
 int mmhip_image_preprocess(const uint8_t* images, const int32_t* plan_host, const int32_t* plan_dev, const float* lut,
                            float* out_f32, uint8_t* out_u8, uint8_t* tmp, void* stream);
 
-/* ---- operator-level entry points (parity tests; the engine calls the same launchers).  dtype = MMHIP_BF16 | MMHIP_F16.
- * 16-bit matrices are row-major with explicit leading dimensions (elements). */
+/* ---- operator-level entry points (parity tests; the engine calls the same launchers; the first version of the early-fusion
+ * LXMERT path, reference models/mm_early.py:105-172, is built on them).  dtype = MMHIP_BF16 | MMHIP_F16 | MMHIP_F32 (= the
+ * bf16x3 parity products on fp32 matrices).  Matrices are row-major with explicit leading dimensions (elements). */
 /* C[M,N] = epilogue(A[M,K] . B[N,K]^T): + bias[N] (fp32, may be NULL); act: 0 none, 1 exact-erf GELU, 2 tanh;
  * aux_pre (may be NULL) receives the value before the activation; mul_gelu_grad_of (may be NULL): value *= gelu'(that);
  * dropout (p > 0) on element index m*N+n with (seed, stream_id); + residual (may be NULL); out_f32 selects fp32 C. */
