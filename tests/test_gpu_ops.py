@@ -257,3 +257,31 @@ def test_colsum_and_casts():
     call("mmhip_op_cast", 0, ptr(src), ptr(d1), src.numel(), 0, 0, stream())
     call("mmhip_op_cast", 0, ptr(src), ptr(d2), 0, 2304, 768, stream())
     assert torch.equal(d1, src.to(torch.bfloat16)) and torch.equal(d2, src.to(torch.bfloat16).t().contiguous())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_gemm_tn_group_matches_single_problems(dt):
+    """mmhip_op_gemm_tn_group: many C (+)= A^T B problems of different shapes in few launches (fast grouped tiles and generic shapes mixed),
+    accumulate into non-zero C and column sums -- against fp64"""
+    import ctypes as C
+    from smtc_amd import _lib
+    code, tdt = DT[dt]
+    g = torch.Generator(device="cpu").manual_seed(11)
+    shapes = [(4096, 768, 768), (4096, 3072, 768), (1152, 768, 2048), (4096, 768, 3072), (80, 3, 768), (144, 768, 4), (4096, 2304, 768), (1152, 768, 768),
+              (256, 256, 128), (4096, 768, 768), (4096, 768, 768)]
+    keep, refs = [], []
+    arr = (_lib.TNProblem * len(shapes))()
+    for i, (M, Nn, Nc) in enumerate(shapes):
+        A = (torch.randn(M, Nn, generator=g) * 0.1).to(tdt).to(dev())
+        B = (torch.randn(M, Nc, generator=g) * 0.5).to(tdt).to(dev())
+        C0 = torch.randn(Nn, Nc, generator=g).to(dev())
+        cs = torch.randn(Nn, generator=g).to(dev()) if Nn % 4 == 0 else None
+        refs.append((C0.double().cpu() + A.double().cpu().t() @ B.double().cpu(), None if cs is None else cs.double().cpu() + A.double().cpu().sum(0)))
+        keep.append((A, B, C0, cs))
+        arr[i] = _lib.TNProblem(A.data_ptr(), B.data_ptr(), C0.data_ptr(), M, Nn, Nc, Nn, Nc, Nc, None if cs is None else cs.data_ptr())
+    call("mmhip_op_gemm_tn_group", code, C.cast(arr, C.c_void_p), len(shapes), 1, stream())
+    torch.cuda.synchronize()
+    for (A, B, C0, cs), (rc, rcs), shp in zip(keep, refs, shapes):
+        assert rel_err(C0, rc) < 3e-5, shp
+        if cs is not None:
+            assert rel_err(cs, rcs) < 3e-5, shp
