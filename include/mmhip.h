@@ -223,6 +223,29 @@ typedef struct mmhip_tn_problem {
     float* colsum;
 } mmhip_tn_problem;
 int mmhip_op_gemm_tn_group(int dtype, const mmhip_tn_problem* problems, int count, int accumulate, void* stream);
+/* composite operators of the early-fusion path: one post-LN sub-block of a BERT-shaped stream per call, on caller-owned buffers
+ * (activation-typed [rows, width] matrices; weights as the activation-typed copies, `*T` = transposed copies [K_in, N_out] for the
+ * input gradients).  Self-attention block:  y = LayerNorm(dropout(att Wo^T + bo) + x), att = softmax(Q K^T / 8 + maskbias) V,
+ * [Q|K|V] = x Wqkv^T + bqkv (64-wide heads, rows = posts * S); dropouts are the hash dropouts of the fused epilogues (p_att on the
+ * probabilities, p_hid on the projection output), replayed in the backward from (seed).  Saved for the backward: qkv, att, lse, pre,
+ * mean, rstd.  The backward returns dx (incl. the residual branch) and leaves the operands of the weight gradients in
+ * dd (= d of the projection output; = dpre when p_hid == 0, then dd is not written) / att (Wo), dqkv / x (Wq, Wk, Wv): the caller
+ * runs them through mmhip_op_gemm_tn_group.  LayerNorm weight / bias gradients are ADDED to dgamma / dbeta. */
+int mmhip_op_self_att_block_fwd(int dtype, const void* x, const float* maskbias, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                                const float* gamma, const float* beta, float eps, int posts, int S, int heads, float p_att, float p_hid, uint64_t seed,
+                                void* qkv, void* att, float* lse, void* pre, float* mean, float* rstd, void* y, void* stream);
+int mmhip_op_self_att_block_bwd(int dtype, const void* dy, const float* maskbias, const void* wqkvT, const void* woT, const float* gamma, int posts, int S,
+                                int heads, float p_att, float p_hid, uint64_t seed, const void* qkv, const void* att, const float* lse, const void* pre,
+                                const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dpre, void* dd, void* datt, void* dqkv, void* dx,
+                                void* stream);
+/* feed-forward block:  y = LayerNorm(dropout(GELU(x W1^T + b1) W2^T + b2) + x); saved: h (activation), u (pre-activation), pre, mean, rstd;
+ * backward: du = (dd W2) * gelu'(u), dx = du W1 + dpre; weight-gradient operands: dd / h (W2), du / x (W1). */
+int mmhip_op_ffn_block_fwd(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, const float* beta,
+                           float eps, int M, int H, int I, float p_hid, uint64_t seed, void* h, void* u, void* pre, float* mean, float* rstd, void* y,
+                           void* stream);
+int mmhip_op_ffn_block_bwd(int dtype, const void* dy, const void* w1T, const void* w2T, const float* gamma, int M, int H, int I, float p_hid, uint64_t seed,
+                           const void* u, const void* pre, const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dpre, void* dd, void* du,
+                           void* dx, void* stream);
 int mmhip_op_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                            int rows, int width, float eps, void* stream);
 int mmhip_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,

@@ -77,6 +77,10 @@ _SIGS = {
     "mmhip_op_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, P, I, F, U64, U32, P, I, I, I, P]),
     "mmhip_op_gemm_tn": (I, [I, P, I, P, I, P, I, I, I, I, I, I, P, P]),
     "mmhip_op_gemm_tn_group": (I, [I, P, I, I, P]),
+    "mmhip_op_self_att_block_fwd": (I, [I, P, P, P, P, P, P, P, P, F, I, I, I, F, F, U64, P, P, P, P, P, P, P, P]),
+    "mmhip_op_self_att_block_bwd": (I, [I, P, P, P, P, P, I, I, I, F, F, U64, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "mmhip_op_ffn_block_fwd": (I, [I, P, P, P, P, P, P, P, F, I, I, I, F, U64, P, P, P, P, P, P, P]),
+    "mmhip_op_ffn_block_bwd": (I, [I, P, P, P, P, I, I, I, F, U64, P, P, P, P, P, P, P, P, P, P, P]),
     "mmhip_op_layernorm_fwd": (I, [I, P, P, P, P, P, P, I, I, F, P]),
     "mmhip_op_layernorm_bwd": (I, [I, P, P, P, P, P, P, P, P, P, I, I, P]),
     "mmhip_op_attn_fwd": (I, [I, P, P, P, P, I, I, I, F, U64, U32, P]),

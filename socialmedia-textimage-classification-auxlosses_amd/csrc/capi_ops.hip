@@ -129,6 +129,94 @@ int mmhip_op_gemm_tn_group(int dtype, const mmhip_tn_problem* problems, int coun
     return 0;
 }
 
+// ---- composite operators: one post-LN sub-block of a BERT-shaped stream per call (the early-fusion path's host time is launch
+// and interpreter work: a block is 3-4 launches of the same kernels, enqueued from C++)
+namespace {
+GemmNTArgs nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K) {
+    GemmNTArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    return a;
+}
+}  // namespace
+
+int mmhip_op_self_att_block_fwd(int dtype, const void* x, const float* maskbias, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                                const float* gamma, const float* beta, float eps, int posts, int S, int heads, float p_att, float p_hid, uint64_t seed,
+                                void* qkv, void* att, float* lse, void* pre, float* mean, float* rstd, void* y, void* stream) {
+    if (!x || !wqkv || !bqkv || !wo || !bo || !gamma || !beta || !qkv || !att || !lse || !pre || !mean || !rstd || !y || posts < 1 || S < 1 || heads < 1)
+        return MMHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int H = heads * 64, M = posts * S;
+    { GemmNTArgs a = nt(x, H, wqkv, H, qkv, 3 * H, M, 3 * H, H); a.bias = bqkv; a.flags = GEMM_BIAS; CHECK_HIP(launch_gemm_nt(a, dtype, s)); }
+    AttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.qkv = qkv; at.maskbias = maskbias; at.ctx = att; at.lse = lse; at.posts = posts; at.S = S; at.heads = heads;
+    at.hidden = H; at.ld_qkv = 3 * H; at.ld_ctx = H; at.scale = 0.125f; at.drop = drop_of(p_att, seed, 7);
+    CHECK_HIP(launch_attn_fwd(at, dtype, s));
+    { GemmNTArgs a = nt(att, H, wo, H, pre, H, M, H, H); a.bias = bo; a.residual = x; a.ldres = H; a.flags = GEMM_BIAS | GEMM_RESIDUAL;
+      if (p_hid > 0.f) { a.drop = drop_of(p_hid, seed, 8); a.flags |= GEMM_DROPOUT; }
+      CHECK_HIP(launch_gemm_nt(a, dtype, s)); }
+    LNArgs ln{pre, y, gamma, beta, mean, rstd, M, H, H, H, eps};
+    CHECK_HIP(launch_layernorm_fwd(ln, dtype, s));
+    return 0;
+}
+
+int mmhip_op_self_att_block_bwd(int dtype, const void* dy, const float* maskbias, const void* wqkvT, const void* woT, const float* gamma, int posts, int S,
+                                int heads, float p_att, float p_hid, uint64_t seed, const void* qkv, const void* att, const float* lse, const void* pre,
+                                const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dpre, void* dd, void* datt, void* dqkv, void* dx,
+                                void* stream) {
+    if (!dy || !wqkvT || !woT || !gamma || !qkv || !att || !lse || !pre || !mean || !rstd || !dgamma || !dbeta || !dpre || !dd || !datt || !dqkv || !dx)
+        return MMHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int H = heads * 64, M = posts * S;
+    LNBwdArgs b;
+    memset(&b, 0, sizeof(b));
+    b.dy = dy; b.x = pre; b.gamma = gamma; b.mean = mean; b.rstd = rstd; b.dx = dpre; b.dgamma = dgamma; b.dbeta = dbeta; b.rows = M; b.width = H; b.alpha = 1.0f;
+    const bool dropping = p_hid > 0.f;
+    if (dropping) { b.dx_drop = dd; b.drop = drop_of(p_hid, seed, 8); b.drop_row_mul = 1; }
+    CHECK_HIP(launch_layernorm_bwd(b, dtype, s));
+    const void* dsrc = dropping ? dd : dpre;          // gradient of the output projection's result
+    { GemmNTArgs a = nt(dsrc, H, woT, H, datt, H, M, H, H); CHECK_HIP(launch_gemm_nt(a, dtype, s)); }
+    AttnBwdArgs ab;
+    memset(&ab, 0, sizeof(ab));
+    ab.qkv = qkv; ab.maskbias = maskbias; ab.ctx = att; ab.dctx = datt; ab.lse = lse; ab.dqkv = dqkv; ab.posts = posts; ab.S = S; ab.heads = heads;
+    ab.hidden = H; ab.ld_qkv = 3 * H; ab.ld_ctx = H; ab.scale = 0.125f; ab.drop = drop_of(p_att, seed, 7);
+    CHECK_HIP(launch_attn_bwd(ab, dtype, s));
+    { GemmNTArgs a = nt(dqkv, 3 * H, wqkvT, 3 * H, dx, H, M, H, 3 * H); a.residual = dpre; a.ldres = H; a.flags = GEMM_RESIDUAL; CHECK_HIP(launch_gemm_nt(a, dtype, s)); }
+    return 0;
+}
+
+int mmhip_op_ffn_block_fwd(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, const float* beta,
+                           float eps, int M, int H, int I, float p_hid, uint64_t seed, void* h, void* u, void* pre, float* mean, float* rstd, void* y,
+                           void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !gamma || !beta || !h || !u || !pre || !mean || !rstd || !y || M < 1) return MMHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    { GemmNTArgs a = nt(x, H, w1, H, h, I, M, I, H); a.bias = b1; a.aux = u; a.ldaux = I; a.flags = GEMM_BIAS | GEMM_GELU | GEMM_AUX_PRE; CHECK_HIP(launch_gemm_nt(a, dtype, s)); }
+    { GemmNTArgs a = nt(h, I, w2, I, pre, H, M, H, I); a.bias = b2; a.residual = x; a.ldres = H; a.flags = GEMM_BIAS | GEMM_RESIDUAL;
+      if (p_hid > 0.f) { a.drop = drop_of(p_hid, seed, 9); a.flags |= GEMM_DROPOUT; }
+      CHECK_HIP(launch_gemm_nt(a, dtype, s)); }
+    LNArgs ln{pre, y, gamma, beta, mean, rstd, M, H, H, H, eps};
+    CHECK_HIP(launch_layernorm_fwd(ln, dtype, s));
+    return 0;
+}
+
+int mmhip_op_ffn_block_bwd(int dtype, const void* dy, const void* w1T, const void* w2T, const float* gamma, int M, int H, int I, float p_hid, uint64_t seed,
+                           const void* u, const void* pre, const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dpre, void* dd, void* du,
+                           void* dx, void* stream) {
+    if (!dy || !w1T || !w2T || !gamma || !u || !pre || !mean || !rstd || !dgamma || !dbeta || !dpre || !dd || !du || !dx) return MMHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    LNBwdArgs b;
+    memset(&b, 0, sizeof(b));
+    b.dy = dy; b.x = pre; b.gamma = gamma; b.mean = mean; b.rstd = rstd; b.dx = dpre; b.dgamma = dgamma; b.dbeta = dbeta; b.rows = M; b.width = H; b.alpha = 1.0f;
+    const bool dropping = p_hid > 0.f;
+    if (dropping) { b.dx_drop = dd; b.drop = drop_of(p_hid, seed, 9); b.drop_row_mul = 1; }
+    CHECK_HIP(launch_layernorm_bwd(b, dtype, s));
+    const void* dsrc = dropping ? dd : dpre;
+    { GemmNTArgs a = nt(dsrc, H, w2T, H, du, I, M, I, H); a.mul_in = u; a.ldmul = I; a.flags = GEMM_MUL_GELU_GRAD; CHECK_HIP(launch_gemm_nt(a, dtype, s)); }
+    { GemmNTArgs a = nt(du, I, w1T, I, dx, H, M, H, I); a.residual = dpre; a.ldres = H; a.flags = GEMM_RESIDUAL; CHECK_HIP(launch_gemm_nt(a, dtype, s)); }
+    return 0;
+}
+
 int mmhip_op_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                            int rows, int width, float eps, void* stream) {
     if (!x || !y || !gamma || !beta) return MMHIP_E_INVALID;

@@ -109,6 +109,16 @@ class _Ctx:
         self.cache[key] = (ver, out)
         return out
 
+    def bias_cat(self, bs):
+        key = ("b",) + tuple(id(b) for b in bs)
+        ver = tuple(b._version for b in bs)
+        hit = self.cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        out = torch.cat([b.detach() for b in bs])
+        self.cache[key] = (ver, out)
+        return out
+
     def next_seed(self):
         self.calls += 1
         return (self.seed * 0x9E3779B97F4A7C15 + self.calls) & 0xFFFFFFFFFFFFFFFF
@@ -263,110 +273,76 @@ class _Attention(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None, None
 
 
-def _gemm(oc, x, w16, ldw, y, M, N, K, bias=None, act=0, aux=None, mulg=None):
-    _lib.check(_lib.lib().mmhip_op_gemm_nt(oc.code, _p(x), K, _p(w16), ldw, _p(y), N, M, N, K, _p(bias), act, _p(aux), N if aux is not None else 0,
-                                           _p(mulg), N if mulg is not None else 0, 0.0, 0, 0, None, 0, 0, 0, _s()), "gemm_nt")
-
-
-def _drop_mask(t, p):
-    """keep-mask scaled by 1/(1-p) in the activation type, or None (torch's generator: plumbing, like the reference's nn.Dropout)"""
-    if p <= 0:
-        return None
-    return (torch.rand_like(t, dtype=torch.float32) >= p).to(t.dtype) * (1.0 / (1.0 - p))
-
-
 class _SelfAttBlock(torch.autograd.Function):
-    """LayerNorm(dropout(dense(attention(x))) + x) of one stream as ONE autograd node: fused Q/K/V GEMM, attention, output GEMM,
-    LayerNorm on the HIP operators; the dropout mask and the residual add are torch tensor ops inside the node"""
+    """LayerNorm(dropout(dense(attention(x))) + x) of one stream as ONE autograd node and ONE native call per direction
+    (mmhip_op_self_att_block_fwd / _bwd: fused Q/K/V GEMM, attention, output GEMM with bias + hash dropout + residual in its epilogue,
+    LayerNorm; backward: LayerNorm backward emitting the dropout-backward copy, two input-gradient GEMMs, attention backward)"""
 
     @staticmethod
     def forward(ctx, x, maskbias, wq, bq, wk, bk, wv, bv, wo, bo, g, b, posts, S, heads, p_att, p_hid, seed, eps, oc):
         M, H = x.shape
-        lib = _lib.lib()
-        qkv = torch.empty(M, 3 * H, dtype=oc.tdt, device=x.device)
-        _gemm(oc, x, oc.weight_cat((wq, wk, wv)), H, qkv, M, 3 * H, H, bias=torch.cat([bq.detach(), bk.detach(), bv.detach()]))
-        att = torch.empty(M, H, dtype=oc.tdt, device=x.device)
-        lse = torch.empty(posts * heads * S, dtype=torch.float32, device=x.device)
-        _lib.check(lib.mmhip_op_attn_fwd(oc.code, _p(qkv), _p(maskbias), _p(att), _p(lse), posts, S, heads, p_att, seed, 7, _s()), "attn_fwd")
-        d = torch.empty(M, H, dtype=oc.tdt, device=x.device)
-        _gemm(oc, att, oc.weight(wo), H, d, M, H, H, bias=bo.detach())
-        keep = _drop_mask(d, p_hid)
-        pre = (d * keep if keep is not None else d) + x
-        y = torch.empty_like(pre)
-        mean = torch.empty(M, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-        _lib.check(lib.mmhip_op_layernorm_fwd(oc.code, _p(pre), _p(y), _p(g), _p(b), _p(mean), _p(rstd), M, H, eps, _s()), "ln_fwd")
+        e = lambda *shape: torch.empty(*shape, dtype=oc.tdt, device=x.device)
+        f = lambda n: torch.empty(n, dtype=torch.float32, device=x.device)
+        qkv, att, pre, y, lse, mean, rstd = e(M, 3 * H), e(M, H), e(M, H), e(M, H), f(posts * heads * S), f(M), f(M)
+        _lib.check(_lib.lib().mmhip_op_self_att_block_fwd(oc.code, _p(x), _p(maskbias), _p(oc.weight_cat((wq, wk, wv))), _p(oc.bias_cat((bq, bk, bv))),
+                                                          _p(oc.weight(wo)), _p(bo), _p(g), _p(b), eps, posts, S, heads, p_att, p_hid, seed,
+                                                          _p(qkv), _p(att), _p(lse), _p(pre), _p(mean), _p(rstd), _p(y), _s()), "self_att_block_fwd")
         ctx.save_for_backward(x, maskbias, qkv, att, lse, pre, mean, rstd)
-        ctx.keep, ctx.params, ctx.cfg = keep, (wq, bq, wk, bk, wv, bv, wo, bo, g, b), (posts, S, heads, p_att, seed, oc)
+        ctx.params, ctx.cfg = (wq, bq, wk, bk, wv, bv, wo, bo, g, b), (posts, S, heads, p_att, p_hid, seed, oc)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, maskbias, qkv, att, lse, pre, mean, rstd = ctx.saved_tensors
         wq, bq, wk, bk, wv, bv, wo, bo, g, b = ctx.params
-        posts, S, heads, p_att, seed, oc = ctx.cfg
-        lib, gv = _lib.lib(), oc.gview
+        posts, S, heads, p_att, p_hid, seed, oc = ctx.cfg
+        gv = oc.gview
         M, H = x.shape
-        dy = dy.contiguous()
-        dpre = torch.empty_like(pre)
-        _lib.check(lib.mmhip_op_layernorm_bwd(oc.code, _p(dy), _p(pre), _p(g), _p(mean), _p(rstd), _p(dpre), None, _p(gv[id(g)]), _p(gv[id(b)]), M, H, _s()), "ln_bwd")
-        dd = dpre * ctx.keep if ctx.keep is not None else dpre
-        datt = torch.empty(M, H, dtype=oc.tdt, device=x.device)
-        _gemm(oc, dd, oc.weight(wo, True), H, datt, M, H, H)
+        e = lambda *shape: torch.empty(*shape, dtype=oc.tdt, device=x.device)
+        dpre, datt, dqkv, dx = e(M, H), e(M, H), e(M, 3 * H), e(M, H)
+        dd = e(M, H) if p_hid > 0 else dpre
+        _lib.check(_lib.lib().mmhip_op_self_att_block_bwd(oc.code, _p(dy.contiguous()), _p(maskbias), _p(oc.weight_cat((wq, wk, wv), True)), _p(oc.weight(wo, True)),
+                                                          _p(g), posts, S, heads, p_att, p_hid, seed, _p(qkv), _p(att), _p(lse), _p(pre), _p(mean), _p(rstd),
+                                                          _p(gv[id(g)]), _p(gv[id(b)]), _p(dpre), _p(dd), _p(datt), _p(dqkv), _p(dx), _s()), "self_att_block_bwd")
         oc.tn(dd, att, gv[id(wo)], gv[id(bo)], M, H, H)
-        dqkv = torch.empty_like(qkv)
-        _lib.check(lib.mmhip_op_attn_bwd(oc.code, _p(qkv), _p(maskbias), _p(att), _p(datt), _p(lse), _p(dqkv), posts, S, heads, p_att, seed, 7, _s()), "attn_bwd")
-        dx = torch.empty(M, H, dtype=oc.tdt, device=x.device)
-        _gemm(oc, dqkv, oc.weight_cat((wq, wk, wv), True), 3 * H, dx, M, H, 3 * H)
         for i, (w, bb) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
             oc.tn(dqkv, x, gv[id(w)], gv[id(bb)], M, H, H, lda=3 * H, a_ptr=dqkv.data_ptr() + i * H * dqkv.element_size())
-        dx = dx + dpre
         return (dx,) + (None,) * 19
 
 
 class _FFNBlock(torch.autograd.Function):
-    """LayerNorm(dropout(W2 GELU(W1 x + b1) + b2) + x) as ONE autograd node (GELU + stash and gelu' in the GEMM epilogues)"""
+    """LayerNorm(dropout(W2 GELU(W1 x + b1) + b2) + x) as ONE autograd node and ONE native call per direction (mmhip_op_ffn_block_fwd / _bwd)"""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, g, b, p_hid, eps, oc):
+    def forward(ctx, x, w1, b1, w2, b2, g, b, p_hid, seed, eps, oc):
         M, H = x.shape
         I = w1.shape[0]
-        lib = _lib.lib()
-        h = torch.empty(M, I, dtype=oc.tdt, device=x.device)
-        u = torch.empty(M, I, dtype=oc.tdt, device=x.device)
-        _gemm(oc, x, oc.weight(w1), H, h, M, I, H, bias=b1.detach(), act=1, aux=u)
-        d = torch.empty(M, H, dtype=oc.tdt, device=x.device)
-        _gemm(oc, h, oc.weight(w2), I, d, M, H, I, bias=b2.detach())
-        keep = _drop_mask(d, p_hid)
-        pre = (d * keep if keep is not None else d) + x
-        y = torch.empty_like(pre)
-        mean = torch.empty(M, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-        _lib.check(lib.mmhip_op_layernorm_fwd(oc.code, _p(pre), _p(y), _p(g), _p(b), _p(mean), _p(rstd), M, H, eps, _s()), "ln_fwd")
+        e = lambda *shape: torch.empty(*shape, dtype=oc.tdt, device=x.device)
+        f = lambda n: torch.empty(n, dtype=torch.float32, device=x.device)
+        h, u, pre, y, mean, rstd = e(M, I), e(M, I), e(M, H), e(M, H), f(M), f(M)
+        _lib.check(_lib.lib().mmhip_op_ffn_block_fwd(oc.code, _p(x), _p(oc.weight(w1)), _p(b1), _p(oc.weight(w2)), _p(b2), _p(g), _p(b), eps, M, H, I, p_hid, seed,
+                                                     _p(h), _p(u), _p(pre), _p(mean), _p(rstd), _p(y), _s()), "ffn_block_fwd")
         ctx.save_for_backward(x, h, u, pre, mean, rstd)
-        ctx.keep, ctx.params, ctx.oc = keep, (w1, b1, w2, b2, g, b), oc
+        ctx.params, ctx.cfg = (w1, b1, w2, b2, g, b), (p_hid, seed, oc)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, h, u, pre, mean, rstd = ctx.saved_tensors
         w1, b1, w2, b2, g, b = ctx.params
-        oc = ctx.oc
-        lib, gv = _lib.lib(), oc.gview
+        p_hid, seed, oc = ctx.cfg
+        gv = oc.gview
         M, H = x.shape
         I = w1.shape[0]
-        dy = dy.contiguous()
-        dpre = torch.empty_like(pre)
-        _lib.check(lib.mmhip_op_layernorm_bwd(oc.code, _p(dy), _p(pre), _p(g), _p(mean), _p(rstd), _p(dpre), None, _p(gv[id(g)]), _p(gv[id(b)]), M, H, _s()), "ln_bwd")
-        dd = dpre * ctx.keep if ctx.keep is not None else dpre
-        du = torch.empty(M, I, dtype=oc.tdt, device=x.device)
-        _gemm(oc, dd, oc.weight(w2, True), H, du, M, I, H, mulg=u)
-        dx = torch.empty(M, H, dtype=oc.tdt, device=x.device)
-        _gemm(oc, du, oc.weight(w1, True), I, dx, M, H, I)
+        e = lambda *shape: torch.empty(*shape, dtype=oc.tdt, device=x.device)
+        dpre, du, dx = e(M, H), e(M, I), e(M, H)
+        dd = e(M, H) if p_hid > 0 else dpre
+        _lib.check(_lib.lib().mmhip_op_ffn_block_bwd(oc.code, _p(dy.contiguous()), _p(oc.weight(w1, True)), _p(oc.weight(w2, True)), _p(g), M, H, I, p_hid, seed,
+                                                     _p(u), _p(pre), _p(mean), _p(rstd), _p(gv[id(g)]), _p(gv[id(b)]), _p(dpre), _p(dd), _p(du), _p(dx), _s()),
+                   "ffn_block_bwd")
         oc.tn(dd, h, gv[id(w2)], gv[id(b2)], M, H, I)
         oc.tn(du, x, gv[id(w1)], gv[id(b1)], M, I, H)
-        return (dx + dpre,) + (None,) * 9
-
+        return (dx,) + (None,) * 10
 
 class _Node(nn.Module):
     pass
@@ -572,7 +548,7 @@ class Lxmert(nn.Module):
             return _SelfAttBlock.apply(x.contiguous(), ctx_bias.contiguous(), P(q + "query.weight"), P(q + "query.bias"), P(q + "key.weight"), P(q + "key.bias"),
                                        P(q + "value.weight"), P(q + "value.bias"), P(n + ".output.dense.weight"), P(n + ".output.dense.bias"),
                                        P(n + ".output.LayerNorm.weight"), P(n + ".output.LayerNorm.bias"), B, Sq, a["heads"], p_att,
-                                       a["p_hidden"] if self.training else 0.0, self.oc.next_seed() if p_att > 0 else 0, a["ln_eps"], self.oc)
+                                       a["p_hidden"] if self.training else 0.0, self.oc.next_seed() if self.training else 0, a["ln_eps"], self.oc)
         a = self._attend(x, ctx, ctx_bias, f"{n}.{inner}", B, Sq, Sk)
         return self._ln(self._drop(self._lin(a, n + ".output.dense"), self.arch["p_hidden"]) + x, n + ".output.LayerNorm")
 
@@ -580,7 +556,8 @@ class Lxmert(nn.Module):
         if os.environ.get("MMHIP_EARLY_FUSED", "1") != "0":
             P = self._P
             return _FFNBlock.apply(x.contiguous(), P(i_ + ".dense.weight"), P(i_ + ".dense.bias"), P(o_ + ".dense.weight"), P(o_ + ".dense.bias"),
-                                   P(o_ + ".LayerNorm.weight"), P(o_ + ".LayerNorm.bias"), self.arch["p_hidden"] if self.training else 0.0, self.arch["ln_eps"], self.oc)
+                                   P(o_ + ".LayerNorm.weight"), P(o_ + ".LayerNorm.bias"), self.arch["p_hidden"] if self.training else 0.0,
+                                   self.oc.next_seed() if self.training else 0, self.arch["ln_eps"], self.oc)
         y = _FFN.apply(x.contiguous(), self._P(i_ + ".dense.weight"), self._P(i_ + ".dense.bias"), self._P(o_ + ".dense.weight"), self._P(o_ + ".dense.bias"), self.oc)
         return self._ln(self._drop(y, self.arch["p_hidden"]) + x, o_ + ".LayerNorm")
 
