@@ -223,6 +223,10 @@ typedef struct mmhip_tn_problem {
     float* colsum;
 } mmhip_tn_problem;
 int mmhip_op_gemm_tn_group(int dtype, const mmhip_tn_problem* problems, int count, int accumulate, void* stream);
+/* refresh of many weight copies in few launches: dst = cast(src) [rows, cols] and (dst_t may be NULL) dst_t = cast(src)^T [cols, rows], every fp32
+ * 64 x 64 tile read once; rows, cols multiples of 4 */
+typedef struct mmhip_cast_mat { const float* src; void* dst; void* dst_t; int32_t rows, cols; } mmhip_cast_mat;
+int mmhip_op_cast_group(int dtype, const mmhip_cast_mat* mats, int count, void* stream);
 /* composite operators of the early-fusion path: one post-LN sub-block of a BERT-shaped stream per call, on caller-owned buffers
  * (activation-typed [rows, width] matrices; weights as the activation-typed copies, `*T` = transposed copies [K_in, N_out] for the
  * input gradients).  Self-attention block:  y = LayerNorm(dropout(att Wo^T + bo) + x), att = softmax(Q K^T / 8 + maskbias) V,

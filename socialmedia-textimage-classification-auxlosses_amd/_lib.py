@@ -34,6 +34,10 @@ class TNProblem(C.Structure):        # include/mmhip.h: mmhip_tn_problem
                 ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("colsum", C.c_void_p)]
 
 
+class CastMat(C.Structure):          # include/mmhip.h: mmhip_cast_mat
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
 class MMHipError(RuntimeError):
     pass
 
@@ -77,6 +81,7 @@ _SIGS = {
     "mmhip_op_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, P, I, F, U64, U32, P, I, I, I, P]),
     "mmhip_op_gemm_tn": (I, [I, P, I, P, I, P, I, I, I, I, I, I, P, P]),
     "mmhip_op_gemm_tn_group": (I, [I, P, I, I, P]),
+    "mmhip_op_cast_group": (I, [I, P, I, P]),
     "mmhip_op_self_att_block_fwd": (I, [I, P, P, P, P, P, P, P, P, F, I, I, I, F, F, U64, P, P, P, P, P, P, P, P]),
     "mmhip_op_self_att_block_bwd": (I, [I, P, P, P, P, P, I, I, I, F, F, U64, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "mmhip_op_ffn_block_fwd": (I, [I, P, P, P, P, P, P, P, F, I, I, I, F, U64, P, P, P, P, P, P, P]),

@@ -129,6 +129,20 @@ int mmhip_op_gemm_tn_group(int dtype, const mmhip_tn_problem* problems, int coun
     return 0;
 }
 
+int mmhip_op_cast_group(int dtype, const mmhip_cast_mat* mats, int count, void* stream) {
+    if (!mats || count < 0 || (dtype != MMHIP_BF16 && dtype != MMHIP_F16 && dtype != MMHIP_F32)) return MMHIP_E_INVALID;
+    CastMat g[CAST_MAX_GROUP];
+    for (int i = 0; i < count;) {
+        int n = 0;
+        for (; n < CAST_MAX_GROUP && i < count; ++n, ++i) {
+            if (!mats[i].src || !mats[i].dst || mats[i].rows < 4 || mats[i].cols < 4) return MMHIP_E_INVALID;
+            g[n] = CastMat{mats[i].src, mats[i].dst, mats[i].dst_t, mats[i].rows, mats[i].cols, 0};
+        }
+        CHECK_HIP(launch_cast_group(g, n, dtype, (hipStream_t)stream));
+    }
+    return 0;
+}
+
 // ---- composite operators: one post-LN sub-block of a BERT-shaped stream per call (the early-fusion path's host time is launch
 // and interpreter work: a block is 3-4 launches of the same kernels, enqueued from C++)
 namespace {

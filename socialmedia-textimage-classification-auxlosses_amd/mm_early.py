@@ -60,6 +60,7 @@ class _Ctx:
         self.calls = 0
         self.seed = 0x5DEECE66D
         self.gview = {}            # id(parameter) -> its slice of the flat gradient buffer: the operators accumulate there directly
+        self.persistent = {}       # id(parameter) or tuple of ids (fused Q/K/V) -> (copy, transposed copy) refreshed once per step
         self.tn_queue = []         # weight-gradient products of the running backward pass (dy, x, C, colsum, M, Nn, Nc, lda, A address)
 
     def tn(self, dy, x, gw, gb, M, Nn, Nc, lda=None, a_ptr=None):
@@ -78,7 +79,11 @@ class _Ctx:
         self.tn_queue = []
 
     def weight(self, w, transpose=False):
-        """activation-typed copy of an fp32 [N,K] weight ([K,N] when transpose), refreshed when the parameter changed"""
+        """activation-typed copy of an fp32 [N,K] weight ([K,N] when transpose): the persistent copy (Lxmert.refresh_weights, one grouped
+        launch per step) when the matrix has one, else cast on demand and cached by parameter version"""
+        pers = self.persistent.get(id(w))
+        if pers is not None:
+            return pers[1 if transpose else 0]
         key = (id(w), transpose)
         hit = self.cache.get(key)
         if hit is not None and hit[0] == w._version:
@@ -94,6 +99,9 @@ class _Ctx:
 
     def weight_cat(self, ws, transpose=False):
         """activation-typed copy of the row-wise concatenation of fp32 [N_i, K] weights (fused Q / K / V projection)"""
+        pers = self.persistent.get(tuple(id(w) for w in ws))
+        if pers is not None:
+            return pers[1 if transpose else 0]
         key = (tuple(id(w) for w in ws), transpose)
         ver = tuple(w._version for w in ws)
         hit = self.cache.get(key)
@@ -110,6 +118,9 @@ class _Ctx:
         return out
 
     def bias_cat(self, bs):
+        pers = self.persistent.get(("b",) + tuple(id(b) for b in bs))
+        if pers is not None:
+            return pers
         key = ("b",) + tuple(id(b) for b in bs)
         ver = tuple(b._version for b in bs)
         hit = self.cache.get(key)
@@ -368,8 +379,21 @@ class Lxmert(nn.Module):
         shapes = self.param_shapes(a, num_labels)
         # one flat fp32 buffer for the parameters, one for the gradients (every parameter 16-byte aligned): AdamW is a few launches
         # over flat ranges, and the operators add weight gradients straight into the gradient slices
+        order, seen = [], set()
+        for name in shapes:                                   # Q / K / V weights (and biases) of a block adjacent: [Wq; Wk; Wv] is a VIEW of the flat buffer
+            if name in seen:
+                continue
+            if name.endswith(".query.weight"):
+                stem = name[: -len("query.weight")]
+                group = [stem + "query.weight", stem + "key.weight", stem + "value.weight", stem + "query.bias", stem + "key.bias", stem + "value.bias"]
+                order += group
+                seen.update(group)
+            else:
+                order.append(name)
+                seen.add(name)
         offs, total = {}, 0
-        for name, shape in shapes.items():
+        for name in order:
+            shape = shapes[name]
             offs[name] = total
             total += (int(np.prod(shape, dtype=np.int64)) if shape else 1) + 3 & ~3
         self._flat = torch.zeros(total, dtype=torch.float32, device=self.device_)
@@ -394,8 +418,54 @@ class Lxmert(nn.Module):
                 node = node._modules[part]
             node.register_parameter(parts[-1], nn.Parameter(view))
         self._attach_grads()
+        self._build_persistent()
         if model_dir and os.path.isdir(model_dir):
             self._load_hf(model_dir)
+
+    def _build_persistent(self):
+        """activation-typed copy + transposed copy of every weight matrix (and of the fused [Wq; Wk; Wv] views), refreshed by ONE grouped
+        native call per step instead of ~230 cast launches"""
+        oc, H = self.oc, self.arch["hidden"]
+        named = dict(self.named_parameters())
+        mats = []
+
+        def add(key, src):
+            N, K = src.shape
+            if N % 4 or K % 4:
+                return
+            dst = torch.empty(N, K, dtype=oc.tdt, device=src.device)
+            dst_t = torch.empty(K, N, dtype=oc.tdt, device=src.device)
+            oc.persistent[key] = (dst, dst_t)
+            mats.append((src, dst, dst_t))
+
+        for name, p in named.items():
+            if p.dim() == 2 and "embeddings" not in name:
+                add(id(p), p.detach())
+            if name.endswith(".query.weight"):
+                stem = name[: -len("query.weight")]
+                trio = (named[stem + "query.weight"], named[stem + "key.weight"], named[stem + "value.weight"])
+                o = self._offs[name]
+                add(tuple(id(t) for t in trio), self._flat[o: o + 3 * H * H].view(3 * H, H))
+                ob = self._offs[stem + "query.bias"]
+                oc.persistent[("b",) + tuple(id(named[stem + n]) for n in ("query.bias", "key.bias", "value.bias"))] = self._flat[ob: ob + 3 * H]
+        arr = (_lib.CastMat * len(mats))()
+        for i, (src, dst, dst_t) in enumerate(mats):
+            arr[i] = _lib.CastMat(src.data_ptr(), dst.data_ptr(), dst_t.data_ptr(), src.shape[0], src.shape[1])
+        self._cast_arr, self._cast_keep, self._wsig = arr, mats, None
+
+    def refresh_weights(self, force=False):
+        sig = sum(p._version for p in self._pcache_list())
+        if force or sig != self._wsig:
+            _lib.check(_lib.lib().mmhip_op_cast_group(self.oc.code, C.cast(self._cast_arr, C.c_void_p), len(self._cast_keep), _s()), "cast_group")
+            self.oc.cache.clear()
+            self._wsig = sig
+
+    def _pcache_list(self):
+        try:
+            return self._plist
+        except AttributeError:
+            object.__setattr__(self, "_plist", list(self.parameters()))
+            return self._plist
 
     def _attach_grads(self):
         """every parameter's .grad is its slice of the flat gradient buffer (autograd accumulates in place for the few parameters torch ops
@@ -599,6 +669,7 @@ class Lxmert(nn.Module):
         """reference :121-163 -> (linear_output, max_embeddings_t, max_embeddings_v, out_tim), fp32"""
         dev = self.device_
         _refresh_stream()
+        self.refresh_weights()
         ids, mask = ids.to(dev), mask.to(dev)
         tt = None if token_type_ids is None else token_type_ids.to(dev)
         features, boxes = features.to(dev, torch.float32), normalized_boxes.to(dev, torch.float32)
@@ -692,7 +763,8 @@ class MMEarly_Model(object):
         for b, e in m.grad_ranges(self.use_clip_loss, self.use_tim_loss):
             _lib.check(lib.mmhip_adamw(at(m._flat, b), at(m._flat_grad, b), at(self._opt[0], b), at(self._opt[1], b), e - b, lr, 0.9, 0.999, 1e-8,
                                        weight_decay, step, 1.0 / world, 1, _s()), "adamw")  # zero_grad fused: the slices are clean for the next step
-        m.oc.cache.clear()                                     # the kernels updated the weights through raw pointers: drop the 16-bit copies
+        m._wsig = None                                         # the kernels updated the weights through raw pointers: the copies are refreshed by the next forward
+        m.oc.cache.clear()
         return loss.detach()
 
     def load_saved_model(self, model_path):
