@@ -237,6 +237,22 @@ def main():
     # ---- extra: forward+backward only (no optimizer / refresh), same batch
     lib, m = _lib.lib(), trainer.model
     sync()
+    # phase ends inside a step (HIP events on the phases' own streams, no profiler): image tower | text tower | forward | backward | step
+    import ctypes as Ct
+    spans = None
+    if world == 1 and hasattr(lib, "mmhip_step_spans"):
+        acc = []
+        _lib.check(lib.mmhip_step_spans(m._handle, 1, None))
+        for _ in range(4):
+            step_no += 1
+            trainer.train_step(ids, mask, pixels, onehot, None, lr, wd, step_no)
+            buf = (Ct.c_float * 5)()
+            _lib.check(lib.mmhip_step_spans(m._handle, 1, buf))
+            acc.append(list(buf))
+        _lib.check(lib.mmhip_step_spans(m._handle, 0, None))
+        acc = sorted(acc[1:], key=lambda r: r[4])[len(acc[1:]) // 2]
+        spans = dict(zip(["image_tower_end", "text_tower_end", "forward_end", "backward_end", "step_end"], (round(x, 3) for x in acc)))
+    sync()
     t1 = time.perf_counter()
     nfb = max(3, args.steps // 4)
     for _ in range(nfb):
@@ -254,8 +270,6 @@ def main():
     # ---- roofline of the dominant kernel (MFMA NT GEMM): HIP events around every launch, on the stream it is launched on.
     # Two passes: side streams ON (the conditions of the timed step: a launch may share the chip with the other tower or with
     # the weight-gradient GEMM -- this is `frac`) and side streams OFF (every kernel alone on the chip: `frac_serial`).
-    import ctypes as Ct
-
     def gemm_pass(mode):
         nonlocal step_no
         _lib.check(lib.mmhip_gemm_timing(m._handle, mode, 1, None, None, None))
@@ -318,7 +332,7 @@ def main():
         "host_enqueue_ms_per_step": round(host_ms, 3), "fwd_bwd_ms": round(fb_ms, 3), "fwd_bwd_posts_per_s": round(world * B / (fb_ms * 1e-3), 1),
         "model_tflops": round(posts_s * GF_PER_POST[mode] / 1e3, 1),
         "model_frac_of_peak": round(posts_s / world * GF_PER_POST[mode] / 1e3 / PEAK_TFLOPS, 4),
-        "final_loss": round(final_loss, 5), "roofline": roofline,
+        "final_loss": round(final_loss, 5), "spans_ms": spans, "roofline": roofline,
         "parity": {"metric": PARITY["metric"], "north_star_tolerance": PARITY["north_star_tolerance"], "source": PARITY["source"],
                    "this_dtype": PARITY[args.dtype], "parity_mode_bf16x3": PARITY["bf16x3"]},
     }

@@ -172,6 +172,12 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, float* loss,
                      int* n_correct, void* stream);
 
+/* Debug: phase ends of the last forward / train step, in milliseconds after the forward's fork, from HIP events recorded on the
+ * streams the phases run on (no profiler in the way): ms[0] image tower end, [1] text tower end, [2] forward end, [3] backward
+ * end, [4] step end; -1 = not recorded.  enable != 0 arms the events for the steps that follow.  Synchronises the device.
+ * No reference counterpart (run_mm_late.py times whole epochs only, models/mm_late.py:424-430). */
+int mmhip_step_spans(mmhip_handle h, int enable, float* ms);
+
 /* ---- timing of the dominant kernel for bench.py: HIP events recorded around every MFMA NT-GEMM launch issued by the
  * handle, on the stream the launch goes to, while enabled; returns accumulated milliseconds, launches and algorithmic FLOPs
  * since reset.  enable = 1: the engine keeps its internal side streams (the conditions of a normal step: a launch may share

@@ -288,7 +288,128 @@ class Dropout:
 # --------------------------------------------------------------------------------------
 # encoders
 # --------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------
+# rounding emulation: the 16-bit HIP modes round BOTH operands of every matrix product to bf16 / f16,
+# accumulate in fp32 and round every activation they STORE between kernels (and, in the backward, every stored gradient).
+# `with rounding("bf16"):` makes this restatement do the same at the same places, so that a 16-bit HIP path can be compared
+# against an execution with its own rounding policy (expected agreement: the noise of single rounding decisions) instead of
+# against fp32 through a band wide enough for twelve layers of operand rounding.  Policy None = exact fp32 (the pinned oracle).
+#   stored activation   _q   forward: round            backward: round the gradient (it is stored in 16 bits too)
+#   MFMA operand only   _qo  forward: round            backward: identity          (softmax weights P; weights via _qw)
+#   gradient operand    _qg  forward: identity         backward: round             (dS, an operand of the dQ / dK products)
+# f16 carries text-tower gradients multiplied by `loss_scale` (engine.hip gscale(): 1024) -- range, not precision.
+# --------------------------------------------------------------------------------------
+class _Policy:
+    # what is rounded, each one of None (fp32) | "bf16" | "f16" | "bf16x2" (hi + lo bf16 pair = 16 significant bits):
+    op_a = None       # activation operand of a matrix product
+    op_w = None       # weight operand
+    st_act = None     # stored activations (qkv, ctx, FC1 output and stash) and stored gradients
+    st_resid = None   # stored residual-stream tensors: LayerNorm INPUTS (pre1, pre2), the image tower's x
+    st_ln = None      # stored LayerNorm OUTPUTS (x of the next layer, a1)
+    loss_scale = 1.0
+
+
+_POLICY = _Policy()
+_FIELDS = ("op_a", "op_w", "st_act", "st_resid", "st_ln")
+
+
+class rounding:
+    """context manager: `with rounding("bf16" | "f16" | None, loss_scale=..., **overrides)`; overrides name single fields of the
+    policy (op_a, op_w, st_act, st_resid, st_ln) for the numerics study of tools/numerics_study.py."""
+
+    def __init__(self, round_operands: Optional[str] = None, loss_scale: Optional[float] = None, **over):
+        base = None if round_operands in (None, "none", "fp32") else round_operands
+        self.new = {k: over.get(k, base) for k in _FIELDS}
+        any16 = any(v == "f16" for v in self.new.values())
+        self.new["loss_scale"] = loss_scale if loss_scale is not None else (1024.0 if any16 else 1.0)
+
+    def __enter__(self):
+        self.prev = {k: getattr(_POLICY, k) for k in _FIELDS + ("loss_scale",)}
+        for k, v in self.new.items():
+            setattr(_POLICY, k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            setattr(_POLICY, k, v)
+        return False
+
+
+def _rnd(x: Tensor, kind: str) -> Tensor:
+    if kind == "bf16":
+        return x.to(torch.bfloat16).to(torch.float32)
+    if kind == "f16":
+        return x.to(torch.float16).to(torch.float32)
+    if kind == "bf16x2":
+        hi = x.to(torch.bfloat16).to(torch.float32)
+        return hi + (x - hi).to(torch.bfloat16).to(torch.float32)
+    raise ValueError(kind)
+
+
+class _RoundFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind, fwd, bwd, gs):
+        ctx.kind, ctx.bwd, ctx.gs = kind, bwd, gs
+        return _rnd(x, kind) if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.bwd:
+            g = _rnd(g * ctx.gs, ctx.kind) / ctx.gs
+        return g, None, None, None, None
+
+
+def _q(x: Tensor, where: str = "act") -> Tensor:
+    """a tensor the 16-bit path stores between kernels (where: act | resid | ln); its gradient is stored the same way"""
+    kind = getattr(_POLICY, "st_" + where)
+    return x if kind is None else _RoundFn.apply(x, kind, True, True, _POLICY.loss_scale)
+
+
+def _qo(x: Tensor) -> Tensor:
+    return x if _POLICY.op_a is None else _RoundFn.apply(x, _POLICY.op_a, True, False, 1.0)
+
+
+def _qg(x: Tensor) -> Tensor:
+    return x if _POLICY.op_a is None else _RoundFn.apply(x, _POLICY.op_a, False, True, _POLICY.loss_scale)
+
+
+def _qw(w: Tensor) -> Tensor:
+    """weight as a 16-bit GEMM operand: the fp32 master receives the unrounded fp32 weight gradient."""
+    return w if _POLICY.op_w is None else _RoundFn.apply(w, _POLICY.op_w, True, False, 1.0)
+
+
+class _GeluStash(torch.autograd.Function):
+    """FC1 epilogue of the 16-bit modes: h = gelu(v) on the fp32 accumulator value; the backward multiplies by gelu'(u) of the
+    STORED (rounded) pre-activation u (gemm8.hip EP_GELU / EP_MULG)."""
+
+    @staticmethod
+    def forward(ctx, v, kind):
+        ctx.save_for_backward(_rnd(v, kind))
+        return F.gelu(v)
+
+    @staticmethod
+    def backward(ctx, g):
+        (u,) = ctx.saved_tensors
+        cdf = 0.5 * (1.0 + torch.erf(u * (2.0 ** -0.5)))
+        pdf = torch.exp(-0.5 * u * u) * (1.0 / math.sqrt(2.0 * math.pi))
+        return g * (cdf + u * pdf), None
+
+
+def _gelu(v: Tensor) -> Tensor:
+    return F.gelu(v) if _POLICY.st_act is None else _GeluStash.apply(v, _POLICY.st_act)
+
+
+# --------------------------------------------------------------------------------------
+# encoders
+# --------------------------------------------------------------------------------------
 def _lin(x: Tensor, P: Dict[str, Tensor], name: str) -> Tensor:
+    """Linear inside a tower: 16-bit operands under a rounding policy (fp32 accumulate, fp32 bias); the caller rounds the result
+    where the HIP path stores it."""
+    return F.linear(_qo(x), _qw(P[name + ".weight"]), P.get(name + ".bias"))
+
+
+def _lin32(x: Tensor, P: Dict[str, Tensor], name: str) -> Tensor:
+    """Linear of the heads: fp32 in every mode (heads.hip small_gemm on v_mfma_f32_32x32x2_f32)."""
     return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
 
 
@@ -301,6 +422,16 @@ def _heads(x: Tensor, nh: int) -> Tensor:
     return x.view(B, S, nh, H // nh).permute(0, 2, 1, 3)
 
 
+def _attend(q: Tensor, k: Tensor, v: Tensor, scale: float, bias: Optional[Tensor], dropf) -> Tensor:
+    """softmax(q k^T * scale + bias) v per head; under a rounding policy q, k, v arrive rounded (stored qkv), the dropped softmax
+    weights are rounded as the P.V operand and dS as the operand of the dQ / dK products (attention.hip)."""
+    s = _qg(q @ k.transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias
+    a = dropf(torch.softmax(s, dim=-1))
+    return _qo(a) @ v
+
+
 def vit_forward(P: Dict[str, Tensor], pixels: Tensor, cfg: OracleConfig,
                 collect: Optional[list] = None) -> Tuple[Tensor, Tensor]:
     """HF:models/vit/modeling_vit.py:373-388 (ViTModel.forward); all dropouts are 0.0."""
@@ -309,26 +440,26 @@ def vit_forward(P: Dict[str, Tensor], pixels: Tensor, cfg: OracleConfig,
     B = pixels.shape[0]
     w = P[vm + "embeddings.patch_embeddings.projection.weight"]
     b = P[vm + "embeddings.patch_embeddings.projection.bias"]
-    x = F.conv2d(pixels, w, b, stride=cfg.patch).flatten(2).transpose(1, 2)           # :60,69
-    x = torch.cat([P[vm + "embeddings.cls_token"].expand(B, -1, -1), x], dim=1)        # :146-150
-    x = x + P[vm + "embeddings.position_embeddings"]                                   # :153-155
+    x = F.conv2d(_qo(pixels), _qw(w), b, stride=cfg.patch).flatten(2).transpose(1, 2)  # :60,69
+    x = torch.cat([P[vm + "embeddings.cls_token"].expand(B, -1, -1), _q(x)], dim=1)    # :146-150
+    x = _q(x + P[vm + "embeddings.position_embeddings"], "resid")                               # :153-155
     scale = (cfg.hidden // cfg.heads) ** -0.5
+    ident = lambda a: a
     for l in range(cfg.layers_img):
         p = f"{vm}encoder.layer.{l}."
-        h = _ln(x, P, p + "layernorm_before", cfg.ln_eps_img)                           # :274
-        q = _heads(_lin(h, P, p + "attention.attention.query"), cfg.heads)              # :216-218
-        k = _heads(_lin(h, P, p + "attention.attention.key"), cfg.heads)
-        v = _heads(_lin(h, P, p + "attention.attention.value"), cfg.heads)
-        a = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)                      # :164-189
-        c = (a @ v).permute(0, 2, 1, 3).reshape(B, -1, cfg.hidden)
-        x = x + _lin(c, P, p + "attention.output.dense")                                # :236,276-277
-        h = _ln(x, P, p + "layernorm_after", cfg.ln_eps_img)                            # :281
-        h = F.gelu(_lin(h, P, p + "intermediate.dense"))                                # :250-251 (erf)
-        x = x + _lin(h, P, p + "output.dense")                                          # :252,283-284
+        h = _q(_ln(x, P, p + "layernorm_before", cfg.ln_eps_img), "ln")                       # :274
+        q = _heads(_q(_lin(h, P, p + "attention.attention.query")), cfg.heads)          # :216-218
+        k = _heads(_q(_lin(h, P, p + "attention.attention.key")), cfg.heads)
+        v = _heads(_q(_lin(h, P, p + "attention.attention.value")), cfg.heads)
+        c = _q(_attend(q, k, v, scale, None, ident)).permute(0, 2, 1, 3).reshape(B, -1, cfg.hidden)   # :164-189
+        x = _q(x + _lin(c, P, p + "attention.output.dense"), "resid")                            # :236,276-277
+        h = _q(_ln(x, P, p + "layernorm_after", cfg.ln_eps_img), "ln")                        # :281
+        h = _q(_gelu(_lin(h, P, p + "intermediate.dense")))                             # :250-251 (erf)
+        x = _q(x + _lin(h, P, p + "output.dense"), "resid")                                   # :252,283-284
         if collect is not None:
             collect.append(x)
-    x = _ln(x, P, vm + "layernorm", cfg.ln_eps_img)                                     # :385
-    pooled = torch.tanh(_lin(x[:, 0], P, vm + "pooler.dense"))                          # :289-301
+    x = _q(_ln(x, P, vm + "layernorm", cfg.ln_eps_img), "ln")                                 # :385
+    pooled = torch.tanh(_lin32(x[:, 0], P, vm + "pooler.dense"))                        # :289-301
     return x, pooled
 
 
@@ -339,23 +470,23 @@ def clip_vision_forward(P: Dict[str, Tensor], pixels: Tensor, cfg: OracleConfig,
     output as it is, pooler_output = post_layernorm of its CLS row).  -> (last_hidden_state [B,P,Hv], pooler_output [B,Hv])"""
     vm = "dual_encoder.vision_model.vision_model."
     B, Hv, nh = pixels.shape[0], cfg.Hv, cfg.heads_v
-    x = F.conv2d(pixels, P[vm + "embeddings.patch_embedding.weight"], None, stride=cfg.patch).flatten(2).transpose(1, 2)
-    x = torch.cat([P[vm + "embeddings.class_embedding"].expand(B, 1, -1), x], dim=1)
-    x = x + P[vm + "embeddings.position_embedding.weight"]
-    x = _ln(x, P, vm + "pre_layrnorm", cfg.ln_eps_img)
+    x = F.conv2d(_qo(pixels), _qw(P[vm + "embeddings.patch_embedding.weight"]), None, stride=cfg.patch).flatten(2).transpose(1, 2)
+    x = torch.cat([P[vm + "embeddings.class_embedding"].expand(B, 1, -1), _q(x)], dim=1)
+    x = _q(x + P[vm + "embeddings.position_embedding.weight"], "resid")
+    x = _q(_ln(x, P, vm + "pre_layrnorm", cfg.ln_eps_img), "resid")
     scale = (Hv // nh) ** -0.5
+    ident = lambda a: a
     for l in range(cfg.layers_img):
         p = f"{vm}encoder.layers.{l}."
-        h = _ln(x, P, p + "layer_norm1", cfg.ln_eps_img)
-        q = _heads(_lin(h, P, p + "self_attn.q_proj"), nh)
-        k = _heads(_lin(h, P, p + "self_attn.k_proj"), nh)
-        v = _heads(_lin(h, P, p + "self_attn.v_proj"), nh)
-        a = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
-        c = (a @ v).permute(0, 2, 1, 3).reshape(B, -1, Hv)
-        x = x + _lin(c, P, p + "self_attn.out_proj")
-        h = _lin(_ln(x, P, p + "layer_norm2", cfg.ln_eps_img), P, p + "mlp.fc1")
-        h = h * torch.sigmoid(1.702 * h)                                     # quick_gelu
-        x = x + _lin(h, P, p + "mlp.fc2")
+        h = _q(_ln(x, P, p + "layer_norm1", cfg.ln_eps_img), "ln")
+        q = _heads(_q(_lin(h, P, p + "self_attn.q_proj")), nh)
+        k = _heads(_q(_lin(h, P, p + "self_attn.k_proj")), nh)
+        v = _heads(_q(_lin(h, P, p + "self_attn.v_proj")), nh)
+        c = _q(_attend(q, k, v, scale, None, ident)).permute(0, 2, 1, 3).reshape(B, -1, Hv)
+        x = _q(x + _lin(c, P, p + "self_attn.out_proj"), "resid")
+        h = _lin(_q(_ln(x, P, p + "layer_norm2", cfg.ln_eps_img), "ln"), P, p + "mlp.fc1")
+        h = _q(h * torch.sigmoid(1.702 * h))                                 # quick_gelu
+        x = _q(x + _lin(h, P, p + "mlp.fc2"), "resid")
         if collect is not None:
             collect.append(x)
     pooled = _ln(x[:, 0], P, vm + "post_layernorm", cfg.ln_eps_img)
@@ -383,25 +514,24 @@ def text_forward(P: Dict[str, Tensor], ids: Tensor, mask: Tensor, cfg: OracleCon
          + P[tm + "embeddings.token_type_embeddings.weight"][0]
          + P[tm + "embeddings.position_embeddings.weight"][pos])
     x = _ln(x, P, tm + "embeddings.LayerNorm", cfg.ln_eps_txt)
-    x = drop(x, cfg.p_hidden, STREAM_EMBED, post_offset * T * H)
+    x = _q(drop(x, cfg.p_hidden, STREAM_EMBED, post_offset * T * H), "ln")
     bias = (1.0 - mask.to(torch.float32))[:, None, None, :] * torch.finfo(torch.float32).min
     scale = (H // nh) ** -0.5
     for l in range(cfg.layers_txt):
         p = f"{tm}encoder.layer.{l}."
-        q = _heads(_lin(x, P, p + "attention.self.query"), nh)
-        k = _heads(_lin(x, P, p + "attention.self.key"), nh)
-        v = _heads(_lin(x, P, p + "attention.self.value"), nh)
-        a = torch.softmax(q @ k.transpose(-1, -2) * scale + bias, dim=-1)
-        a = drop(a, cfg.p_attn, stream_attn(l), post_offset * nh * T * T)
-        c = (a @ v).permute(0, 2, 1, 3).reshape(B, T, H)
+        q = _heads(_q(_lin(x, P, p + "attention.self.query")), nh)
+        k = _heads(_q(_lin(x, P, p + "attention.self.key")), nh)
+        v = _heads(_q(_lin(x, P, p + "attention.self.value")), nh)
+        dropf = lambda a, l=l: drop(a, cfg.p_attn, stream_attn(l), post_offset * nh * T * T)
+        c = _q(_attend(q, k, v, scale, bias, dropf)).permute(0, 2, 1, 3).reshape(B, T, H)
         o = drop(_lin(c, P, p + "attention.output.dense"), cfg.p_hidden, stream_attn_out(l), post_offset * T * H)
-        a1 = _ln(o + x, P, p + "attention.output.LayerNorm", cfg.ln_eps_txt)
-        h = F.gelu(_lin(a1, P, p + "intermediate.dense"))
+        a1 = _q(_ln(_q(o + x, "resid"), P, p + "attention.output.LayerNorm", cfg.ln_eps_txt), "ln")
+        h = _q(_gelu(_lin(a1, P, p + "intermediate.dense")))
         f = drop(_lin(h, P, p + "output.dense"), cfg.p_hidden, stream_ffn_out(l), post_offset * T * H)
-        x = _ln(f + a1, P, p + "output.LayerNorm", cfg.ln_eps_txt)
+        x = _q(_ln(_q(f + a1, "resid"), P, p + "output.LayerNorm", cfg.ln_eps_txt), "ln")
         if collect is not None:
             collect.append(x)
-    pooled = torch.tanh(_lin(x[:, 0], P, tm + "pooler.dense"))
+    pooled = torch.tanh(_lin32(x[:, 0], P, tm + "pooler.dense"))
     return x, pooled
 
 
@@ -418,15 +548,15 @@ def mm_fusion(P: Dict[str, Tensor], x_t: Tensor, x_v: Tensor, cfg: OracleConfig)
     """reference models/mm_late.py:91-113 + Scaled_Dot_Product_Attention :195-210."""
     if cfg.fusion == "concat":
         z = torch.cat((x_t[:, 0, :], x_v[:, 0, :]), dim=1)
-        return F.relu(_lin(z, P, "linear_fusion"))
+        return F.relu(_lin32(z, P, "linear_fusion"))
     if cfg.fusion == "attention":
         N, L, E = x_t.shape
-        Q, K, V = _lin(x_t, P, "fc_Q"), _lin(x_v, P, "fc_K"), _lin(x_v, P, "fc_V")
+        Q, K, V = _lin32(x_t, P, "fc_Q"), _lin32(x_v, P, "fc_K"), _lin32(x_v, P, "fc_V")
         scale = K.shape[-1] ** -0.5
         att = torch.softmax(Q @ K.permute(0, 2, 1) * scale, dim=-1)
         ctx = (att @ V).view(N, L, E)
         z = torch.cat((x_t[:, 0, :], ctx[:, 0, :]), dim=1)
-        return F.relu(_lin(z, P, "linear_fusion"))
+        return F.relu(_lin32(z, P, "linear_fusion"))
     raise ValueError(cfg.fusion)
 
 
@@ -442,13 +572,13 @@ def mm_forward(P: Dict[str, Tensor], ids: Tensor, mask: Tensor, pixels: Tensor, 
     x_t, t_pool = text_forward(P, ids, mask, cfg, drop, 0, ct)
     logits_per_text = itc_logits(P, t_pool, v_pool)
     feats = mm_fusion(P, x_t, x_v, cfg)
-    out_cls = _lin(drop(feats, cfg.p_head, STREAM_HEAD, 0), P, "linear_cls")
+    out_cls = _lin32(drop(feats, cfg.p_head, STREAM_HEAD, 0), P, "linear_cls")
     out_tim = None
     if tim_inputs is not None:
         tim_ids, tim_mask = tim_inputs
         # second dual-encoder call; the frozen, dropout-free ViT output is identical
         x_t2, _ = text_forward(P, tim_ids, tim_mask, cfg, drop, B, None)
-        out_tim = _lin(mm_fusion(P, x_t2, x_v, cfg), P, "linear_tim")      # no dropout, :181-182
+        out_tim = _lin32(mm_fusion(P, x_t2, x_v, cfg), P, "linear_tim")      # no dropout, :181-182
     return out_cls, logits_per_text, out_tim, None, feats
 
 

@@ -76,6 +76,7 @@ _SIGS = {
     "mmhip_image_plan_build": (I, [I, P, P, P, I, P, U64]),
     "mmhip_image_plan_tmp_bytes": (U64, [P]),
     "mmhip_image_preprocess": (I, [P, P, P, P, P, P, P, P]),
+    "mmhip_step_spans": (I, [P, I, C.POINTER(C.c_float)]),
     "mmhip_gemm_timing": (I, [P, I, I, C.POINTER(C.c_double), C.POINTER(U64), C.POINTER(C.c_double)]),
     "mmhip_gemm_timing_by_shape": (I, [P, C.c_char_p, U64]),
     "mmhip_op_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, P, I, F, U64, U32, P, I, I, I, P]),

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include "mmhip_common.h"
 #include "mmhip_kernels.h"
 #include "../../include/mmhip.h"
@@ -81,6 +82,22 @@ struct mmhip_engine {
     int cls_only = -1;         // -1 = read MMHIP_CLS_ONLY on first use; 1: the last text layer runs its post-attention part on CLS rows only
     bool cls_compact = false;  // state of the last forward
     int overlap = -1;          // -1 = read MMHIP_OVERLAP on first use
+    // CU partition of the forward (MMHIP_PART="txt,vit", e.g. "96,160"; read once): while both towers run side by side their big GEMMs are
+    // persistent 256 x 256-tile launches of at most part[0] (text) / part[1] (image) workgroups.  A workgroup of that kernel holds a CU
+    // (128 KB of LDS), so the two launches split the chip 96 / 160 without CU masks, each tower's GEMMs see a fixed machine (8192 rows x
+    // 2304 / 768 / 3072 columns = 288 / 96 / 384 tiles = 3 / 1 / 4 rounds of 96; 12608 rows = 450 / 150 / 600 tiles = 2.8 / 0.94 / 3.75 rounds
+    // of 160) instead of racing for CUs launch by launch.  cur_part: the caps of the forward being enqueued (0 = off).
+    int part[2] = {-1, -1}, cur_part[2] = {0, 0};
+    // mmhip_step_spans: timing events at the phase ends of the last forward / train step (0 fork, 1 image tower end, 2 text tower end,
+    // 3 forward end, 4 backward end, 5 step end); recorded only while enabled
+    int spans_on = 0; hipEvent_t span_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool span_set[6] = {false, false, false, false, false, false};
+    int span(int i, hipStream_t s) {
+        if (!spans_on) return 0;
+        if (!span_ev[i]) { hipError_t r = hipEventCreate(&span_ev[i]); if (r != hipSuccess) return (int)r; }
+        hipError_t r = hipEventRecord(span_ev[i], s);
+        span_set[i] = r == hipSuccess;
+        return (int)r;
+    }
     // GEMM timing ----------------------------------------------------------------------
     int timing = 0;            // 0 off, 1 = events around every NT GEMM with the side streams on, 2 = side streams off
     struct Ev { hipEvent_t a, b; double flops; int M, N, K, flags, tile; };
@@ -360,6 +377,11 @@ struct G {
     G& mul_gelu_grad(const void* p, int ld) { a.mul_in = p; a.ldmul = ld; a.flags |= GEMM_MUL_GELU_GRAD; return *this; }
     G& dropout(const DropCfg& d, int row_mul = 1) { a.drop = d; a.drop_row_mul = row_mul; if (d.thresh16) a.flags |= GEMM_DROPOUT; return *this; }
 };
+// forward GEMM of tower `which` (0 text, 1 image) under the CU partition: persistent 256 x 256 tiles on at most cur_part[which] workgroups
+inline void part_gemm(const mmhip_engine& e, G& g, int which) {
+    const int n = e.cur_part[which];
+    if (n > 0 && !g.a.tile && g.a.M >= 2048 && g.a.N % 256 == 0 && g.a.K % 64 == 0 && (e.dt() == DT_BF16 || e.dt() == DT_F16)) { g.a.tile = 15; g.a.grid = n; }
+}
 int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
     // CLS-row GEMMs of the last text layer (<= 128 rows, K = 3072): split along K (gemm.hip launch_nt_splitk).  They are issued on
     // the caller's stream only (the image tower's and the weight-gradient GEMMs have thousands of rows): one scratch buffer.
@@ -462,6 +484,7 @@ int vit_forward(mmhip_engine& e, const float* pixels, hipStream_t s) {
     {
         G g(e.ws + e.v_patches, Kpp, e.ws + e.patch_w16, Kpp, e.ws + e.v_pe, H, B * (P - 1), H, Kpp);
         if (!clip) g.bias(F + e.v_patch_b);           // CLIP's patch conv has no bias
+        part_gemm(e, g, 1);
         if (int r = run_gemm(e, g, s)) return r;
     }
     CHECK_HIP(launch_vit_assemble(e.ws + e.v_pe, F + e.v_cls, F + e.v_pos, e.ws + e.v_x, B, P, H, dt, s));
@@ -481,17 +504,17 @@ int vit_forward(mmhip_engine& e, const float* pixels, hipStream_t s) {
         const LayerW16& w = e.vit_w16[l];
         LNArgs ln{x, e.ws + e.v_ln, F + o.ln1_w, F + o.ln1_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
         CHECK_HIP(launch_layernorm_fwd(ln, dt, s));
-        { G g(e.ws + e.v_ln, H, e.ws + w.qkv, H, e.ws + e.v_qkv, 3 * H, Mv, 3 * H, H); g.bias(F + o.qkv_b); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_ln, H, e.ws + w.qkv, H, e.ws + e.v_qkv, 3 * H, Mv, 3 * H, H); g.bias(F + o.qkv_b); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
         AttnArgs at;
         memset(&at, 0, sizeof(at));
         at.qkv = e.ws + e.v_qkv; at.ctx = e.ws + e.v_ctx; at.posts = B; at.S = P; at.heads = e.heads_v(); at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
         at.scale = 1.0f / sqrtf((float)(H / e.heads_v()));
         CHECK_HIP(launch_attn_fwd(at, dt, s));
-        { G g(e.ws + e.v_ctx, H, e.ws + w.ao, H, x, H, Mv, H, H); g.bias(F + o.ao_b).residual(x, H); g.a.tile = narrow_tile; if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_ctx, H, e.ws + w.ao, H, x, H, Mv, H, H); g.bias(F + o.ao_b).residual(x, H); g.a.tile = narrow_tile; part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
         LNArgs ln2{x, e.ws + e.v_ln, F + o.ln2_w, F + o.ln2_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
         CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
-        { G g(e.ws + e.v_ln, H, e.ws + w.fc1, H, e.ws + e.v_h, I, Mv, I, H); g.bias(F + o.fc1_b); if (clip) g.qgelu(); else g.gelu(); if (int r = run_gemm(e, g, s)) return r; }
-        { G g(e.ws + e.v_h, I, e.ws + w.fc2, I, x, H, Mv, H, I); g.bias(F + o.fc2_b).residual(x, H); g.a.tile = narrow_tile; if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_ln, H, e.ws + w.fc1, H, e.ws + e.v_h, I, Mv, I, H); g.bias(F + o.fc1_b); if (clip) g.qgelu(); else g.gelu(); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_h, I, e.ws + w.fc2, I, x, H, Mv, H, I); g.bias(F + o.fc2_b).residual(x, H); g.a.tile = narrow_tile; part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
     }
     if (clip) {
         // last_hidden_state = the encoder output as it is; pooler_output = post_layernorm(CLS row)   (CLIPVisionTransformer.forward)
@@ -530,7 +553,7 @@ int text_forward(mmhip_engine& e, hipStream_t s) {
         const LayerOff& o = e.txt[l];
         const LayerW16& w = e.txt_w16[l];
         const TextAct& a = e.tact[l];
-        { G g(x, H, e.ws + w.qkv, H, e.ws + a.qkv, 3 * H, Mt, 3 * H, H); g.bias(W + o.qkv_b); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(x, H, e.ws + w.qkv, H, e.ws + a.qkv, 3 * H, Mt, 3 * H, H); g.bias(W + o.qkv_b); part_gemm(e, g, 0); if (int r = run_gemm(e, g, s)) return r; }
         // Only the CLS row of the last layer's output is ever consumed (fusion query and pooler, mm_late.py:111,155-158):
         // its attention needs query tile 0 only and everything after it runs on Bt rows (row stride T*H in the full
         // tensors, compact [Bt, .] outputs).  Dropout indices keep the full-tensor numbering (row_mul = T).
@@ -546,12 +569,14 @@ int text_forward(mmhip_engine& e, hipStream_t s) {
         CHECK_HIP(launch_attn_fwd(at, dt, s));
         { G g(e.ws + a.ctx, rs, e.ws + w.ao, H, e.ws + a.pre1, H, Mr, H, H);
           g.bias(W + o.ao_b).dropout(make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr), rmul).residual(x, rs);
+          part_gemm(e, g, 0);
           if (int r = run_gemm(e, g, s)) return r; }
         LNArgs ln1{e.ws + a.pre1, e.ws + a.a1, W + o.ln1_w, W + o.ln1_b, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), Mr, H, H, H, c.ln_eps_txt};
         CHECK_HIP(launch_layernorm_fwd(ln1, dt, s));
-        { G g(e.ws + a.a1, H, e.ws + w.fc1, H, e.ws + a.h, I, Mr, I, H); g.bias(W + o.fc1_b).aux(e.ws + a.u, I).gelu(); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + a.a1, H, e.ws + w.fc1, H, e.ws + a.h, I, Mr, I, H); g.bias(W + o.fc1_b).aux(e.ws + a.u, I).gelu(); part_gemm(e, g, 0); if (int r = run_gemm(e, g, s)) return r; }
         { G g(e.ws + a.h, I, e.ws + w.fc2, I, e.ws + a.pre2, H, Mr, H, I);
           g.bias(W + o.fc2_b).dropout(make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr), rmul).residual(e.ws + a.a1, H);
+          part_gemm(e, g, 0);
           if (int r = run_gemm(e, g, s)) return r; }
         LNArgs ln2{e.ws + a.pre2, e.ws + a.out, W + o.ln2_w, W + o.ln2_b, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), Mr, H, H, H, c.ln_eps_txt};
         CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
@@ -972,6 +997,7 @@ void mmhip_destroy(mmhip_handle h) {
             if (ev) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(h->side);
         for (auto sv : h->side_vit) if (sv) (void)hipStreamDestroy(sv);
+        for (auto ev : h->span_ev) if (ev) (void)hipEventDestroy(ev);
     }
     for (auto& ev : h->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     delete h;
@@ -1030,12 +1056,19 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
         CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all + nb, tim_mask, nb, hipMemcpyDeviceToDevice, s));
     }
     if (int r = side_init(e)) return r;
+    if (e.part[0] < 0) {
+        e.part[0] = e.part[1] = 0;
+        if (const char* v = getenv("MMHIP_PART")) { int a = 0, b = 0; if (sscanf(v, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { e.part[0] = a; e.part[1] = b; } }
+    }
+    const bool parted = !imported && use_side(e) && !lockstep_ok(e) && e.part[0] > 0;
+    e.cur_part[0] = parted ? e.part[0] : 0; e.cur_part[1] = parted ? e.part[1] : 0;
     if (!imported && lockstep_ok(e)) {
         e.vit_is_long = false;
         if (int r = towers_forward_lockstep(e, pixels, s)) return r;
     } else if (use_side(e)) {
         // the frozen image tower does not depend on the text tower: run it on the side stream, join before the heads
         CHECK_HIP(hipEventRecord(e.ev_fork, s));
+        if (int r = e.span(0, s)) return r;
         static int force = -2;
         if (force == -2) { const char* v = getenv("MMHIP_VIT_PRIO"); force = v ? atoi(v) : -1; }
         const int P = (e.cfg.image / e.cfg.patch) * (e.cfg.image / e.cfg.patch) + 1;
@@ -1045,15 +1078,21 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
         if (!imported) {
             CHECK_HIP(hipStreamWaitEvent(sv, e.ev_fork, 0));
             if (int r = vit_forward(e, pixels, sv)) return r;
+            if (int r = e.span(1, sv)) return r;
             CHECK_HIP(hipEventRecord(e.ev_vit, sv));
         }
         if (int r = text_forward(e, s)) return r;
+        if (int r = e.span(2, s)) return r;
         if (!imported) CHECK_HIP(hipStreamWaitEvent(s, e.ev_vit, 0));
     } else {
+        if (int r = e.span(0, s)) return r;
         if (!imported) if (int r = vit_forward(e, pixels, s)) return r;
+        if (int r = e.span(1, s)) return r;
         if (int r = text_forward(e, s)) return r;
+        if (int r = e.span(2, s)) return r;
     }
     if (int r = heads_forward(e, out_cls, logits_per_text, out_tim, mm_features, s)) return r;
+    if (int r = e.span(3, s)) return r;
     e.fwd_done = true;
     return 0;
 }
@@ -1280,6 +1319,7 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
     }
     if (int r = mmhip_backward_finish(h, stream)) return r;
     if (opt_pending) CHECK_HIP(hipStreamWaitEvent(s, e.ev_opt, 0));
+    if (int r = e.span(4, s)) return r;
     // merged [begin, end) ranges of the active gradient groups, in address order (text layers already stepped: skipped)
     bool act[6] = {false, use_itc != 0, use_itm != 0, e.cfg.fusion == MMHIP_FUSION_ATTENTION, true, false};
     const uint64_t w0 = e.t_word, V = (uint64_t)e.cfg.vocab, H = (uint64_t)e.cfg.hidden;
@@ -1311,9 +1351,31 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
         rb = b; re = en; open = true;
     }
     if (int r = flush()) return r;
-    return opt_pending ? 0 : mmhip_refresh_weights(h, 2, stream);
+    if (!opt_pending) if (int r = mmhip_refresh_weights(h, 2, stream)) return r;
+    return e.span(5, s);
 }
 
+// phase ends of the last step as milliseconds after the forward's fork (hipEvents on the streams the phases run on; no profiler):
+// ms[0] image tower end, [1] text tower end, [2] forward end (heads), [3] backward end (all gradients and layer optimizers joined),
+// [4] step end.  enable != 0 arms the events for the following steps; a phase that was not recorded reads -1.  Synchronises.
+int mmhip_step_spans(mmhip_handle h, int enable, float* ms) {
+    if (!h) return MMHIP_E_INVALID;
+    mmhip_engine& e = *h;
+    if (ms) {
+        for (int i = 0; i < 5; ++i) ms[i] = -1.f;
+        if (e.span_set[0]) {
+            for (int i = 1; i < 6; ++i) {
+                if (!e.span_set[i]) continue;
+                CHECK_HIP(hipEventSynchronize(e.span_ev[i]));
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, e.span_ev[0], e.span_ev[i]) == hipSuccess) ms[i - 1] = t;
+            }
+        }
+    }
+    e.spans_on = enable;
+    if (!enable) for (int i = 0; i < 6; ++i) e.span_set[i] = false;
+    return 0;
+}
 int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_t* launches, double* flops) {
     if (!h) return MMHIP_E_INVALID;
     mmhip_engine& e = *h;

@@ -629,9 +629,8 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if (t == 11 && a.N % 128) t = 0;
     if (t == 12 && a.N % 96) t = 0;
     if ((t == 17 || t == 18) && a.N % 192) t = 0;
-    if ((t >= 19 && t <= 22) && a.N % 256) t = 0;
-    if ((t == 23 || t == 24) && a.N % 192) t = 0;
-    if (t >= 13 && t <= 24) return t;
+    if ((t == 19 || t == 20) && a.N % 256) t = 0;
+    if (t >= 13 && t <= 20) return t;
     if (t >= 1 && t <= 12) return t;
     if (a.N % 128 && a.N % 192 == 0 && a.N % 256) { /* only the 192-wide tiles divide N */ }
     // Measured inside the training step (bench.py with MMHIP_NT_TILE forced, profiles/r01_tile_sweep.txt): 128x128 at two
@@ -705,13 +704,16 @@ static int choose_nt_tile(const GemmNTArgs& a) {
 
 template <typename T>
 static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
-    const int tile = choose_nt_tile(a);
+    int tile = choose_nt_tile(a);
+    // MMHIP_NT8I=1: wherever the rules (or a caller) pick the deep-pipelined 256 x 256 tile, run its interleaved-schedule kernel
+    static int nt8i = -1;
+    if (nt8i < 0) { const char* e = getenv("MMHIP_NT8I"); nt8i = e ? atoi(e) : 0; }
+    if (nt8i && (tile == 13 || tile == 15)) tile = tile == 13 ? 19 : 20;
     if (tile >= 13) {      // 13 / 14: deep-pipelined 256x256 / 256x128, one tile per workgroup; 15 / 16: the same, persistent
         const int dt = sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16;
-        // 17 / 18: 256x192, one-shot / persistent; 19 / 20: 256x256 with BK = 32 and the deep LDS ring
-        // 21 / 22: 256x256 on four waves, 128x128 register tile per wave
-        const int bn = tile >= 23 ? 194 : tile >= 21 ? 258 : (tile >= 19 ? 257 : (tile >= 17 ? 192 : ((tile == 13 || tile == 15) ? 256 : 128)));
-        if (launch_gemm_nt8(a, dt, bn, tile == 15 || tile == 16 || tile == 18 || tile == 20 || tile == 22 || tile == 24, s)) return;
+        // 17 / 18: 256x192, one-shot / persistent; 19 / 20: 256x256 with the interleaved K-loop schedule (gemm_nt8i_kernel)
+        const int bn = tile >= 19 ? 257 : (tile >= 17 ? 192 : ((tile == 13 || tile == 15) ? 256 : 128));
+        if (launch_gemm_nt8(a, dt, bn, tile == 15 || tile == 16 || tile == 18 || tile == 20, s)) return;
     }
     switch (tile >= 13 ? 1 : tile) {
         case 12: launch_nt_t<T, 256, 96, 4, 2, 3, 4>(a, s); break;    // role-specialised, 256 tiles for 8192 x 768: one tile per CU

@@ -137,8 +137,12 @@ __device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, 
 
 // epilogue of one 256 x (2 TN) tile from the accumulators: lane holds C[m][n .. n+7], m = m0 + wm*64 + 16 i + (lane&15),
 // n = n0 + wn*TN + 32 j' + 8 (lane>>4); values 0-3 from fragment 2j', 4-7 from fragment 2j'+1
-template <typename T, int FN, int TN, int EPI, int NI = 4>
-__device__ __forceinline__ void tile_epilogue8(const GemmNTArgs& a, f32x4 (&acc)[NI][FN], int m0, int n0, int wm, int wn, int l15, int kc) {
+// lds_bias: the problem's whole bias vector in LDS (gemm_nt8i_kernel copies it there once per workgroup) or null.  From LDS the eight
+// values of a fragment pair are read where they are used -- an LDS read does not queue behind the tile's global stores the way a
+// global load does (vmcnt retires in issue order), so nothing has to be fetched up front and held in 32 registers.
+template <typename T, int FN, int TN, int EPI, int NI = 4, bool LB = false>
+__device__ __forceinline__ void tile_epilogue8(const GemmNTArgs& a, f32x4 (&acc)[NI][FN], int m0, int n0, int wm, int wn, int l15, int kc,
+                                               const float* lds_bias = nullptr) {
     typedef typename Vec<T>::v8 v8;
     constexpr int WROWS = 16 * NI;              // rows of the tile owned by one wave
         // every load of the epilogue first (bias; residual or mul_in of all the lane's fragments), then compute, then stores.
@@ -150,6 +154,7 @@ __device__ __forceinline__ void tile_epilogue8(const GemmNTArgs& a, f32x4 (&acc)
         for (int jp = 0; jp < FN / 2; ++jp) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) bias8[jp][e] = 0.f;
+            if (LB) continue;
             if (EPI == EP_GELU || (a.flags & GEMM_BIAS)) {
                 f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + nb + 32 * jp), b1 = *reinterpret_cast<const f32x4*>(a.bias + nb + 32 * jp + 4);
 #pragma unroll
@@ -176,6 +181,11 @@ __device__ __forceinline__ void tile_epilogue8(const GemmNTArgs& a, f32x4 (&acc)
             for (int j2 = 0; j2 < 2; ++j2) {
                 const int jp = jc + j2;
                 if (jp >= FN / 2) continue;
+                if (LB) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(lds_bias + nb + 32 * jp), b1 = *reinterpret_cast<const f32x4*>(lds_bias + nb + 32 * jp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bias8[jp][e] = b0[e]; bias8[jp][4 + e] = b1[e]; }
+                }
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int m = m0 + wm * WROWS + i * 16 + l15;
@@ -413,40 +423,36 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// 256 x 256 tile, BK = 32, NBUF-deep LDS ring (NBUF = 5: 160 KB).  Why: with 12 K-steps per tile (K = 768) and operands that
-// come from beyond the XCD's L2, the kernel above is bound by the LDS-DMA bytes it can keep in flight, not by the matrix pipe --
-// in-kernel stamps (tools/gemm8_ts.py) put its K-step at 1.86 us against 0.85 us of MFMA work, and its two 64 KB buffers allow
-// one K-tile of B / two of A ahead (<= 64-96 KB in flight; MI355X_MICROARCH.md "Indexed rows: gather into LDS": 33 GB/s per
-// CU from the Infinity Cache at 72 KB in flight).  Halving the K-tile and spending all of the LDS on the ring keeps
-// NBUF - 1 = 4 K-tiles = 128 KB in flight per CU.
-//   * K-tile = 32 KB: A 256 rows x 64 B, B 256 rows x 64 B; a row's four 16-byte chunks are stored at chunk ^ g(row), g = (-(row>>2)) & 3:
-//     conflict-free for the 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md LDS table) for both the A rows (16 consecutive) and
-//     the permuted B rows of a fragment pair;
-//   * two phases per K-tile (fragment pairs 2p, 2p+1: 16 MFMA 16x16x32 per wave each), L / C intervals and the one-interval skew of
-//     waves 4-7 as above; phase 0 stages A, phase 1 stages B of K-tile kt + NBUF - 1 (2 LDS-DMA instructions per wave and phase) into
-//     the buffer K-tile kt - 1 has just left (A read in its phase 0, B columns in phases 0 / 1: >= 2 phases ago);
-//   * one counted wait per K-tile (phase 1): everything up to K-tile kt + 1 has landed, 4 (NBUF - 2) instructions stay in flight.
-template <int NBUF_>
-struct P32 {
-    static constexpr int BM = 256, BN = 256, BK = 32, TN = 128, FN = 8, NBUF = NBUF_, AH = NBUF_ - 1;
-    static constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, KT = A_BYTES + B_BYTES;
-    static constexpr int LDS = NBUF * KT;
-};
-template <int N> __device__ __forceinline__ void wait_vm_le(int n) {
-    // wait until at most min(n, N) * 4 vector-memory operations are outstanding (n is wave-uniform)
-    if constexpr (N == 0) { wait_vm<0>(); }
-    else { if (n >= N) wait_vm<4 * N>(); else wait_vm_le<N - 1>(n); }
-}
-
-template <typename T, int NBUF, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt8k32_kernel(GemmNTPair g, int persistent) {
-    using C = P32<NBUF>;
+// Round 3: the same tile, LDS image, staging pieces and register epilogue, another K-loop schedule ("interleaved").
+// In-kernel stamps of the kernel above (profiles/r02_gemm8_stamps.txt) put a phase at 770-960 cycles for 256 cycles of MFMA per
+// wave: the wave group in its L interval (fragment reads, two LDS-DMA issues at 100-185 cycles each, counted wait) needs longer
+// than the 290 cycles its partner group multiplies, and the partner then stands at the barrier.  Here no wave ever sits in a
+// read-only interval:
+//   * every wave runs the same stream, no skew between wave groups, ONE barrier per phase (was two);
+//   * a phase's 16 MFMAs multiply fragments that were requested during the PREVIOUS phase: the ds_read_b128 of the next phase's
+//     B fragments (4), in the K-tile's last phase also the next K-tile's A fragments (8), and the phase's two LDS-DMA pieces are
+//     spread between the MFMAs of the wave itself (sched_group_barrier), so their issue and latency hide under its own and its
+//     SIMD partner's MFMAs; B fragments alternate between two register sets by phase parity, A fragments by K-tile parity;
+//   * an LDS slot is free as soon as the barrier that ends the phase in which it was READ INTO REGISTERS has passed, i.e. a whole
+//     phase before its MFMAs run: the A image of K-tile kt is free during all of kt.  Phase p of K-tile kt therefore restages,
+//     for K-tile kt+2: p=0 A rows 0-127 | p=1 A rows 128-255 | p=2 B columns of phases 0,1 | p=3 B columns of phases 2,3 --
+//     into slots last read in phases (kt-1,3) | (kt-1,3) | (kt-1,3),(kt,0) | (kt,1),(kt,2);
+//   * RAW: one counted wait per phase, vmcnt(DMAs issued in the last four phases) -- everything issued five or more phases ago
+//     has landed in every wave before the barrier that ends the phase; the earliest read of a piece comes five phases after its
+//     issue (B columns of phase 0: issued (kt,2), read in (kt+1,3)).  Eight 1 KB pieces per wave = 64 KB per CU stay in flight
+//     across barriers; at the end of the work list the count follows the pieces actually issued;
+//   * at a tile boundary the last phase requests nothing; after the epilogue the wave reads the next tile's first fragments and
+//     one extra barrier keeps a fast wave's next LDS-DMA off slots a slower wave has not read yet.
+template <typename T, int BN, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int persistent) {
+    static_assert(BN == 256, "interleaved schedule: 256 x 256 tile");
+    using C = P8<BN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1, grp = w >> 2;
-    const int tilesN = g.p[0].N / C::BN;
+    const int wm = w >> 1, wn = w & 1;
+    const int tilesN = g.p[0].N / BN;
     const int tilesM0 = (g.p[0].M + C::BM - 1) / C::BM, tiles0 = tilesN * tilesM0;
     const int tilesM1 = g.count > 1 ? (g.p[1].M + C::BM - 1) / C::BM : 0, ntiles = tiles0 + tilesN * tilesM1;
     const int nk = g.p[0].K / C::BK;
@@ -469,47 +475,68 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8k32_kernel(GemmNTPair g, int p
         const int cg = id / per_group, rem = id - cg * per_group;
         const int gw = min(GW, tilesN - cg * GW);
         m0 = (rem / gw) * C::BM;
-        n0 = (cg * GW + rem % gw) * C::BN;
+        n0 = (cg * GW + rem % gw) * BN;
         return which;
     };
 
-    // ---- the DMA stream: group 0 = A (staged in phase 0), group 1 = B (phase 1); piece = 16 rows x 64 B, pieces 2w, 2w+1 of the operand
-    const int prow = lane >> 2, pchunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);      // row in the piece; logical chunk of this lane's LDS position
-    const int total_kt = count * nk;
-    const char* src[2][2];
-    int g_rem[2], g_tile[2], g_buf[2], g_done[2];
-    auto rebase = [&](int grp_, int id) {
+    // ---- the DMA stream: staging group gi = the phase that issues it (0: A rows 0-127, 1: A rows 128-255, 2: B phases 0,1, 3: B phases 2,3),
+    // two pieces per wave and group; its n-th issue is for global K-tile n (K-tiles numbered over the work list).  issue() is
+    // branch-free (it sits between the MFMAs of a phase); advance() moves the group to its next K-tile afterwards.  Past the end of
+    // the work list a group keeps issuing (into slots nobody reads any more, from the first tile's rows): every phase issues two
+    // pieces per wave, so the counted wait is the same constant everywhere and the K loop has no tail case.
+    const int lrow = lane >> 3, lslot = lane & 7;
+    // a piece's source = the operand's base pointer + K offset (both wave-uniform: scalar registers) + a per-lane 32-bit byte offset
+    const char* gbase[4];
+    unsigned voff[4][2];
+    int g_rem[4], g_tile[4], g_inc[4];
+    auto piece = [&](int gi, int jj) -> int {
+        const int q = w * 2 + jj;
+        return gi == 0 ? q : (gi == 1 ? 16 + q : (gi == 2 ? q + (q & 8) : q + 8 + (q & 8)));
+    };
+    auto rebase = [&](auto gc_, int id) {
+        constexpr int gi = decltype(gc_)::value;
         int m0, n0;
         const GemmNTArgs& a = g.p[tile_origin(id, m0, n0)];
+        gbase[gi] = gi >= 2 ? (const char*)a.B : (const char*)a.A;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            const int row = (w * 2 + jj) * 16 + prow;
-            if (grp_) src[1][jj] = (const char*)a.B + ((size_t)(n0 + row) * a.ldb + (size_t)(pchunk * 8)) * 2;
-            else src[0][jj] = (const char*)a.A + ((size_t)min(m0 + row, a.M - 1) * a.lda + (size_t)(pchunk * 8)) * 2;
+            const int pc = piece(gi, jj), row = pc * 8 + lrow;
+            if (gi >= 2) {
+                const int sw = (lrow & 3) | ((pc & 1) << 2);
+                voff[gi][jj] = ((unsigned)(n0 + row) * (unsigned)a.ldb + (unsigned)((lslot ^ sw) * 8)) * 2u;
+            } else {
+                const int gm = min(m0 + row, a.M - 1);          // rows past M read a valid row, never stored
+                voff[gi][jj] = ((unsigned)gm * (unsigned)a.lda + (unsigned)((lslot ^ lrow) * 8)) * 2u;
+            }
         }
     };
-    auto stage = [&](auto gc_) {
+    auto issue = [&](auto gc_, const char* buf) {          // the group's two pieces into K-tile buffer `buf`
         constexpr int gi = decltype(gc_)::value;
-        if (g_done[gi] >= total_kt) return;
-        if (g_rem[gi] == 0) {
-            g_tile[gi] += 1;
-            g_rem[gi] = nk;
-            rebase(gi, first + g_tile[gi] * stride);
-        }
-        char* base = smem + g_buf[gi] * C::KT + (gi ? C::A_BYTES : 0);
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            __builtin_amdgcn_global_load_lds(MM_GLB(src[gi][jj]), MM_LDS(base + (w * 2 + jj) * 1024), 16, 0, 0);
-            src[gi][jj] += 64;
+        for (int jj = 0; jj < 2; ++jj)
+            __builtin_amdgcn_global_load_lds(MM_GLB(gbase[gi] + voff[gi][jj]), MM_LDS(buf + (gi >= 2 ? C::A_BYTES : 0) + piece(gi, jj) * 1024), 16, 0, 0);
+    };
+    auto advance = [&](auto gc_) {
+        constexpr int gi = decltype(gc_)::value;
+        if (--g_rem[gi] == 0) {
+            g_rem[gi] = nk;
+            g_tile[gi] += 1;
+            const bool live = g_tile[gi] < count;
+            g_inc[gi] = live ? 128 : 0;
+            rebase(gc_, first + (live ? g_tile[gi] : 0) * stride);
+        } else {
+            gbase[gi] += g_inc[gi];
         }
-        g_rem[gi] -= 1;
-        g_done[gi] += 1;
-        g_buf[gi] = (g_buf[gi] + 1 == C::NBUF) ? 0 : g_buf[gi] + 1;
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi) { g_rem[gi] = nk; g_tile[gi] = 0; g_buf[gi] = 0; g_done[gi] = 0; rebase(gi, first); }
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    auto init_group = [&](auto gc_) {
+        constexpr int gi = decltype(gc_)::value;
+        g_rem[gi] = nk; g_tile[gi] = 0; g_inc[gi] = 128;
+        rebase(gc_, first);
+    };
 
     f32x4 acc[4][C::FN];
     auto zero_acc = [&]() {
@@ -520,217 +547,137 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8k32_kernel(GemmNTPair g, int p
     };
     zero_acc();
 
-    // fragment read offsets: A row = wm*64 + 16 i + (lane&15); B row = wn*128 + 32 j' + 8 ((lane&15)>>2) + 4 h + (lane&3);
-    // 16-byte chunk (lane>>4) stored at chunk ^ g(row)
-    const int l15 = lane & 15, kc = lane >> 4;
-    const int a_off = (wm * 64 + l15) * 64 + ((kc ^ ((0 - (l15 >> 2)) & 3)) << 4);
-    int b_off[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int r = wn * C::TN + 8 * (l15 >> 2) + 4 * h + (lane & 3);
-        b_off[h] = C::A_BYTES + r * 64 + ((kc ^ ((0 - (r >> 2)) & 3)) << 4);
-    }
-    v8 af[4], bf[2][2];
-
-    // ---- prologue: K-tiles 0 .. AH-1
-#pragma unroll
-    for (int i = 0; i < C::AH; ++i) { stage(I0{}); stage(I1{}); }
-    wait_vm_le<C::AH - 1>(min(C::AH, total_kt) - 1);
-    raw_barrier();
-    if (grp == 1) raw_barrier();
-
-    int gkt = 0, cbuf = 0;
-    for (int t = 0; t < count; ++t) {
-#pragma unroll 1
-        for (int k = 0; k < nk; ++k, ++gkt) {
-            const char* Ks = smem + cbuf * C::KT;
-            cbuf = (cbuf + 1 == C::NBUF) ? 0 : cbuf + 1;
-            auto phase = [&](auto pc_) {
-                constexpr int p = decltype(pc_)::value;
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) bf[jj][h] = lds_read8<T>(Ks, b_off[h] + (32 * (2 * p + jj)) * 64);
-                if (p == 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = lds_read8<T>(Ks, a_off + i * (16 * 64));
-                }
-                stage(pc_);
-                if (p == 1) wait_vm_le<C::AH - 1>(total_kt - gkt - 2);
-                raw_barrier();
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-                            acc[i][2 * (2 * p + jj) + h] = mfma16(bf[jj][h], af[i], acc[i][2 * (2 * p + jj) + h]);
-                __builtin_amdgcn_s_setprio(0);
-                raw_barrier();
-            };
-            phase(I0{});
-            phase(I1{});
-        }
-        int m0, n0;
-        const GemmNTArgs& a = g.p[tile_origin(first + t * stride, m0, n0)];
-        tile_epilogue8<T, C::FN, C::TN, EPI>(a, acc, m0, n0, wm, wn, l15, kc);
-        zero_acc();
-    }
-    if (grp == 0) raw_barrier();
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// 256 x 256 tile on FOUR waves (one per SIMD), each owning a 128 x 128 register tile (8 x 8 fragments of 16 x 16, 256 accumulator
-// registers): the shape the vendor library runs on these GEMMs (rocprofv3 of hipBLASLt: MT256x256x64, 256 threads, MIWT 8x8).
-// Against the eight-wave kernel above: every operand fragment read from LDS feeds 8 MFMAs instead of 4 (32 ds_read_b128 per
-// wave and K-tile for 128 MFMAs), ONE barrier per K-tile instead of eight, no partner wave -- the wave overlaps its own LDS reads
-// with its own MFMAs: the fragments of the second K-half are requested in front of the MFMAs of the first, those of the next
-// K-tile's first half in front of the MFMAs of the second.
-//   K-tile kt lives in buffer kt & 1 (2 x 64 KB, layout and swizzle of the eight-wave kernel).  In the middle of K-tile kt every
-//   wave has all its fragments of buffer kt & 1 in registers and its own DMA pieces of K-tile kt+1 have landed (vmcnt(0)); after
-//   the barrier the buffer is free and K-tile kt+1 is complete: issue the 16 LDS-DMA pieces of K-tile kt+2 into it, request the
-//   first-half fragments of K-tile kt+1, run the second half's MFMAs.
-template <int FN_>
-struct P4 {          // FN_ = 8: 256 x 256 tile (all 256 accumulator registers); 6: 256 x 192 (192, leaves the allocator room)
-    static constexpr int BM = 256, FN = FN_, TN = 16 * FN_, BN = 2 * TN, BK = 64, NI = 8, NPB = BN / 32;   // NPB: B pieces per wave
-    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, KT = A_BYTES + B_BYTES, LDS = 2 * KT;
-};
-
-template <typename T, int FN_, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt4_kernel(GemmNTPair g, int persistent) {
-    using C = P4<FN_>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename Vec<T>::v8 v8;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;
-    const int tilesN = g.p[0].N / C::BN;
-    const int tilesM0 = (g.p[0].M + C::BM - 1) / C::BM, tiles0 = tilesN * tilesM0;
-    const int tilesM1 = g.count > 1 ? (g.p[1].M + C::BM - 1) / C::BM : 0, ntiles = tiles0 + tilesN * tilesM1;
-    const int nk = g.p[0].K / C::BK;
-    const int nwg = gridDim.x;
-    int first, stride, count;
-    if (persistent) {
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, wpx = (nwg + 7 - x) / 8;
-        const int q = ntiles >> 3, r = ntiles & 7;
-        const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, n_x = q + (x < r ? 1 : 0);
-        first = lo + j; stride = wpx; count = j < n_x ? (n_x - j + wpx - 1) / wpx : 0;
-    } else {
-        first = xcd_remap(blockIdx.x, nwg); stride = 0; count = 1;
-    }
-    if (count <= 0) return;
-    constexpr int GW = 8;
-    auto tile_origin = [&](int id, int& m0, int& n0) -> int {
-        const int which = id >= tiles0 ? 1 : 0;
-        if (which) id -= tiles0;
-        const int per_group = (which ? tilesM1 : tilesM0) * GW;
-        const int cg = id / per_group, rem = id - cg * per_group;
-        const int gw = min(GW, tilesN - cg * GW);
-        m0 = (rem / gw) * C::BM;
-        n0 = (cg * GW + rem % gw) * C::BN;
-        return which;
-    };
-
-    // ---- the DMA stream: 64 pieces of 1 KB (8 rows x 128 B) per K-tile, 16 per wave: A pieces 8w .. 8w+7, B pieces 8w .. 8w+7
-    const int lrow = lane >> 3, lslot = lane & 7;
-    const int total_kt = count * nk;
-    const char* srcA[8];
-    const char* srcB[C::NPB];
-    int d_rem = nk, d_tile = 0, d_done = 0;
-    auto rebase = [&](int id) {
-        int m0, n0;
-        const GemmNTArgs& a = g.p[tile_origin(id, m0, n0)];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int row = (w * 8 + jj) * 8 + lrow;
-            srcA[jj] = (const char*)a.A + ((size_t)min(m0 + row, a.M - 1) * a.lda + (size_t)((lslot ^ lrow) * 8)) * 2;
-        }
-#pragma unroll
-        for (int jj = 0; jj < C::NPB; ++jj) {
-            const int pc = w * C::NPB + jj, row = pc * 8 + lrow;
-            const int sw = (lrow & 3) | ((pc & 1) << 2);
-            srcB[jj] = (const char*)a.B + ((size_t)(n0 + row) * a.ldb + (size_t)((lslot ^ sw) * 8)) * 2;
-        }
-    };
-    auto stage = [&]() {                       // the next K-tile of the stream into buffer (d_done & 1)
-        if (d_done >= total_kt) return;
-        if (d_rem == 0) { d_tile += 1; d_rem = nk; rebase(first + d_tile * stride); }
-        char* base = smem + (d_done & 1) * C::KT;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            __builtin_amdgcn_global_load_lds(MM_GLB(srcA[jj]), MM_LDS(base + (w * 8 + jj) * 1024), 16, 0, 0);
-            srcA[jj] += 128;
-        }
-#pragma unroll
-        for (int jj = 0; jj < C::NPB; ++jj) {
-            __builtin_amdgcn_global_load_lds(MM_GLB(srcB[jj]), MM_LDS(base + C::A_BYTES + (w * C::NPB + jj) * 1024), 16, 0, 0);
-            srcB[jj] += 128;
-        }
-        d_rem -= 1;
-        d_done += 1;
-    };
-    rebase(first);
-
-    f32x4 acc[C::NI][C::FN];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < C::NI; ++i)
-#pragma unroll
-            for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    zero_acc();
-
+    // fragment read offsets (layout of gemm_nt8_kernel): A row = wm*64 + 16 i + (lane&15); B (permuted) row = wn*128 + 32 p + 8((lane&15)>>2) + 4 h + (lane&3);
+    // 16-byte chunk = (kk*4 + (lane>>4)) ^ (lane&7)
     const int l15 = lane & 15, kc = lane >> 4, sw7 = lane & 7;
-    const int a_row_off = (wm * 128 + l15) * 128;
+    const int a_row_off = (wm * 64 + l15) * 128;
     const int b_row_off = C::A_BYTES + (wn * C::TN + 8 * (l15 >> 2) + (lane & 3)) * 128;
     const int ch[2] = {((0 * 4 + kc) ^ sw7) << 4, ((1 * 4 + kc) ^ sw7) << 4};
-    v8 af[2][8], bf[2][C::FN / 2][2];
-    auto read_half = [&](const char* Ks, int kk, int set) {
+    v8 af[4][2], bf[2][2][2];          // A fragments [i][kk] (reloaded in place in a K-tile's last phase); B [phase parity][h][kk]
+    auto read_b = [&](auto set_, const char* Ks, int p) {
+        constexpr int set = decltype(set_)::value;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[set][i] = lds_read8<T>(Ks, a_row_off + i * (16 * 128) + ch[kk]);
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int jp = 0; jp < C::FN / 2; ++jp)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) bf[set][jp][h] = lds_read8<T>(Ks, b_row_off + (32 * jp + 4 * h) * 128 + ch[kk]);
+            for (int kk = 0; kk < 2; ++kk) bf[set][h][kk] = lds_read8<T>(Ks, b_row_off + (32 * p + 4 * h) * 128 + ch[kk]);
     };
-    auto mma_half = [&](int set) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int jp = 0; jp < C::FN / 2; ++jp)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i][2 * jp + h] = mfma16(bf[set][jp][h], af[set][i], acc[i][2 * jp + h]);
-        __builtin_amdgcn_s_setprio(0);
+    // the builtin, not inline asm: hipcc's own wait insertion then knows that nothing is outstanding on the LGKM counter and puts no
+    // `lgkmcnt(0)` of its own in front of the next phase's first MFMA (behind that phase's first fragment requests)
+    auto lgkm0 = [&]() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };
+    auto phase_end = [&]() {
+        wait_vm<8>();                      // everything issued five or more phases ago has landed (this wave's pieces)
+        lgkm0();                           // this wave's fragment requests are back: the slots they read may be restaged after the barrier
+        raw_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- prologue: K-tiles 0 and 1 on their way, K-tile 0 landed, its first-half fragments requested
-    stage();
-    stage();
-    if (total_kt > 1) wait_vm<8 + C::NPB>(); else wait_vm<0>();
+    // ---- the bias vectors of the launch's problems into LDS behind the K-tile buffers (`persistent & 2`: the launcher reserved the room)
+    float* lds_bias_all = reinterpret_cast<float*>(smem + C::LDS);
+    {
+        for (int pi = 0; pi < g.count; ++pi) {
+            const GemmNTArgs& a = g.p[pi];
+            if (!(a.flags & GEMM_BIAS)) {
+                for (int c = tid * 4; c < a.N; c += 2048) *reinterpret_cast<f32x4*>(lds_bias_all + pi * a.N + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                for (int c = tid * 4; c < a.N; c += 2048) *reinterpret_cast<f32x4*>(lds_bias_all + pi * a.N + c) = *reinterpret_cast<const f32x4*>(a.bias + c);
+            }
+        }
+    }
+    // ---- prologue: what phases (-2,0) .. (-1,3) would have issued: K-tiles 0 and 1
+    init_group(I0{}); init_group(I1{}); init_group(I2{}); init_group(I3{});
+    issue(I0{}, smem); issue(I1{}, smem); issue(I2{}, smem); issue(I3{}, smem);
+    advance(I0{}); advance(I1{}); advance(I2{}); advance(I3{});
+    issue(I0{}, smem + C::KT); issue(I1{}, smem + C::KT); issue(I2{}, smem + C::KT); issue(I3{}, smem + C::KT);
+    advance(I0{}); advance(I1{}); advance(I2{}); advance(I3{});
+    wait_vm<10>();                         // A and the B columns of phases 0,1 of K-tile 0: behind them group 3 (2 pieces) and K-tile 1 (8)
     raw_barrier();
-    read_half(smem, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) af[i][kk] = lds_read8<T>(smem, a_row_off + i * (16 * 128) + ch[kk]);
+    read_b(I0{}, smem, 0);
+    lgkm0();
+    raw_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 
     int gkt = 0;
     for (int t = 0; t < count; ++t) {
 #pragma unroll 1
         for (int k = 0; k < nk; ++k, ++gkt) {
-            const char* Ks = smem + (gkt & 1) * C::KT;
-            read_half(Ks, 1, 1);                       // second-half fragments, in flight under the first half's MFMAs
-            mma_half(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave holds every fragment of the buffer
-            wait_vm<0>();                              // and its pieces of K-tile gkt + 1 have landed
-            raw_barrier();
-            stage();                                   // K-tile gkt + 2 -> the buffer just left
-            if (gkt + 1 < total_kt) read_half(smem + ((gkt + 1) & 1) * C::KT, 0, 0);
-            mma_half(1);
+            const char* Ks = smem + (gkt & 1) * C::KT;          // this K-tile; also the buffer K-tile gkt + 2 is staged into
+            const char* Kn = smem + ((gkt + 1) & 1) * C::KT;
+            // ---- phases 0-2: request the B fragments of the next phase, issue the phase's two pieces, 16 MFMAs
+            auto phase = [&](auto pc_) {
+                constexpr int p = decltype(pc_)::value;
+                constexpr int bs = p & 1;
+                read_b(std::integral_constant<int, bs ^ 1>{}, Ks, p + 1);
+                issue(pc_, Ks);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) acc[i][2 * p + h] = mfma16(bf[bs][h][kk], af[i][kk], acc[i][2 * p + h]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                advance(pc_);
+                phase_end();
+            };
+            phase(I0{});
+            phase(I1{});
+            phase(I2{});
+            // ---- phase 3: the next K-tile's B fragments of phase 0 (other register set) and its A fragments, each A fragment into the
+            // registers of the one whose last two MFMAs have just been issued
+            {
+                read_b(I0{}, Kn, 0);
+                issue(I3{}, Ks);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) acc[i][6 + h] = mfma16(bf[1][h][kk], af[i][kk], acc[i][6 + h]);
+                        af[i][kk] = lds_read8<T>(Kn, a_row_off + i * (16 * 128) + ch[kk]);
+                    }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (r == 1 || r == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                advance(I3{});
+                phase_end();
+            }
         }
+        // ---- epilogue of tile t from the accumulators (register epilogue of gemm_nt8_kernel).  The fragments requested in the last
+        // phase belong to the next tile's first K-tile when there is one.
         int m0, n0;
-        const GemmNTArgs& a = g.p[tile_origin(first + t * stride, m0, n0)];
-        tile_epilogue8<T, C::FN, C::TN, EPI, C::NI>(a, acc, m0, n0, wm, wn, l15, kc);
+        const int which = tile_origin(first + t * stride, m0, n0);
+        const GemmNTArgs& a = g.p[which];
+        tile_epilogue8<T, C::FN, C::TN, EPI, 4, true>(a, acc, m0, n0, wm, wn, l15, kc, lds_bias_all + which * a.N);
         zero_acc();
+        if (t + 1 < count) {
+            // the fragments requested in the tile's last phase are not kept across the epilogue (it needs the registers): request the
+            // next tile's first fragments again; the barrier keeps a faster wave's next LDS-DMA off slots this wave has not read yet
+            const char* Ks = smem + (gkt & 1) * C::KT;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) af[i][kk] = lds_read8<T>(Ks, a_row_off + i * (16 * 128) + ch[kk]);
+            read_b(I0{}, Ks, 0);
+            lgkm0();
+            raw_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    wait_vm<0>();          // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
 // split-K finish (launch_nt_splitk in gemm.hip): thread = 8 consecutive columns of one row; sums the slices' fp32 partial products,
@@ -797,28 +744,23 @@ static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
     if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<T, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
     int ntiles = 0;
     for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / BN);
-    const int grid = persistent ? nt8_grid(ntiles) : ntiles;
-    hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI>), dim3(grid), dim3(512), C::LDS, s, g, persistent && ntiles > 256 ? 1 : 0);
+    const int cap = g.p[0].grid > 0 ? (g.p[0].grid < ntiles ? g.p[0].grid : ntiles) : 0;
+    const int grid = persistent ? (cap ? cap : nt8_grid(ntiles)) : ntiles;
+    hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI>), dim3(grid), dim3(512), C::LDS, s, g, persistent && ntiles > grid ? 1 : 0);
 }
-template <typename T, int NBUF, int EPI>
-static void launch_nt8k32_e(const GemmNTPair& g, int persistent, hipStream_t s) {
-    using C = P32<NBUF>;
+template <typename T, int BN, int EPI>
+static void launch_nt8i_e(const GemmNTPair& g, int persistent, hipStream_t s) {
+    using C = P8<BN>;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8k32_kernel<T, NBUF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8i_kernel<T, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
     int ntiles = 0;
-    for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / C::BN);
-    const int grid = persistent ? (ntiles < 256 ? ntiles : 256) : ntiles;
-    hipLaunchKernelGGL((gemm_nt8k32_kernel<T, NBUF, EPI>), dim3(grid), dim3(512), C::LDS, s, g, persistent && ntiles > 256 ? 1 : 0);
-}
-template <typename T, int FN, int EPI>
-static void launch_nt4_e(const GemmNTPair& g, int persistent, hipStream_t s) {
-    using C = P4<FN>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt4_kernel<T, FN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
-    int ntiles = 0;
-    for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / C::BN);
-    const int grid = persistent ? (ntiles < 256 ? ntiles : 256) : ntiles;
-    hipLaunchKernelGGL((gemm_nt4_kernel<T, FN, EPI>), dim3(grid), dim3(256), C::LDS, s, g, persistent && ntiles > 256 ? 1 : 0);
+    for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / BN);
+    const int cap = g.p[0].grid > 0 ? (g.p[0].grid < ntiles ? g.p[0].grid : ntiles) : 0;
+    const int grid = persistent ? (cap ? cap : nt8_grid(ntiles)) : ntiles;
+    // the bias vectors live in LDS behind the K-tile buffers (nt8i_ok: they fit the CU's 160 KB)
+    size_t lds = C::LDS;
+    for (int i = 0; i < g.count; ++i) lds += (size_t)g.p[i].N * 4;
+    hipLaunchKernelGGL((gemm_nt8i_kernel<T, BN, EPI>), dim3(grid), dim3(512), lds, s, g, persistent && ntiles > grid ? 1 : 0);
 }
 // epilogue class that covers a flag set (a pair uses the class that covers both)
 static int nt8_class(int f) {
@@ -828,26 +770,14 @@ static int nt8_class(int f) {
     if (!(f & ~(GEMM_BIAS | GEMM_DROPOUT | GEMM_RESIDUAL))) return EP_PLAIN;
     return EP_ANY;
 }
-static int nt8_ring() {          // MMHIP_NT8_RING: K-tiles in the ring of the BK = 32 kernel (4 = 128 KB, 5 = 160 KB)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MMHIP_NT8_RING"); v = e ? atoi(e) : 5; }
-    return v;
-}
-template <typename T>
-static void launch_nt8k32_t(const GemmNTPair& g, int persistent, hipStream_t s) {
+template <typename T, int BN>
+static void launch_nt8i_t(const GemmNTPair& g, int persistent, hipStream_t s) {
     int c = nt8_class(g.p[0].flags);
     if (g.count > 1 && nt8_class(g.p[1].flags) != c) c = EP_ANY;
-    if (nt8_ring() == 4) {
-        if (c == EP_GELU) launch_nt8k32_e<T, 4, EP_GELU>(g, persistent, s);
-        else if (c == EP_MULG) launch_nt8k32_e<T, 4, EP_MULG>(g, persistent, s);
-        else if (c == EP_PLAIN) launch_nt8k32_e<T, 4, EP_PLAIN>(g, persistent, s);
-        else launch_nt8k32_e<T, 4, EP_ANY>(g, persistent, s);
-    } else {
-        if (c == EP_GELU) launch_nt8k32_e<T, 5, EP_GELU>(g, persistent, s);
-        else if (c == EP_MULG) launch_nt8k32_e<T, 5, EP_MULG>(g, persistent, s);
-        else if (c == EP_PLAIN) launch_nt8k32_e<T, 5, EP_PLAIN>(g, persistent, s);
-        else launch_nt8k32_e<T, 5, EP_ANY>(g, persistent, s);
-    }
+    if (c == EP_GELU) launch_nt8i_e<T, BN, EP_GELU>(g, persistent, s);
+    else if (c == EP_MULG) launch_nt8i_e<T, BN, EP_MULG>(g, persistent, s);
+    else if (c == EP_PLAIN) launch_nt8i_e<T, BN, EP_PLAIN>(g, persistent, s);
+    else launch_nt8i_e<T, BN, EP_ANY>(g, persistent, s);
 }
 template <typename T, int BN>
 static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
@@ -858,24 +788,10 @@ static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
     else if (c == EP_PLAIN) launch_nt8_e<T, BN, EP_PLAIN>(g, persistent, s);
     else launch_nt8_e<T, BN, EP_ANY>(g, persistent, s);
 }
-template <typename T, int FN>
-static void launch_nt4_t(const GemmNTPair& g, int persistent, hipStream_t s) {
-    int c = nt8_class(g.p[0].flags);
-    if (g.count > 1 && nt8_class(g.p[1].flags) != c) c = EP_ANY;
-    if (c == EP_GELU) launch_nt4_e<T, FN, EP_GELU>(g, persistent, s);
-    else if (c == EP_MULG) launch_nt4_e<T, FN, EP_MULG>(g, persistent, s);
-    else if (c == EP_PLAIN) launch_nt4_e<T, FN, EP_PLAIN>(g, persistent, s);
-    else launch_nt4_e<T, FN, EP_ANY>(g, persistent, s);
-}
 static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent, hipStream_t s) {
-    if (bn == 258 || bn == 194) {             // four waves: 256 x 256 (128 x 128 register tile per wave) / 256 x 192 (128 x 96)
-        if (dtype == DT_BF16) { if (bn == 258) launch_nt4_t<bf16_t, 8>(g, persistent, s); else launch_nt4_t<bf16_t, 6>(g, persistent, s); }
-        else { if (bn == 258) launch_nt4_t<f16_t, 8>(g, persistent, s); else launch_nt4_t<f16_t, 6>(g, persistent, s); }
-        return;
-    }
-    if (bn == 257) {             // 256 x 256, BK = 32, deep ring
-        if (dtype == DT_BF16) launch_nt8k32_t<bf16_t>(g, persistent, s);
-        else launch_nt8k32_t<f16_t>(g, persistent, s);
+    if (bn == 257) {             // 256 x 256, interleaved schedule
+        if (dtype == DT_BF16) launch_nt8i_t<bf16_t, 256>(g, persistent, s);
+        else launch_nt8i_t<f16_t, 256>(g, persistent, s);
         return;
     }
     if (dtype == DT_BF16) {
@@ -889,10 +805,15 @@ static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent,
     }
 }
 
-// bn: 256, 192 or 128; 257 = 256 x 256 with BK = 32 and the deep ring; 258 = 256 x 256 on four waves.  Returns false when the shape rules of the kernel do not
-// hold (caller falls back).
+// bn: 256, 192 or 128 (two-interval schedule); 257 = 256 x 256 with the interleaved schedule.  Returns false when the shape rules of
+// the kernel do not hold (caller falls back).
+// interleaved kernel: bias vector(s) in LDS behind the two 64 KB K-tile buffers; 32-bit byte offsets into the operands
+static bool nt8i_ok(const GemmNTArgs& a, int nprob) {
+    return (size_t)a.N * 4 * nprob <= 32 * 1024 && (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldb * 2 < (1ull << 32);
+}
 bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hipStream_t s) {
-    if ((bn != 258 && bn != 257 && bn != 256 && bn != 194 && bn != 192 && bn != 128) || !nt8_ok(a, bn >= 257 ? 256 : (bn == 194 ? 192 : bn))) return false;
+    if (bn == 257 && !nt8i_ok(a, 1)) bn = 256;
+    if ((bn != 257 && bn != 256 && bn != 192 && bn != 128) || !nt8_ok(a, bn == 257 ? 256 : bn)) return false;
     GemmNTPair g;
     g.p[0] = a; g.p[1] = a; g.count = 1;
     launch_nt8_d(g, dtype, bn, persistent, s);

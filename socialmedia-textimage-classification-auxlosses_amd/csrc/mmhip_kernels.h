@@ -32,6 +32,10 @@ struct GemmNTArgs {
     int drop_row_mul;         // dropout element index uses row m * drop_row_mul (0 = 1): compact CLS-row GEMMs keep the
                               // masks of the full [posts*T, N] tensor
     DropCfg drop;
+    int grid;                 // persistent deep-pipelined kernels (gemm8.hip): at most this many workgroups (0 = one per CU).  The forward
+                              // partitions the chip between its two towers this way: each workgroup holds a CU's LDS, so 96 + 160
+                              // resident workgroups of two concurrent launches ARE a 96 / 160 CU split, and 256-row tiles of the
+                              // 8192-row text GEMMs come in multiples of 96
     float* splitk_ws;         // optional fp32 scratch [K/384][M][N]: a GEMM of <= 128 rows with K >= 1536 (the CLS-row GEMMs of the last
                               // text layer) is cut along K into slices that run side by side; a second kernel sums them and applies the epilogue
 };

@@ -6,7 +6,8 @@ for round in 1 2; do
     python - "$round" "$envs" "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[3])
-print(sys.argv[1], "|", sys.argv[2], "|", d["ms_per_step"], d["fwd_bwd_ms"], d["roofline"]["frac"], d["roofline"]["frac_serial"], flush=True)
+sp = d.get("spans_ms") or {}
+print(sys.argv[1], "|", sys.argv[2], "|", d["ms_per_step"], d["fwd_bwd_ms"], d["roofline"]["frac"], d["roofline"]["frac_serial"], "| spans", " ".join("%.2f" % v for v in sp.values()), flush=True)
 PY
   done
 done
