@@ -300,7 +300,7 @@ class Dropout:
 # f16 carries text-tower gradients multiplied by `loss_scale` (engine.hip gscale(): 1024) -- range, not precision.
 # --------------------------------------------------------------------------------------
 class _Policy:
-    # what is rounded, each one of None (fp32) | "bf16" | "f16" | "bf16x2" (hi + lo bf16 pair = 16 significant bits):
+    # what is rounded, each one of None (fp32) | "bf16" | "f16" | "bf16x2" / "f16x2" (hi + lo pair = 16 / 22 significant bits):
     op_a = None       # activation operand of a matrix product
     op_w = None       # weight operand
     st_act = None     # stored activations (qkv, ctx, FC1 output and stash) and stored gradients
@@ -343,6 +343,9 @@ def _rnd(x: Tensor, kind: str) -> Tensor:
     if kind == "bf16x2":
         hi = x.to(torch.bfloat16).to(torch.float32)
         return hi + (x - hi).to(torch.bfloat16).to(torch.float32)
+    if kind == "f16x2":
+        hi = x.to(torch.float16).to(torch.float32)
+        return hi + (x - hi).to(torch.float16).to(torch.float32)
     raise ValueError(kind)
 
 

@@ -87,7 +87,9 @@ struct mmhip_engine {
     // (128 KB of LDS), so the two launches split the chip 96 / 160 without CU masks, each tower's GEMMs see a fixed machine (8192 rows x
     // 2304 / 768 / 3072 columns = 288 / 96 / 384 tiles = 3 / 1 / 4 rounds of 96; 12608 rows = 450 / 150 / 600 tiles = 2.8 / 0.94 / 3.75 rounds
     // of 160) instead of racing for CUs launch by launch.  cur_part: the caps of the forward being enqueued (0 = off).
-    int part[2] = {-1, -1}, cur_part[2] = {0, 0};
+    int part[2] = {-1, -1}, cur_part[2] = {0, 0}; bool part_auto = false;
+    int part_bwd = -1;         // MMHIP_PART_BWD=n: the backward's activation-gradient GEMMs as persistent 256 x 256-tile launches of at most n workgroups
+                               // (the grouped weight-gradient GEMM of the layer above runs beside them on the side stream)
     // mmhip_step_spans: timing events at the phase ends of the last forward / train step (0 fork, 1 image tower end, 2 text tower end,
     // 3 forward end, 4 backward end, 5 step end); recorded only while enabled
     int spans_on = 0; hipEvent_t span_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool span_set[6] = {false, false, false, false, false, false};
@@ -380,7 +382,7 @@ struct G {
 // forward GEMM of tower `which` (0 text, 1 image) under the CU partition: persistent 256 x 256 tiles on at most cur_part[which] workgroups
 inline void part_gemm(const mmhip_engine& e, G& g, int which) {
     const int n = e.cur_part[which];
-    if (n > 0 && !g.a.tile && g.a.M >= 2048 && g.a.N % 256 == 0 && g.a.K % 64 == 0 && (e.dt() == DT_BF16 || e.dt() == DT_F16)) { g.a.tile = 15; g.a.grid = n; }
+    if (n > 0 && !g.a.tile && g.a.M >= 2048 && g.a.N % 256 == 0 && g.a.K % 64 == 0 && (e.dt() == DT_BF16 || e.dt() == DT_F16)) { g.a.tile = 20; g.a.grid = n; }
 }
 int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
     // CLS-row GEMMs of the last text layer (<= 128 rows, K = 3072): split along K (gemm.hip launch_nt_splitk).  They are issued on
@@ -706,6 +708,30 @@ int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s)
     return 0;
 }
 
+// The split of the chip's 256 CUs between the two towers of this forward: both towers' big GEMMs run 256 x 256 tiles of K / 64 K-steps
+// each, a launch of n tiles on c workgroups takes ceil(n / c) rounds, a round costs its K-steps plus a fixed prologue + epilogue share
+// (in K-step units: 5, from the in-kernel stamps: 7.5 us of 29.5 at K = 768).  Pick the split (whole XCD-eighths: multiples of 8) that
+// minimises the longer tower; partition only when the model says it beats both towers sharing every launch's tail.
+void choose_partition(mmhip_engine& e) {
+    const mmhip_config& c = e.cfg;
+    const int H = c.hidden, I = c.inter, Hv = e.Hv(), Iv = e.Iv();
+    if (H % 256 || I % 256 || Hv % 256 || Iv % 256 || c.layers_txt < 1 || c.layers_img < 1) return;
+    const long Mt = (long)e.Bt * e.T, Mv = (long)e.B * e.P();
+    if (Mt < 2048 || Mv < 2048) return;
+    const long rt = (Mt + 255) / 256, rv = (Mv + 255) / 256;
+    auto tower = [](long rows, int h, int inter, int layers, int cap) -> double {
+        auto gemm = [&](int n, int k) { const long tiles = rows * (n / 256); return (double)((tiles + cap - 1) / cap) * (k / 64 + 5); };
+        return layers * (gemm(3 * h, h) + gemm(h, h) + gemm(inter, h) + gemm(h, inter));
+    };
+    double best = 1e30; int bt = 0;
+    for (int t = 32; t <= 224; t += 8) {
+        const double ct = tower(rt, H, I, c.layers_txt, t), cv = tower(rv, Hv, Iv, c.layers_img, 256 - t);
+        const double m = ct > cv ? ct : cv;
+        if (m < best) { best = m; bt = t; }
+    }
+    if (bt) { e.cur_part[0] = bt; e.cur_part[1] = 256 - bt; }
+}
+
 const char* text_last(const mmhip_engine& e) { return e.cfg.layers_txt ? e.ws + e.tact[e.cfg.layers_txt - 1].out : e.ws + e.x0; }
 
 int heads_forward(mmhip_engine& e, float* out_cls, float* logits, float* out_tim, float* feats_out, hipStream_t s) {
@@ -859,14 +885,20 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
     const char* df = d_ffn.thresh16 ? ddrop2 : dpre2;
     // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
-    { G g(df, H, e.ws + w.fc2T, H, du, I, Mr, I, H); g.mul_gelu_grad(e.ws + a.u, I); if (int r = run_gemm(e, g, s)) return r; }
+    if (e.part_bwd < 0) { const char* v = getenv("MMHIP_PART_BWD"); e.part_bwd = v ? atoi(v) : 0; }
+    static int bwd_mask = -1;
+    if (bwd_mask < 0) { const char* v = getenv("MMHIP_PART_BWD_MASK"); bwd_mask = v ? atoi(v) : 15; }
+    auto part_bwd = [&](G& g, int bit) {
+        if (e.part_bwd > 0 && (bwd_mask & bit) && side && g.a.M >= 2048 && g.a.N % 256 == 0 && g.a.K % 64 == 0 && (dt == DT_BF16 || dt == DT_F16)) { g.a.tile = 15; g.a.grid = e.part_bwd; }
+    };
+    { G g(df, H, e.ws + w.fc2T, H, du, I, Mr, I, H); g.mul_gelu_grad(e.ws + a.u, I); part_bwd(g, 1); if (int r = run_gemm(e, g, s)) return r; }
     // the two long-K activation-gradient GEMMs of the layer (768 wide): one role-specialised 256x96 tile per CU when M gives
     // exactly <= 256 of them -- in isolation 7 % faster than the 192 tiles of 256x128, in the step -0.05 ms (same-box A/B; the
     // same tile in the FORWARD costs +0.3 ms: it leaves no CU to the image tower).  MMHIP_BWD_TILE12=0 turns it off.
     static int bt12 = -1;
     if (bt12 < 0) { const char* v = getenv("MMHIP_BWD_TILE12"); bt12 = v ? atoi(v) : 1; }
     const int nt = (bt12 && Mr >= 4096 && Mr <= 8192 && H % 96 == 0) ? 12 : 0;
-    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mr, H, I); g.residual(dpre2, H); g.a.tile = nt; if (int r = run_gemm(e, g, s)) return r; }
+    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mr, H, I); g.residual(dpre2, H); g.a.tile = nt; part_bwd(g, 2); if (int r = run_gemm(e, g, s)) return r; }
     // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
     LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mr, H,
@@ -882,6 +914,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     } else {
         G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H);
         g.a.tile = (bt12 & 2) ? nt : 0;
+        part_bwd(g, 4);
         if (int r = run_gemm(e, g, s)) return r;
     }
     AttnBwdArgs ab;
@@ -908,6 +941,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
         G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H);
         g.residual(dpre1, H);
         g.a.tile = nt;
+        part_bwd(g, 8);
         if (int r = run_gemm(e, g, s)) return r;
     }
     GemmTNProblem pr[4];
@@ -1057,11 +1091,18 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
     }
     if (int r = side_init(e)) return r;
     if (e.part[0] < 0) {
-        e.part[0] = e.part[1] = 0;
-        if (const char* v = getenv("MMHIP_PART")) { int a = 0, b = 0; if (sscanf(v, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { e.part[0] = a; e.part[1] = b; } }
+        // MMHIP_PART: "txt,vit" forces a split, "0" turns the partition off; default: chosen per forward (choose_partition)
+        e.part[0] = e.part[1] = 0; e.part_auto = true;
+        if (const char* v = getenv("MMHIP_PART")) {
+            int a = 0, b = 0;
+            e.part_auto = false;
+            if (sscanf(v, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { e.part[0] = a; e.part[1] = b; }
+        }
     }
-    const bool parted = !imported && use_side(e) && !lockstep_ok(e) && e.part[0] > 0;
-    e.cur_part[0] = parted ? e.part[0] : 0; e.cur_part[1] = parted ? e.part[1] : 0;
+    const bool can_part = !imported && use_side(e) && !lockstep_ok(e) && (e.dt() == DT_BF16 || e.dt() == DT_F16);
+    e.cur_part[0] = e.cur_part[1] = 0;
+    if (can_part && e.part_auto) choose_partition(e);
+    else if (can_part && e.part[0] > 0) { e.cur_part[0] = e.part[0]; e.cur_part[1] = e.part[1]; }
     if (!imported && lockstep_ok(e)) {
         e.vit_is_long = false;
         if (int r = towers_forward_lockstep(e, pixels, s)) return r;

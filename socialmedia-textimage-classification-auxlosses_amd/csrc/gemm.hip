@@ -7,6 +7,8 @@
 // Tiling: 128x128 output tile, BK = 64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.
 // Operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered.
 // LDS images are XOR-swizzled on the *source* address (the LDS-DMA destination is lane-linear) and on the read.
+#include <cstdio>
+#include <cstdlib>
 #include "mmhip_common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -617,7 +619,30 @@ static void launch_nt_splitk(const GemmNTArgs& a, int slices, hipStream_t s) {
 // tile choice: explicit (a.tile: 1 = 128x128 2-stage, 2 = 256x128 2-stage, 3 = 256x256 2-stage, 4 = 128x128 4-stage ring,
 // 5 = 256x128 3-stage ring, 6 = 128x192 2-stage, 7 = 256x192 2-stage, 8 = 128x128 role-specialised (4 MFMA + 4 loader
 // waves, 4-stage ring), 9 = 256x128 role-specialised (8 + 4 waves, 3-stage ring)) or measured rules
+// MMHIP_TILE_MAP="MxNxK:tile,MxNxK/FLAGS:tile,..." -- per-shape tile override for same-box A/B runs of the whole step (an entry with
+// /FLAGS matches that epilogue flag set only)
+struct TileMapEntry { int M, N, K, flags, tile; };
+static int tile_map_lookup(const GemmNTArgs& a) {
+    static TileMapEntry tab[32];
+    static int n = -1;
+    if (n < 0) {
+        n = 0;
+        const char* e = getenv("MMHIP_TILE_MAP");
+        while (e && *e && n < 32) {
+            TileMapEntry t{0, 0, 0, -1, 0};
+            int used = 0;
+            if (sscanf(e, "%dx%dx%d/%d:%d%n", &t.M, &t.N, &t.K, &t.flags, &t.tile, &used) == 5 && used > 0) { tab[n++] = t; }
+            else { t.flags = -1; if (sscanf(e, "%dx%dx%d:%d%n", &t.M, &t.N, &t.K, &t.tile, &used) == 4 && used > 0) tab[n++] = t; else break; }
+            e += used;
+            if (*e == ',') ++e;
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (tab[i].M == a.M && tab[i].N == a.N && tab[i].K == a.K && (tab[i].flags < 0 || tab[i].flags == a.flags)) return tab[i].tile;
+    return 0;
+}
 static int choose_nt_tile(const GemmNTArgs& a) {
+    if (!a.grid) { const int m = tile_map_lookup(a); if (m) return m; }
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_NT_TILE"); env = e ? atoi(e) : 0; }
     int t = a.tile ? a.tile : env;
@@ -630,7 +655,9 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if (t == 12 && a.N % 96) t = 0;
     if ((t == 17 || t == 18) && a.N % 192) t = 0;
     if ((t == 19 || t == 20) && a.N % 256) t = 0;
-    if (t >= 13 && t <= 20) return t;
+    if ((t == 21 || t == 22) && a.N % 192) t = 0;
+    if ((t == 23 || t == 24) && a.N % 128) t = 0;
+    if (t >= 13 && t <= 24) return t;
     if (t >= 1 && t <= 12) return t;
     if (a.N % 128 && a.N % 192 == 0 && a.N % 256) { /* only the 192-wide tiles divide N */ }
     // Measured inside the training step (bench.py with MMHIP_NT_TILE forced, profiles/r01_tile_sweep.txt): 128x128 at two
@@ -707,13 +734,14 @@ static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
     int tile = choose_nt_tile(a);
     // MMHIP_NT8I=1: wherever the rules (or a caller) pick the deep-pipelined 256 x 256 tile, run its interleaved-schedule kernel
     static int nt8i = -1;
-    if (nt8i < 0) { const char* e = getenv("MMHIP_NT8I"); nt8i = e ? atoi(e) : 0; }
-    if (nt8i && (tile == 13 || tile == 15)) tile = tile == 13 ? 19 : 20;
+    if (nt8i < 0) { const char* e = getenv("MMHIP_NT8I"); nt8i = e ? atoi(e) : 1; }
+    if (nt8i && tile >= 13 && tile <= 18) tile = (tile == 13 || tile == 15) ? 19 + (tile == 15) : ((tile == 17 || tile == 18) ? 21 + (tile == 18) : 23 + (tile == 16));
     if (tile >= 13) {      // 13 / 14: deep-pipelined 256x256 / 256x128, one tile per workgroup; 15 / 16: the same, persistent
         const int dt = sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16;
-        // 17 / 18: 256x192, one-shot / persistent; 19 / 20: 256x256 with the interleaved K-loop schedule (gemm_nt8i_kernel)
-        const int bn = tile >= 19 ? 257 : (tile >= 17 ? 192 : ((tile == 13 || tile == 15) ? 256 : 128));
-        if (launch_gemm_nt8(a, dt, bn, tile == 15 || tile == 16 || tile == 18 || tile == 20, s)) return;
+        // 17 / 18: 256x192, one-shot / persistent; 19 / 20, 21 / 22, 23 / 24: 256x256, 256x192, 256x128 with the interleaved K-loop
+        // schedule (gemm_nt8i_kernel), one-shot / persistent
+        const int bn = tile >= 23 ? 129 : (tile >= 21 ? 193 : (tile >= 19 ? 257 : (tile >= 17 ? 192 : ((tile == 13 || tile == 15) ? 256 : 128))));
+        if (launch_gemm_nt8(a, dt, bn, tile == 15 || (tile >= 16 && !(tile & 1)), s)) return;
     }
     switch (tile >= 13 ? 1 : tile) {
         case 12: launch_nt_t<T, 256, 96, 4, 2, 3, 4>(a, s); break;    // role-specialised, 256 tiles for 8192 x 768: one tile per CU

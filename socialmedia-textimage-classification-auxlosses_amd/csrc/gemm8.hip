@@ -83,7 +83,10 @@ __device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, 
         for (int e = 0; e < 8; ++e) o[e] = from_f<T>(v[e]);
         *reinterpret_cast<v8*>((T*)a.aux + (size_t)m * a.ldaux + n) = o;
     }
-    if (EPI == EP_GELU || (EPI == EP_ANY && (fl & GEMM_GELU))) {
+    if (EPI == EP_GELU && (fl & GEMM_QGELU)) {          // the CLIP tower's quick-GELU shares the class of the exact GELU (bias [+ stash] + activation)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mm_qgelu(v[e]);
+    } else if (EPI == EP_GELU || (EPI == EP_ANY && (fl & GEMM_GELU))) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = mm_gelu(v[e]);
     }
@@ -161,24 +164,26 @@ __device__ __forceinline__ void tile_epilogue8(const GemmNTArgs& a, f32x4 (&acc)
                 for (int e = 0; e < 4; ++e) { bias8[jp][e] = b0[e]; bias8[jp][4 + e] = b1[e]; }
             }
         }
-        // (BN = 256: two chunks of two fragment-pair columns -- 64 more registers for all sixteen residual fragments would spill)
+        // (BN = 256: two chunks of two fragment-pair columns -- 64 more registers for all sixteen residual fragments would spill; the
+        // interleaved kernel (LB) takes one column per chunk: its K loop keeps a second set of B fragments)
+        constexpr int CW = LB ? 1 : 2;
 #pragma unroll
-        for (int jc = 0; jc < FN / 2; jc += 2) {
-            v8 pre[NI][2];
+        for (int jc = 0; jc < FN / 2; jc += CW) {
+            v8 pre[NI][CW];
             const T* pbase = (EPI == EP_MULG) ? (const T*)a.mul_in : (const T*)a.residual;
             const int pld = (EPI == EP_MULG) ? a.ldmul : a.ldres;
             const bool want = (EPI == EP_MULG) || ((EPI == EP_PLAIN || EPI == EP_ANY) && (a.flags & GEMM_RESIDUAL));
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j2 = 0; j2 < 2; ++j2) {
+                for (int j2 = 0; j2 < CW; ++j2) {
                     if (EPI != EP_GELU && want && jc + j2 < FN / 2) {
                         const int m = min(m0 + wm * WROWS + i * 16 + l15, a.M - 1);
                         pre[i][j2] = *reinterpret_cast<const v8*>(pbase + (size_t)m * pld + nb + 32 * (jc + j2));
                     }
                 }
 #pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2) {
+            for (int j2 = 0; j2 < CW; ++j2) {
                 const int jp = jc + j2;
                 if (jp >= FN / 2) continue;
                 if (LB) {
@@ -443,10 +448,42 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
 //     across barriers; at the end of the work list the count follows the pieces actually issued;
 //   * at a tile boundary the last phase requests nothing; after the epilogue the wave reads the next tile's first fragments and
 //     one extra barrier keeps a fast wave's next LDS-DMA off slots a slower wave has not read yet.
+// Staging plan of the interleaved schedule, per tile width (a K-tile = NPH phases of 16 MFMAs per wave; phase p of K-tile kt issues its
+// pieces for K-tile kt + NBUF into the buffer of K-tile kt, whose slots were read into registers one phase before their MFMAs):
+//   BN = 256 (NBUF 2)  p0: A rows 0-127 (2 per wave) | p1: A rows 128-255 (2) | p2: B columns of phases 0,1 (2) | p3: B phases 2,3 (2);   wait 8 | 8 | 8 | 8
+//   BN = 192 (NBUF 2)  p0: A rows 0-127 (2), A rows 128-255 (2) | p1: B phase 0 (1), B phase 1 (1) | p2: B phase 2 (1);                  wait 8 | 8 | 10
+//   BN = 128 (NBUF 3)  p0: A rows 0-127 (2) + B phase 0 (1) | p1: A rows 128-255 (2) + B phase 1 (1);                                     wait 9 | 12
+// `wait` = the vmcnt of the counted wait that ends phase p: how many of the wave's youngest pieces may stay in flight so that every
+// slot requested in the NEXT phase has landed (derivation per width next to I8::wait).
+template <int BN>
+struct I8 {
+    using C = P8<BN>;
+    static constexpr int NPH = C::NPH, NBUF = C::NBUF, TN = C::TN;
+    static constexpr int PIECES = (C::A_BYTES + C::B_BYTES) / 1024 / 8;            // per wave and K-tile: 8 | 7 | 6
+    __host__ __device__ static constexpr int cnt(int p) { return BN == 256 ? 2 : (BN == 192 ? (p == 0 ? 4 : 1 + (p == 1)) : 3); }
+    // BN = 192: slots free at the start of (kt,0): all of A(kt), B(kt,0) [read in (kt-1,2)]; B(kt,1) is read in (kt,0), B(kt,2) in (kt,1).
+    //   p0 issues A (4); p1 issues B phase 0 and B phase 1 (2: both free by then); p2 issues B phase 2 (1).
+    //   reads in (kt+1,2) [A(kt+2), B(kt+2,0)]: issued (kt,0), (kt,1)#1 -> behind them (kt,1)#2, (kt,2), (kt+1,0), (kt+1,1) = 1+1+4+2 = 8 at the end of (kt+1,1)
+    //   reads in (kt+2,0) [B(kt+2,1)]: issued (kt,1)#2 -> behind it (kt,2), (kt+1,0), (kt+1,1), (kt+1,2) = 1+4+2+1 = 8 at the end of (kt+1,2)... that wait is p2's
+    //   reads in (kt+2,1) [B(kt+2,2)]: issued (kt,2)   -> behind it (kt+1,0..2), (kt+2,0) = 4+2+1+4 = 11 at the end of (kt+2,0) -> 10 (even, conservative)
+    // BN = 128 (three buffers, K-tile kt+3): reads in (kt+2,1) [A(kt+3), B(kt+3,0)]: issued (kt,0), (kt,1) -> behind them (kt+1,0), (kt+1,1), (kt+2,0) = 9
+    //   at the end of (kt+2,0); reads in (kt+3,0) [B(kt+3,1)]: issued (kt,1) -> (kt+1,0) .. (kt+2,1) = 12 at the end of (kt+2,1)
+    __host__ __device__ static constexpr int wait(int p) { return BN == 256 ? 8 : (BN == 192 ? (p == 0 ? 10 : 8) : (p == 0 ? 9 : 12)); }
+    // is piece jj of phase p a B piece; its index among the operand's 1 KB pieces (8 rows x 128 B) for wave w
+    __host__ __device__ static constexpr bool is_b(int p, int jj) { return BN == 256 ? p >= 2 : (BN == 192 ? p >= 1 : jj == 2); }
+    __device__ static int piece(int p, int jj, int w) {
+        const int bh = (w >> 2) * (TN / 8) + (w & 3);                  // + 4 * phase: this wave's piece of a phase's B columns (both halves of the tile)
+        if (BN == 256) { const int q = w * 2 + jj; return p == 0 ? q : (p == 1 ? 16 + q : (p == 2 ? q + (q & 8) : q + 8 + (q & 8))); }
+        if (BN == 192) return p == 0 ? w * 4 + jj : (p == 1 ? bh + 4 * jj : bh + 8);
+        return jj < 2 ? p * 16 + w * 2 + jj : bh + 4 * p;
+    }
+};
+
 template <typename T, int BN, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int persistent) {
-    static_assert(BN == 256, "interleaved schedule: 256 x 256 tile");
     using C = P8<BN>;
+    using P = I8<BN>;
+    constexpr int NPH = P::NPH, NBUF = P::NBUF, GPP = BN == 256 ? 2 : (BN == 192 ? 4 : 3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -479,63 +516,64 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int per
         return which;
     };
 
-    // ---- the DMA stream: staging group gi = the phase that issues it (0: A rows 0-127, 1: A rows 128-255, 2: B phases 0,1, 3: B phases 2,3),
-    // two pieces per wave and group; its n-th issue is for global K-tile n (K-tiles numbered over the work list).  issue() is
-    // branch-free (it sits between the MFMAs of a phase); advance() moves the group to its next K-tile afterwards.  Past the end of
-    // the work list a group keeps issuing (into slots nobody reads any more, from the first tile's rows): every phase issues two
-    // pieces per wave, so the counted wait is the same constant everywhere and the K loop has no tail case.
+    // ---- the DMA stream: staging group p = the phase that issues it; its n-th issue is for global K-tile n (K-tiles numbered over the
+    // work list).  issue() is branch-free (it sits between the MFMAs of a phase); advance() moves the group to its next K-tile afterwards.
+    // Past the end of the work list a group keeps issuing (into slots nobody reads any more, from the first tile's rows): every phase
+    // issues its fixed number of pieces, so the counted waits are constants and the K loop has no tail case.
+    // A piece's source = the operand's base pointer + K offset (wave-uniform: scalar registers) + a per-lane 32-bit byte offset.
     const int lrow = lane >> 3, lslot = lane & 7;
-    // a piece's source = the operand's base pointer + K offset (both wave-uniform: scalar registers) + a per-lane 32-bit byte offset
-    const char* gbase[4];
-    unsigned voff[4][2];
-    int g_rem[4], g_tile[4], g_inc[4];
-    auto piece = [&](int gi, int jj) -> int {
-        const int q = w * 2 + jj;
-        return gi == 0 ? q : (gi == 1 ? 16 + q : (gi == 2 ? q + (q & 8) : q + 8 + (q & 8)));
-    };
-    auto rebase = [&](auto gc_, int id) {
-        constexpr int gi = decltype(gc_)::value;
+    const char* gA[NPH];
+    const char* gB[NPH];
+    unsigned voff[NPH][GPP];
+    int g_rem[NPH], g_tile[NPH], g_inc[NPH];
+    auto rebase = [&](auto pc_, int id) {
+        constexpr int p = decltype(pc_)::value;
         int m0, n0;
         const GemmNTArgs& a = g.p[tile_origin(id, m0, n0)];
-        gbase[gi] = gi >= 2 ? (const char*)a.B : (const char*)a.A;
+        gA[p] = (const char*)a.A;
+        gB[p] = (const char*)a.B;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int pc = piece(gi, jj), row = pc * 8 + lrow;
-            if (gi >= 2) {
+        for (int jj = 0; jj < P::cnt(p); ++jj) {
+            const int pc = P::piece(p, jj, w), row = pc * 8 + lrow;
+            if (P::is_b(p, jj)) {
                 const int sw = (lrow & 3) | ((pc & 1) << 2);
-                voff[gi][jj] = ((unsigned)(n0 + row) * (unsigned)a.ldb + (unsigned)((lslot ^ sw) * 8)) * 2u;
+                voff[p][jj] = ((unsigned)(n0 + row) * (unsigned)a.ldb + (unsigned)((lslot ^ sw) * 8)) * 2u;
             } else {
                 const int gm = min(m0 + row, a.M - 1);          // rows past M read a valid row, never stored
-                voff[gi][jj] = ((unsigned)gm * (unsigned)a.lda + (unsigned)((lslot ^ lrow) * 8)) * 2u;
+                voff[p][jj] = ((unsigned)gm * (unsigned)a.lda + (unsigned)((lslot ^ lrow) * 8)) * 2u;
             }
         }
     };
-    auto issue = [&](auto gc_, const char* buf) {          // the group's two pieces into K-tile buffer `buf`
-        constexpr int gi = decltype(gc_)::value;
+    auto issue = [&](auto pc_, const char* buf) {          // the phase's pieces into K-tile buffer `buf`
+        constexpr int p = decltype(pc_)::value;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-            __builtin_amdgcn_global_load_lds(MM_GLB(gbase[gi] + voff[gi][jj]), MM_LDS(buf + (gi >= 2 ? C::A_BYTES : 0) + piece(gi, jj) * 1024), 16, 0, 0);
+        for (int jj = 0; jj < P::cnt(p); ++jj) {
+            const char* src = (P::is_b(p, jj) ? gB[p] : gA[p]) + voff[p][jj];
+            __builtin_amdgcn_global_load_lds(MM_GLB(src), MM_LDS(buf + (P::is_b(p, jj) ? C::A_BYTES : 0) + P::piece(p, jj, w) * 1024), 16, 0, 0);
+        }
     };
-    auto advance = [&](auto gc_) {
-        constexpr int gi = decltype(gc_)::value;
-        if (--g_rem[gi] == 0) {
-            g_rem[gi] = nk;
-            g_tile[gi] += 1;
-            const bool live = g_tile[gi] < count;
-            g_inc[gi] = live ? 128 : 0;
-            rebase(gc_, first + (live ? g_tile[gi] : 0) * stride);
+    auto advance = [&](auto pc_) {
+        constexpr int p = decltype(pc_)::value;
+        if (--g_rem[p] == 0) {
+            g_rem[p] = nk;
+            g_tile[p] += 1;
+            const bool live = g_tile[p] < count;
+            g_inc[p] = live ? 128 : 0;
+            rebase(pc_, first + (live ? g_tile[p] : 0) * stride);
         } else {
-            gbase[gi] += g_inc[gi];
+            gA[p] += g_inc[p];
+            gB[p] += g_inc[p];
         }
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<int, 2> I2;
     typedef std::integral_constant<int, 3> I3;
-    auto init_group = [&](auto gc_) {
-        constexpr int gi = decltype(gc_)::value;
-        g_rem[gi] = nk; g_tile[gi] = 0; g_inc[gi] = 128;
-        rebase(gc_, first);
+    auto for_phases = [&](auto&& f) {
+        f(I0{});
+        f(I1{});
+        if constexpr (NPH >= 3) f(I2{});
+        if constexpr (NPH == 4) f(I3{});
     };
 
     f32x4 acc[4][C::FN];
@@ -547,13 +585,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int per
     };
     zero_acc();
 
-    // fragment read offsets (layout of gemm_nt8_kernel): A row = wm*64 + 16 i + (lane&15); B (permuted) row = wn*128 + 32 p + 8((lane&15)>>2) + 4 h + (lane&3);
+    // fragment read offsets (layout of gemm_nt8_kernel): A row = wm*64 + 16 i + (lane&15); B (permuted) row = wn*TN + 32 p + 8((lane&15)>>2) + 4 h + (lane&3);
     // 16-byte chunk = (kk*4 + (lane>>4)) ^ (lane&7)
     const int l15 = lane & 15, kc = lane >> 4, sw7 = lane & 7;
     const int a_row_off = (wm * 64 + l15) * 128;
     const int b_row_off = C::A_BYTES + (wn * C::TN + 8 * (l15 >> 2) + (lane & 3)) * 128;
     const int ch[2] = {((0 * 4 + kc) ^ sw7) << 4, ((1 * 4 + kc) ^ sw7) << 4};
-    v8 af[4][2], bf[2][2][2];          // A fragments [i][kk] (reloaded in place in a K-tile's last phase); B [phase parity][h][kk]
+    v8 af[4][2], bf[2][2][2];          // A fragments [i][kk] (reloaded in place in a K-tile's last phase); B [set][h][kk], sets alternate by phase
     auto read_b = [&](auto set_, const char* Ks, int p) {
         constexpr int set = decltype(set_)::value;
 #pragma unroll
@@ -564,32 +602,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int per
     // the builtin, not inline asm: hipcc's own wait insertion then knows that nothing is outstanding on the LGKM counter and puts no
     // `lgkmcnt(0)` of its own in front of the next phase's first MFMA (behind that phase's first fragment requests)
     auto lgkm0 = [&]() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };
-    auto phase_end = [&]() {
-        wait_vm<8>();                      // everything issued five or more phases ago has landed (this wave's pieces)
-        lgkm0();                           // this wave's fragment requests are back: the slots they read may be restaged after the barrier
-        raw_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
 
-    // ---- the bias vectors of the launch's problems into LDS behind the K-tile buffers (`persistent & 2`: the launcher reserved the room)
+    // ---- the bias vectors of the launch's problems into LDS behind the K-tile buffers
     float* lds_bias_all = reinterpret_cast<float*>(smem + C::LDS);
-    {
-        for (int pi = 0; pi < g.count; ++pi) {
-            const GemmNTArgs& a = g.p[pi];
-            if (!(a.flags & GEMM_BIAS)) {
-                for (int c = tid * 4; c < a.N; c += 2048) *reinterpret_cast<f32x4*>(lds_bias_all + pi * a.N + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
-                for (int c = tid * 4; c < a.N; c += 2048) *reinterpret_cast<f32x4*>(lds_bias_all + pi * a.N + c) = *reinterpret_cast<const f32x4*>(a.bias + c);
-            }
+    for (int pi = 0; pi < g.count; ++pi) {
+        const GemmNTArgs& a = g.p[pi];
+        if (!(a.flags & GEMM_BIAS)) {
+            for (int c = tid * 4; c < a.N; c += 2048) *reinterpret_cast<f32x4*>(lds_bias_all + pi * a.N + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            for (int c = tid * 4; c < a.N; c += 2048) *reinterpret_cast<f32x4*>(lds_bias_all + pi * a.N + c) = *reinterpret_cast<const f32x4*>(a.bias + c);
         }
     }
-    // ---- prologue: what phases (-2,0) .. (-1,3) would have issued: K-tiles 0 and 1
-    init_group(I0{}); init_group(I1{}); init_group(I2{}); init_group(I3{});
-    issue(I0{}, smem); issue(I1{}, smem); issue(I2{}, smem); issue(I3{}, smem);
-    advance(I0{}); advance(I1{}); advance(I2{}); advance(I3{});
-    issue(I0{}, smem + C::KT); issue(I1{}, smem + C::KT); issue(I2{}, smem + C::KT); issue(I3{}, smem + C::KT);
-    advance(I0{}); advance(I1{}); advance(I2{}); advance(I3{});
-    wait_vm<10>();                         // A and the B columns of phases 0,1 of K-tile 0: behind them group 3 (2 pieces) and K-tile 1 (8)
+    // ---- prologue: K-tiles 0 .. NBUF-1, i.e. what the phases of K-tiles -NBUF .. -1 would have issued
+    for_phases([&](auto pc_) { constexpr int p = decltype(pc_)::value; g_rem[p] = nk; g_tile[p] = 0; g_inc[p] = 128; rebase(pc_, first); });
+#pragma unroll
+    for (int b = 0; b < NBUF; ++b) for_phases([&](auto pc_) { issue(pc_, smem + b * C::KT); advance(pc_); });
+    wait_vm<(NBUF - 1) * P::PIECES>();          // K-tile 0 has landed
     raw_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -600,64 +628,77 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int per
     raw_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
-    int gkt = 0;
+    int cb = 0;                                  // buffer of the current K-tile
     for (int t = 0; t < count; ++t) {
-#pragma unroll 1
-        for (int k = 0; k < nk; ++k, ++gkt) {
-            const char* Ks = smem + (gkt & 1) * C::KT;          // this K-tile; also the buffer K-tile gkt + 2 is staged into
-            const char* Kn = smem + ((gkt + 1) & 1) * C::KT;
-            // ---- phases 0-2: request the B fragments of the next phase, issue the phase's two pieces, 16 MFMAs
-            auto phase = [&](auto pc_) {
+        // one K-tile; S0 = the B register set its phase 0 multiplies (sets alternate by phase: with three phases per K-tile also by K-tile)
+        auto ktile = [&](auto s0_) {
+            constexpr int S0 = decltype(s0_)::value;
+            const int nb = cb + 1 == NBUF ? 0 : cb + 1;
+            const char* Ks = smem + cb * C::KT;          // this K-tile; also the buffer K-tile + NBUF is staged into
+            const char* Kn = smem + nb * C::KT;
+            cb = nb;
+            for_phases([&](auto pc_) {
                 constexpr int p = decltype(pc_)::value;
-                constexpr int bs = p & 1;
-                read_b(std::integral_constant<int, bs ^ 1>{}, Ks, p + 1);
-                issue(pc_, Ks);
+                constexpr int bs = (S0 + p) & 1;
+                constexpr int nd = P::cnt(p);
+                if constexpr (p < NPH - 1) {
+                    // request the B fragments of the next phase, issue the phase's pieces, 16 MFMAs
+                    read_b(std::integral_constant<int, bs ^ 1>{}, Ks, p + 1);
+                    issue(pc_, Ks);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) acc[i][2 * p + h] = mfma16(bf[bs][h][kk], af[i][kk], acc[i][2 * p + h]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                advance(pc_);
-                phase_end();
-            };
-            phase(I0{});
-            phase(I1{});
-            phase(I2{});
-            // ---- phase 3: the next K-tile's B fragments of phase 0 (other register set) and its A fragments, each A fragment into the
-            // registers of the one whose last two MFMAs have just been issued
-            {
-                read_b(I0{}, Kn, 0);
-                issue(I3{}, Ks);
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) acc[i][6 + h] = mfma16(bf[1][h][kk], af[i][kk], acc[i][6 + h]);
-                        af[i][kk] = lds_read8<T>(Kn, a_row_off + i * (16 * 128) + ch[kk]);
-                    }
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
+                            for (int h = 0; h < 2; ++h) acc[i][2 * p + h] = mfma16(bf[bs][h][kk], af[i][kk], acc[i][2 * p + h]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if (r == 1 || r == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+                    for (int d = 0; d < nd; ++d) {
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, nd <= 2 ? 4 : 2, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 12 - (nd <= 2 ? 4 : 2) * nd, 0);
+                } else {
+                    // last phase: the next K-tile's B fragments of phase 0 (other register set) and its A fragments, each A fragment into
+                    // the registers of the one whose last two MFMAs have just been issued
+                    read_b(std::integral_constant<int, bs ^ 1>{}, Kn, 0);
+                    issue(pc_, Ks);
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) acc[i][2 * p + h] = mfma16(bf[bs][h][kk], af[i][kk], acc[i][2 * p + h]);
+                            af[i][kk] = lds_read8<T>(Kn, a_row_off + i * (16 * 128) + ch[kk]);
+                        }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (r < nd * 2 && (r & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
                 }
-                advance(I3{});
-                phase_end();
-            }
+                advance(pc_);
+                wait_vm<P::wait(p)>();             // every slot the next phase requests has landed (this wave's pieces)
+                lgkm0();                           // this wave's fragment requests are back: the slots they read may be restaged after the barrier
+                raw_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        if constexpr (NPH & 1) {
+            int k = 0;
+#pragma unroll 1
+            for (; k + 2 <= nk; k += 2) { ktile(I0{}); ktile(I1{}); }
+            if (k < nk) ktile(I0{});
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < nk; ++k) ktile(I0{});
         }
-        // ---- epilogue of tile t from the accumulators (register epilogue of gemm_nt8_kernel).  The fragments requested in the last
-        // phase belong to the next tile's first K-tile when there is one.
+        // ---- epilogue of tile t from the accumulators (register epilogue of gemm_nt8_kernel, bias from LDS)
         int m0, n0;
         const int which = tile_origin(first + t * stride, m0, n0);
         const GemmNTArgs& a = g.p[which];
@@ -666,7 +707,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int per
         if (t + 1 < count) {
             // the fragments requested in the tile's last phase are not kept across the epilogue (it needs the registers): request the
             // next tile's first fragments again; the barrier keeps a faster wave's next LDS-DMA off slots this wave has not read yet
-            const char* Ks = smem + (gkt & 1) * C::KT;
+            const char* Ks = smem + cb * C::KT;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -765,7 +806,7 @@ static void launch_nt8i_e(const GemmNTPair& g, int persistent, hipStream_t s) {
 // epilogue class that covers a flag set (a pair uses the class that covers both)
 static int nt8_class(int f) {
     f &= ~(GEMM_DEBUG_TS | GEMM_DEBUG_CYC);
-    if (f == (GEMM_BIAS | GEMM_GELU) || f == (GEMM_BIAS | GEMM_GELU | GEMM_AUX_PRE)) return EP_GELU;
+    if (f == (GEMM_BIAS | GEMM_GELU) || f == (GEMM_BIAS | GEMM_GELU | GEMM_AUX_PRE) || f == (GEMM_BIAS | GEMM_QGELU)) return EP_GELU;
     if (f == GEMM_MUL_GELU_GRAD || f == (GEMM_MUL_GELU_GRAD | GEMM_RESIDUAL)) return EP_MULG;
     if (!(f & ~(GEMM_BIAS | GEMM_DROPOUT | GEMM_RESIDUAL))) return EP_PLAIN;
     return EP_ANY;
@@ -789,9 +830,16 @@ static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
     else launch_nt8_e<T, BN, EP_ANY>(g, persistent, s);
 }
 static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent, hipStream_t s) {
-    if (bn == 257) {             // 256 x 256, interleaved schedule
-        if (dtype == DT_BF16) launch_nt8i_t<bf16_t, 256>(g, persistent, s);
-        else launch_nt8i_t<f16_t, 256>(g, persistent, s);
+    if (bn == 257 || bn == 193 || bn == 129) {             // interleaved schedule, 256 x 256 / 192 / 128
+        if (dtype == DT_BF16) {
+            if (bn == 257) launch_nt8i_t<bf16_t, 256>(g, persistent, s);
+            else if (bn == 193) launch_nt8i_t<bf16_t, 192>(g, persistent, s);
+            else launch_nt8i_t<bf16_t, 128>(g, persistent, s);
+        } else {
+            if (bn == 257) launch_nt8i_t<f16_t, 256>(g, persistent, s);
+            else if (bn == 193) launch_nt8i_t<f16_t, 192>(g, persistent, s);
+            else launch_nt8i_t<f16_t, 128>(g, persistent, s);
+        }
         return;
     }
     if (dtype == DT_BF16) {
@@ -805,15 +853,18 @@ static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent,
     }
 }
 
-// bn: 256, 192 or 128 (two-interval schedule); 257 = 256 x 256 with the interleaved schedule.  Returns false when the shape rules of
-// the kernel do not hold (caller falls back).
-// interleaved kernel: bias vector(s) in LDS behind the two 64 KB K-tile buffers; 32-bit byte offsets into the operands
-static bool nt8i_ok(const GemmNTArgs& a, int nprob) {
-    return (size_t)a.N * 4 * nprob <= 32 * 1024 && (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldb * 2 < (1ull << 32);
+// bn: 256, 192 or 128 (two-interval schedule); 257 / 193 / 129 = the same tiles with the interleaved schedule.  Returns false when the
+// shape rules of the kernel do not hold (caller falls back).
+// interleaved kernel: bias vector(s) in LDS behind the K-tile buffers; 32-bit byte offsets into the operands
+static bool nt8i_ok(const GemmNTArgs& a, int nprob, int bn) {
+    const size_t lds = (bn == 256 ? P8<256>::LDS : (bn == 192 ? P8<192>::LDS : P8<128>::LDS)) + (size_t)a.N * 4 * nprob;
+    return lds <= 160 * 1024 && (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldb * 2 < (1ull << 32);
 }
 bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hipStream_t s) {
-    if (bn == 257 && !nt8i_ok(a, 1)) bn = 256;
-    if ((bn != 257 && bn != 256 && bn != 192 && bn != 128) || !nt8_ok(a, bn == 257 ? 256 : bn)) return false;
+    const bool il = bn == 257 || bn == 193 || bn == 129;
+    if (il && !nt8i_ok(a, 1, bn - 1)) bn -= 1;
+    const int w = (bn == 257 || bn == 193 || bn == 129) ? bn - 1 : bn;
+    if ((w != 256 && w != 192 && w != 128) || !nt8_ok(a, w)) return false;
     GemmNTPair g;
     g.p[0] = a; g.p[1] = a; g.count = 1;
     launch_nt8_d(g, dtype, bn, persistent, s);

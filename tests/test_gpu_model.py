@@ -147,6 +147,68 @@ def test_train_losses_and_grads_match_reference_golden(dtype, path):
         assert float(np.median(list(worst.values()))) < TOL_GRAD_MEDIAN[dtype], (mix, sorted(worst.values()))
 
 
+# per-tensor bounds against the ROUNDING-EMULATING oracle (oracle/mm_oracle.py `rounding`): an fp32 execution that rounds both operands of
+# every tower matrix product, every stored activation and every stored gradient to the dtype where the HIP path does.  What is left
+# between the two is the noise of single rounding decisions (fp32 summation order flips an operand by one 16-bit ulp), not twelve layers
+# of operand rounding -- so the 16-bit backward is pinned per tensor an order of magnitude tighter than against fp32 (TOL_GRAD).
+TOL_EMU_OUT = {"bf16": 8e-3, "f16": 1.2e-3}
+TOL_EMU_GRAD = {"bf16": 6e-2, "f16": 1e-2}
+TOL_EMU_GRAD_MEDIAN = {"bf16": 2e-2, "f16": 3e-3}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_16bit_modes_track_the_rounding_emulating_oracle(dtype):
+    z, cfg = load("train_small_xlmr.npz")
+    B, T = int(z["B"]), int(z["T"])
+    model = build(cfg, dtype, "bernice", B, T)
+    P0 = O.make_params(cfg, int(z["seed_w"]))
+    load_oracle_params(model, P0)
+    model.train()
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, B, T, int(z["seed_x"]), True)
+    w = t(z, "class_weight")
+    dev = model.device_
+    from smtc_amd import _lib
+    for mix, (itc, itm) in {"plain": (False, False), "itcitm": (True, True)}.items():
+        tim = (t(z, "tim_ids"), t(z, "tim_mask")) if itm else None
+        bi, bm = (0.1 if itc else 0.0), (0.1 if itm else 0.0)
+        model._flat_grad.zero_()
+        ti, tm_ = tim if tim else (None, None)
+        outs = model._engine_forward(ids, mask, pixels, ti, tm_)
+        lo = torch.empty(4, device=dev)
+        oh, cw, lt = onehot.to(dev).contiguous(), w.to(dev), t(z, "lbl_tim").to(dev)
+        _lib.check(_lib.lib().mmhip_loss(model._handle, _lib.ptr(oh), _lib.ptr(cw), _lib.ptr(lt) if itm else None, 1.0 - bi - bm, bi, bm,
+                                         _lib.ptr(lo), None, _lib.stream_ptr()))
+        _lib.check(_lib.lib().mmhip_backward(model._handle, None, None, None, None, _lib.stream_ptr()))
+        grads = {i["name"]: model._flat_grad[i["offset"]: i["offset"] + i["numel"]].view(i["shape"]).detach().float().cpu().clone() for i in model._train_params}
+        # the emulation: same parameters, same batch, the dtype's rounding policy (f16: gradients carried x 1024, as engine.hip gscale())
+        P = {k: v.clone().requires_grad_(O.trainable(k)) for k, v in P0.items()}
+        with O.rounding(dtype):
+            r_cls, r_lpt, r_tim, _, r_feats = O.mm_forward(P, ids, mask, pixels, cfg, tim)
+            ref = O.mix_loss(r_cls, onehot, w, r_lpt, r_tim, t(z, "lbl_tim"), itc, itm)
+            ref.backward()
+        assert abs(lo[0].item() - ref.item()) < 5e-4 * abs(ref.item()), (mix, lo[0].item(), ref.item())
+        got_out = {"out_cls": outs[0], "logits_per_text": outs[1], "mm_features": outs[3]}
+        ref_out = {"out_cls": r_cls, "logits_per_text": r_lpt, "mm_features": r_feats}
+        if itm:
+            got_out["out_tim"], ref_out["out_tim"] = outs[2], r_tim
+        oerr = {k: rel_err(got_out[k], ref_out[k].detach()) for k in got_out if got_out[k] is not None}
+        print("EMU_OUT", dtype, mix, {k: float("%.3g" % e) for k, e in oerr.items()})
+        gerr = {}
+        for k in (str(s_) for s_ in z["watch"]):
+            if P[k].grad is None or k.endswith("key.bias"):
+                continue
+            r = P[k].grad
+            if r.norm().item() == 0.0:
+                continue
+            gerr[k] = (grads[k] - r).norm().item() / r.norm().item()
+        print("EMU_GRAD", dtype, mix, {k: float("%.3g" % e) for k, e in gerr.items()})
+        for k, e in oerr.items():
+            assert e < TOL_EMU_OUT[dtype], (mix, k, e)
+        for k, e in gerr.items():
+            assert e < TOL_EMU_GRAD[dtype], (mix, k, e)
+        assert float(np.median(list(gerr.values()))) < TOL_EMU_GRAD_MEDIAN[dtype], (mix, sorted(gerr.values()))
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "bf16x3"])
 def test_dropout_train_step_matches_oracle_with_replayed_masks(dtype):
     """dropout ON: the oracle replays the kernels' counter-based masks (same hash), so loss and gradients must agree"""

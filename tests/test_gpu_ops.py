@@ -78,14 +78,18 @@ def _gemm_ref(A, B, bias, act, resid, mulg, keep, scale):
                                         (200, 192, 64, 272), (1000, 768, 768, 272), (8192, 3072, 768, 272), (12608, 768, 3072, 272), (300, 384, 128, 272),
                                         (8192, 3072, 768, 288), (12608, 768, 768, 288), (8192, 3072, 64, 288), (70000, 192, 128, 288), (16384, 2304, 192, 288),
                                         (200, 256, 64, 304), (1000, 768, 768, 304), (8192, 2304, 768, 304), (300, 512, 128, 304), (256, 256, 320, 304),
-                                        (8192, 3072, 768, 320), (12608, 2304, 768, 320), (8192, 3072, 64, 320), (70000, 256, 128, 320), (35000, 256, 192, 320),])
+                                        (8192, 3072, 768, 320), (12608, 2304, 768, 320), (8192, 3072, 64, 320), (70000, 256, 128, 320), (35000, 256, 192, 320),
+                                        (200, 192, 64, 336), (1000, 768, 768, 336), (8192, 2304, 768, 336), (300, 384, 128, 336), (256, 192, 320, 336),
+                                        (8192, 3072, 768, 352), (12608, 2304, 768, 352), (8192, 3072, 64, 352), (70000, 192, 128, 352), (35000, 384, 192, 352),
+                                        (200, 128, 64, 368), (1000, 768, 768, 368), (8192, 2304, 768, 368), (300, 384, 128, 368), (256, 128, 320, 368),
+                                        (8192, 3072, 768, 384), (12608, 768, 768, 384), (8192, 3072, 64, 384), (40000, 128, 64, 384), (35000, 128, 192, 384)])
 def test_gemm_nt_epilogues(dt, M, N, K, slow):
     """`slow`: bit 0 forces the generic kernel, bits 4.. pick the tile variant (16 = 128x128, 32 = 256x128, 48 = 256x256,
     64 = 128x128 4-stage ring, 80 = 256x128 3-stage ring, 96 = 128x192, 112 = 256x192,
     128 / 144 = role-specialised 128x128 / 256x128: MFMA waves + LDS-DMA loader waves, 160 = 128x96, 176 = 160x128, 192 = role-specialised 256x96,
     208 / 224 = deep-pipelined 256x256 / 256x128 (gemm8.hip: counted vmcnt across raw barriers, register epilogue), 240 / 256 = the same, persistent,
-    272 / 288 = deep-pipelined 256x192, one-shot / persistent, 304 / 320 = 256x256 with the interleaved K-loop schedule (gemm_nt8i_kernel),
-    one-shot / persistent)"""
+    272 / 288 = deep-pipelined 256x192, one-shot / persistent, 304 / 320, 336 / 352, 368 / 384 = 256x256, 256x192, 256x128 with the interleaved K-loop
+    schedule (gemm_nt8i_kernel), one-shot / persistent)"""
     code, tdt = DT[dt]
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = (torch.randn(M, K, generator=g) * 0.5).to(tdt).to(dev())

@@ -201,3 +201,48 @@ def test_lxmert_oracle_matches_reference(golden_dir):
             assert sorted(str(k) for k in z["no_grad"]) == sorted(k for k, v in Pg.items() if v.grad is None) == ["model.pooler.dense.bias", "model.pooler.dense.weight"]
             # padding_idx=0 on all three embedding tables: position 0 and token type 0 receive no gradient
             assert not Pg["model.embeddings.position_embeddings.weight"].grad[0].any() and not Pg["model.embeddings.token_type_embeddings.weight"].grad[0].any()
+
+
+def test_rounding_emulation_policies(golden_dir):
+    """oracle `rounding`: policy None is the pinned fp32 oracle bit for bit; the 16-bit policies deviate from the reference golden by what
+    twelve layers of operand / storage rounding cost (the magnitudes the HIP modes measure on MI355X); hi+lo bf16 pairs on
+    both operands (the bf16x3 parity mode's products) stay at fp32 level."""
+    z, cfg = load(golden_dir, "fwd_small_xlmr.npz")
+    P = O.make_params(cfg, int(z["seed_w"]))
+    ids, mask, pixels, _ = O.synthetic_batch(cfg, int(z["B"]), int(z["T"]), int(z["seed_x"]), bool(z["pad"]))
+    tim = (t(z, "tim_ids"), t(z, "tim_mask"))
+
+    def run(**kw):
+        with torch.no_grad(), O.rounding(**kw):
+            o = O.mm_forward(P, ids, mask, pixels, cfg, tim)
+        return {"out_cls": o[0], "logits_per_text": o[1], "out_tim": o[2], "mm_features": o[4]}
+
+    with torch.no_grad():
+        base = O.mm_forward(P, ids, mask, pixels, cfg, tim)
+    none = run(round_operands=None)
+    assert all(torch.equal(none[k], b) for k, b in zip(("out_cls", "logits_per_text", "out_tim"), base[:3]))
+    err = lambda o: max((o[k] - t(z, k)).abs().max().item() / t(z, k).abs().max().item() for k in o)
+    e_bf16, e_f16 = err(run(round_operands="bf16")), err(run(round_operands="f16"))
+    e_x3 = err(run(round_operands=None, op_a="bf16x2", op_w="bf16x2"))
+    assert 1e-3 < e_bf16 < 6e-2 and 1e-4 < e_f16 < 8e-3 and e_f16 < e_bf16, (e_bf16, e_f16)
+    assert e_x3 < 1e-4, e_x3
+
+
+def test_rounding_emulation_gradients_are_finite_and_close(golden_dir):
+    """backward through the rounding policy (straight-through rounding of stored activations, gradient rounding, gelu' of the stored
+    pre-activation): gradients stay within the 16-bit band of the fp32 reference gradients"""
+    z, cfg = load(golden_dir, "train_small_xlmr.npz")
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, int(z["B"]), int(z["T"]), int(z["seed_x"]), True)
+    w = t(z, "class_weight")
+    for dtype, band in (("bf16", 0.6), ("f16", 0.05)):
+        P = {k: v.requires_grad_(O.trainable(k)) for k, v in O.make_params(cfg, int(z["seed_w"])).items()}
+        with O.rounding(dtype):
+            out_cls, lpt, out_tim, _, _ = O.mm_forward(P, ids, mask, pixels, cfg, None)
+            O.mix_loss(out_cls, onehot, w, lpt, out_tim, None, False, False).backward()
+        for k in (str(s) for s in z["watch"]):
+            key = f"plain.gnorm.{k}"
+            if key not in z.files or k.endswith("key.bias") or P[k].grad is None:
+                continue
+            g = P[k].grad
+            assert torch.isfinite(g).all(), k
+            assert abs(g.norm().item() - float(z[key])) / float(z[key]) < band, (dtype, k)

@@ -35,6 +35,10 @@ POLICIES = [
     ("bf16, fp32 residual stream", dict(round_operands="bf16", st_resid=None), 1),
     ("bf16, hi+lo activations at the LN outputs only (A operand 2 passes where A is an LN output)", dict(round_operands="bf16", st_ln="bf16x2", st_resid=None), 1.5),
     ("bf16 weights, hi+lo (16-bit-mantissa) activations everywhere: 2 passes", dict(round_operands=None, op_a="bf16x2", op_w="bf16", st_act="bf16x2", st_resid=None, st_ln="bf16x2"), 2),
+    ("f16 activations (stored f16), f16 hi+lo weights: 2 passes", dict(round_operands="f16", op_w="f16x2"), 2),
+    ("f16 operand rounding of fp32-stored activations, f16 hi+lo weights: 2 passes", dict(round_operands=None, op_a="f16", op_w="f16x2"), 2),
+    ("f16 hi+lo activations (stored fp32), f16 weights: 2 passes", dict(round_operands=None, op_a="f16x2", op_w="f16"), 2),
+    ("f16 activations stored f16 except fp32 LN inputs/outputs, f16 hi+lo weights: 2 passes", dict(round_operands="f16", op_w="f16x2", st_resid=None, st_ln=None), 2),
     ("bf16x3-like: hi+lo activations AND weights (3 passes), fp32 stores", dict(round_operands=None, op_a="bf16x2", op_w="bf16x2"), 3),
 ]
 
