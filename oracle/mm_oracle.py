@@ -547,11 +547,18 @@ def itc_logits(P: Dict[str, Tensor], t_pool: Tensor, v_pool: Tensor) -> Tensor:
     return txt @ img.t() * P["dual_encoder.logit_scale"].exp()
 
 
-def mm_fusion(P: Dict[str, Tensor], x_t: Tensor, x_v: Tensor, cfg: OracleConfig) -> Tensor:
+def _relu(pre: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """ReLU; with `mask` (tests only) the given 0/1 pattern decides which units pass instead of the sign of `pre`: two executions that
+    differ by 16-bit rounding flip units whose pre-activation is near zero, and a per-tensor gradient comparison then measures those
+    flips instead of the backward under test"""
+    return F.relu(pre) if mask is None else pre * mask
+
+
+def mm_fusion(P: Dict[str, Tensor], x_t: Tensor, x_v: Tensor, cfg: OracleConfig, relu_mask: Optional[Tensor] = None) -> Tensor:
     """reference models/mm_late.py:91-113 + Scaled_Dot_Product_Attention :195-210."""
     if cfg.fusion == "concat":
         z = torch.cat((x_t[:, 0, :], x_v[:, 0, :]), dim=1)
-        return F.relu(_lin32(z, P, "linear_fusion"))
+        return _relu(_lin32(z, P, "linear_fusion"), relu_mask)
     if cfg.fusion == "attention":
         N, L, E = x_t.shape
         Q, K, V = _lin32(x_t, P, "fc_Q"), _lin32(x_v, P, "fc_K"), _lin32(x_v, P, "fc_V")
@@ -559,13 +566,13 @@ def mm_fusion(P: Dict[str, Tensor], x_t: Tensor, x_v: Tensor, cfg: OracleConfig)
         att = torch.softmax(Q @ K.permute(0, 2, 1) * scale, dim=-1)
         ctx = (att @ V).view(N, L, E)
         z = torch.cat((x_t[:, 0, :], ctx[:, 0, :]), dim=1)
-        return F.relu(_lin32(z, P, "linear_fusion"))
+        return _relu(_lin32(z, P, "linear_fusion"), relu_mask)
     raise ValueError(cfg.fusion)
 
 
 def mm_forward(P: Dict[str, Tensor], ids: Tensor, mask: Tensor, pixels: Tensor, cfg: OracleConfig,
                tim_inputs: Optional[Tuple[Tensor, Tensor]] = None, drop: Optional[Dropout] = None,
-               collect: Optional[dict] = None):
+               collect: Optional[dict] = None, relu_mask: Optional[Tensor] = None):
     """reference models/mm_late.py:148-193 -> (out_cls, logits_per_text, out_tim, None, mm_features)."""
     drop = drop or Dropout("none")
     cv = collect.setdefault("vit_layers", []) if collect is not None else None
@@ -574,7 +581,7 @@ def mm_forward(P: Dict[str, Tensor], ids: Tensor, mask: Tensor, pixels: Tensor, 
     x_v, v_pool = (clip_vision_forward if cfg.img_kind == "clip" else vit_forward)(P, pixels, cfg, cv)
     x_t, t_pool = text_forward(P, ids, mask, cfg, drop, 0, ct)
     logits_per_text = itc_logits(P, t_pool, v_pool)
-    feats = mm_fusion(P, x_t, x_v, cfg)
+    feats = mm_fusion(P, x_t, x_v, cfg, relu_mask)
     out_cls = _lin32(drop(feats, cfg.p_head, STREAM_HEAD, 0), P, "linear_cls")
     out_tim = None
     if tim_inputs is not None:
