@@ -642,7 +642,7 @@ static int tile_map_lookup(const GemmNTArgs& a) {
     return 0;
 }
 static int choose_nt_tile(const GemmNTArgs& a) {
-    if (!a.grid) { const int m = tile_map_lookup(a); if (m) return m; }
+    { const int m = tile_map_lookup(a); if (m) return m; }
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_NT_TILE"); env = e ? atoi(e) : 0; }
     int t = a.tile ? a.tile : env;

@@ -470,6 +470,7 @@ struct I8 {
     //   at the end of (kt+2,0); reads in (kt+3,0) [B(kt+3,1)]: issued (kt,1) -> (kt+1,0) .. (kt+2,1) = 12 at the end of (kt+2,1)
     __host__ __device__ static constexpr int wait(int p) { return BN == 256 ? 8 : (BN == 192 ? (p == 0 ? 10 : 8) : (p == 0 ? 9 : 12)); }
     // is piece jj of phase p a B piece; its index among the operand's 1 KB pieces (8 rows x 128 B) for wave w
+    __host__ __device__ static constexpr int issued_through(int p) { return p == 0 ? cnt(0) : cnt(p) + issued_through(p - 1); }   // pieces of phases 0 .. p
     __host__ __device__ static constexpr bool is_b(int p, int jj) { return BN == 256 ? p >= 2 : (BN == 192 ? p >= 1 : jj == 2); }
     __device__ static int piece(int p, int jj, int w) {
         const int bh = (w >> 2) * (TN / 8) + (w & 3);                  // + 4 * phase: this wave's piece of a phase's B columns (both halves of the tile)
@@ -629,9 +630,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int per
     __builtin_amdgcn_sched_barrier(0);
 
     int cb = 0;                                  // buffer of the current K-tile
+    constexpr int NST1 = 4 * (C::FN / 2);        // global stores of one output tensor per wave and tile
+    int grace0 = 0;
+    const bool grace_on = !(g.p[0].flags & GEMM_DEBUG_CYC);      // (debug flag reused as an A/B switch: MMHIP_NT8_NOGRACE)
     for (int t = 0; t < count; ++t) {
         // one K-tile; S0 = the B register set its phase 0 multiplies (sets alternate by phase: with three phases per K-tile also by K-tile)
-        auto ktile = [&](auto s0_) {
+        auto ktile = [&](auto s0_, int grace) {
             constexpr int S0 = decltype(s0_)::value;
             const int nb = cb + 1 == NBUF ? 0 : cb + 1;
             const char* Ks = smem + cb * C::KT;          // this K-tile; also the buffer K-tile + NBUF is staged into
@@ -683,7 +687,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int per
                     }
                 }
                 advance(pc_);
-                wait_vm<P::wait(p)>();             // every slot the next phase requests has landed (this wave's pieces)
+                // every slot the next phase requests has landed (this wave's pieces).  In the first K-tile behind an epilogue that only
+                // stored (no residual / gelu' loads), those `grace` stores sit inside the window of pieces that may stay in flight as long
+                // as the window still reaches back to pieces issued before the epilogue: the K loop does not wait for HBM writes
+                if (grace && P::wait(p) > P::issued_through(p)) {
+                    if (grace > NST1) wait_vm<P::wait(p) + 2 * NST1>(); else wait_vm<P::wait(p) + NST1>();
+                } else {
+                    wait_vm<P::wait(p)>();
+                }
                 lgkm0();                           // this wave's fragment requests are back: the slots they read may be restaged after the barrier
                 raw_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -692,11 +703,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int per
         if constexpr (NPH & 1) {
             int k = 0;
 #pragma unroll 1
-            for (; k + 2 <= nk; k += 2) { ktile(I0{}); ktile(I1{}); }
-            if (k < nk) ktile(I0{});
+            for (; k + 2 <= nk; k += 2) { ktile(I0{}, k == 0 ? grace0 : 0); ktile(I1{}, 0); }
+            if (k < nk) ktile(I0{}, k == 0 ? grace0 : 0);
         } else {
 #pragma unroll 1
-            for (int k = 0; k < nk; ++k) ktile(I0{});
+            for (int k = 0; k < nk; ++k) ktile(I0{}, k == 0 ? grace0 : 0);
         }
         // ---- epilogue of tile t from the accumulators (register epilogue of gemm_nt8_kernel, bias from LDS)
         int m0, n0;
@@ -704,6 +715,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int per
         const GemmNTArgs& a = g.p[which];
         tile_epilogue8<T, C::FN, C::TN, EPI, 4, true>(a, acc, m0, n0, wm, wn, l15, kc, lds_bias_all + which * a.N);
         zero_acc();
+        // stores this wave has just issued and nothing else (a full tile: every row store executes): see `grace` in the K loop
+        grace0 = 0;
+        if (grace_on && m0 + C::BM <= a.M) {
+            if (EPI == EP_GELU) grace0 = (a.flags & GEMM_AUX_PRE) ? 2 * NST1 : NST1;
+            else if (EPI == EP_PLAIN && !(a.flags & GEMM_RESIDUAL)) grace0 = NST1;
+        }
         if (t + 1 < count) {
             // the fragments requested in the tile's last phase are not kept across the epilogue (it needs the registers): request the
             // next tile's first fragments again; the barrier keeps a faster wave's next LDS-DMA off slots this wave has not read yet
@@ -798,10 +815,14 @@ static void launch_nt8i_e(const GemmNTPair& g, int persistent, hipStream_t s) {
     for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / BN);
     const int cap = g.p[0].grid > 0 ? (g.p[0].grid < ntiles ? g.p[0].grid : ntiles) : 0;
     const int grid = persistent ? (cap ? cap : nt8_grid(ntiles)) : ntiles;
+    static int nograce = -1;
+    if (nograce < 0) { const char* e = getenv("MMHIP_NT8_NOGRACE"); nograce = e ? atoi(e) : 0; }
+    GemmNTPair gg = g;
+    if (nograce) gg.p[0].flags |= GEMM_DEBUG_CYC;
     // the bias vectors live in LDS behind the K-tile buffers (nt8i_ok: they fit the CU's 160 KB)
     size_t lds = C::LDS;
     for (int i = 0; i < g.count; ++i) lds += (size_t)g.p[i].N * 4;
-    hipLaunchKernelGGL((gemm_nt8i_kernel<T, BN, EPI>), dim3(grid), dim3(512), lds, s, g, persistent && ntiles > grid ? 1 : 0);
+    hipLaunchKernelGGL((gemm_nt8i_kernel<T, BN, EPI>), dim3(grid), dim3(512), lds, s, gg, persistent && ntiles > grid ? 1 : 0);
 }
 // epilogue class that covers a flag set (a pair uses the class that covers both)
 static int nt8_class(int f) {
