@@ -54,7 +54,7 @@ struct mmhip_engine {
     std::vector<TextAct> tact;
     size_t ids_all, mask_all, pos_ids, maskbias, x0, xhat_emb, rstd_emb;
     size_t v_patches, v_pe, v_x, v_ln, v_qkv, v_ctx, v_h, v_out;                             // ViT ping-pong
-    size_t g_partial, g_partial_side;
+    size_t g_partial, g_partial_side, g_det_rows = 0;
     size_t g_lnp[2][2];      // LN-backward partials per (layer parity, LN index): reduced on the side stream with the layer's dW
     uint8_t* word_row_state = nullptr;     // caller-owned row flags of the word table (mmhip_set_row_state)
     size_t g_set[2][6];      // double-buffered backward temporaries read by the side stream: dpre2, ddrop2, du, dpre1, ddrop1, dqkv
@@ -325,6 +325,7 @@ void build_workspace(mmhip_engine& e) {
     e.v_h = w.take(Mv * Iv * Z); e.v_out = w.take(Mv * Hv * Z);
     e.g_dx = w.take(Mt * H * Z); e.g_dx2 = w.take(Mt * H * Z); e.g_dpre = w.take(Mt * H * Z); e.g_ddrop = w.take(Mt * H * Z); e.g_dpre1 = w.take(Mt * H * Z); e.g_ddrop1 = w.take(Mt * H * Z);
     e.g_dqkv = w.take(Mt * 3 * H * Z); e.g_dctx = w.take(Mt * H * Z); e.g_du = w.take(Mt * I * Z);
+    e.g_det_rows = w.take(Mt * H * 4);       // per-slot embedding gradient rows of the deterministic mode (MMHIP_DETERMINISTIC=1)
     e.g_set[0][0] = e.g_dpre; e.g_set[0][1] = e.g_ddrop; e.g_set[0][2] = e.g_du; e.g_set[0][3] = e.g_dpre1; e.g_set[0][4] = e.g_ddrop1; e.g_set[0][5] = e.g_dqkv;
     e.g_set[1][0] = w.take(Mt * H * Z); e.g_set[1][1] = w.take(Mt * H * Z); e.g_set[1][2] = w.take(Mt * I * Z);
     e.g_set[1][3] = w.take(Mt * H * Z); e.g_set[1][4] = w.take(Mt * H * Z); e.g_set[1][5] = w.take(Mt * 3 * H * Z);
@@ -985,6 +986,7 @@ int embed_backward(mmhip_engine& e, hipStream_t s) {
     b.partial = e.wsp<float>(e.g_partial);
     b.alpha = 1.0f / e.gscale();
     b.row_state = e.word_row_state;
+    if (deterministic()) { b.det_rows = e.wsp<float>(e.g_det_rows); b.max_pos = c.max_pos; }
     CHECK_HIP(launch_embed_bwd(b, e.dt(), s));
     return 0;
 }
@@ -1338,8 +1340,8 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
     // of after the whole backward; the layer's fp32 LayerNorm weights and transposed 16-bit copies are read by its own backward
     // kernels on the caller's stream, so the side stream first waits for the event recorded behind them.
     hipStream_t s = (hipStream_t)stream;
-    static int early = -1;
-    if (early < 0) { const char* v = getenv("MMHIP_EARLY_ADAMW"); early = v ? atoi(v) : 1; }
+    const char* early_env = getenv("MMHIP_EARLY_ADAMW");          // read per step: tests compare both orders in one process
+    const int early = early_env ? atoi(early_env) : 1;
     if (int r = mmhip_backward_begin(h, nullptr, nullptr, nullptr, nullptr, stream)) return r;
     const int L = e.cfg.layers_txt;
     const bool layer_opt = early && use_side(e);

@@ -139,7 +139,11 @@ struct EmbedBwdArgs {
     float* partial;       // optional workspace of partial_floats_embed(posts, T, H) floats
     float alpha;          // every parameter gradient is multiplied by alpha (0 is read as 1)
     uint8_t* row_state;   // optional [vocab] row flags of the word table: bit0 is set on every row that receives a gradient
+    float* det_rows;      // optional [posts*T, H] fp32 workspace: deterministic mode -- the per-slot gradient rows are stored here and the
+                          // word / position rows are summed from them in slot order by a second kernel (no fp32 atomics)
+    int max_pos;          // rows of the position table (deterministic mode)
 };
+bool deterministic();     // MMHIP_DETERMINISTIC=1
 hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s);
 hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s);
 

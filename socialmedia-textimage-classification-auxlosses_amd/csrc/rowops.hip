@@ -1,12 +1,22 @@
 // Bandwidth-bound row kernels: LayerNorm fwd/bwd, text-embedding gather + LN (+ its backward scatter), ViT patchify /
 // token assembly, column sums (bias gradients), fp32 -> 16-bit casts (plain and transposed).
 // One wave per row, 8-byte (4 x 16-bit) or 16-byte (4 x fp32) accesses per lane, fp32 arithmetic.
+#include <cstdlib>
 #include "mmhip_common.h"
 #include "mmhip_kernels.h"
 
 namespace mmhip {
 
 static constexpr int MAXC = 4;   // 4-element chunks per lane: width <= 64*4*4 = 1024
+
+// MMHIP_DETERMINISTIC=1 (read at every launch, so a test can flip it): fp32 atomics whose arrival order decides the last bits of a sum
+// are replaced by single-writer sums in a fixed order -- the second stage of the column reductions runs one block per column group, the
+// embedding backward stores its per-slot rows and a second kernel adds the rows of equal word / position id in slot order.  The
+// reference's CPU path is deterministic; the default (atomic) path differs between identical runs by ~3e-8 relative in a gradient.
+bool deterministic() {
+    const char* e = getenv("MMHIP_DETERMINISTIC");
+    return e && atoi(e) != 0;
+}
 
 template <typename T> __device__ __forceinline__ void load4(const T* p, float* v) {
     typename Vec<T>::v4 x = *reinterpret_cast<const typename Vec<T>::v4*>(p);
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
 // block finishes (grid.y-way contention only).
 static constexpr int RP_SPLIT = 8;
 struct ReduceOuts { float* out[3]; };
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial0, int n, int cols, ReduceOuts outs, float alpha) {
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial0, int n, int cols, ReduceOuts outs, float alpha, int single_writer) {
     __shared__ float red[4][64];
     const float* __restrict__ partial = partial0 + (size_t)blockIdx.z * n * cols;     // vector blockIdx.z of [nvec][n][cols]
     float* __restrict__ out = outs.out[blockIdx.z];
@@ -205,14 +215,19 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
     red[w][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (w == 0 && c < cols) atomicAdd(out + c, (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * alpha);
+    if (w == 0 && c < cols) {
+        const float v = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * alpha;
+        if (single_writer) out[c] += v;          // gridDim.y == 1: this block is the column's only writer
+        else atomicAdd(out + c, v);
+    }
 }
 static inline void launch_reduce_partials(const float* partial, int n, int cols, float* out, hipStream_t s, float alpha = 1.0f,
                                           float* out1 = nullptr, float* out2 = nullptr) {
-    const int split = n >= 4 * RP_SPLIT ? RP_SPLIT : 1;
+    const bool det = deterministic();
+    const int split = (!det && n >= 4 * RP_SPLIT) ? RP_SPLIT : 1;
     const int nvec = out2 ? 3 : (out1 ? 2 : 1);
     ReduceOuts o{{out, out1, out2}};
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64, split, nvec), dim3(256), 0, s, partial, n, cols, o, alpha);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64, split, nvec), dim3(256), 0, s, partial, n, cols, o, alpha, det ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------ text embeddings
@@ -355,8 +370,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
         const float c1 = wave_sum(s1) / a.H, c2 = wave_sum(s2) / a.H;
         const int64_t id = a.ids[row];
         const int pid = a.pos_ids[row];
-        float* wrow = (id != a.pad_id) ? a.dword + (size_t)id * a.H : nullptr;
-        const bool pos_on = pid != a.pos_pad_id;
+        float* wrow = (id != a.pad_id && !a.det_rows) ? a.dword + (size_t)id * a.H : nullptr;
+        const bool pos_on = pid != a.pos_pad_id && !a.det_rows;      // deterministic mode: word and position rows are summed by embed_scatter_det_kernel
         if (pos_on && pid0 < 0) pid0 = pid;
         const bool pos_reg = pos_on && pid == pid0;
         float* prow = (pos_on && !pos_reg) ? a.dpos + (size_t)pid * a.H : nullptr;     // irregular slot: direct atomics
@@ -373,9 +388,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
                     ov[e] = o * al;
                 }
                 *reinterpret_cast<f32x4*>(&rowbuf[w][c * 4]) = ov;
+                if (a.det_rows) *reinterpret_cast<f32x4*>(a.det_rows + (size_t)row * a.H + c * 4) = ov;
             }
         }
-        if (wrow && a.row_state && lane == 0)        // 32-bit atomic OR: neighbouring rows' flags share the word
+        if (id != a.pad_id && a.row_state && lane == 0)        // 32-bit atomic OR: neighbouring rows' flags share the word
             atomicOr(reinterpret_cast<unsigned*>(a.row_state) + (id >> 2), 1u << (8 * (int)(id & 3)));
         if (wrow || prow) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -434,6 +450,48 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
             atomicAdd(a.dpos + (size_t)pi * a.H + c, sp);
         }
     }
+}
+
+// deterministic second stage of the embedding backward (MMHIP_DETERMINISTIC=1): rows[slot] = the slot's gradient row (already scaled).
+// Block b < n: slot b adds, in slot order, the rows of every slot with its word id -- if it is the FIRST slot with that id (a scan of the
+// ids in front of it); block n + p: position id p adds the rows of its slots in slot order.  One writer per table row, plain += .
+__global__ __launch_bounds__(64) void embed_scatter_det_kernel(const int64_t* __restrict__ ids, const int* __restrict__ pos_ids, const float* __restrict__ rows,
+                                                               float* __restrict__ dword, float* __restrict__ dpos, int n, int H, int pad_id, int pos_pad_id) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    bool any = false;
+    float* dst;
+    if (b < n) {
+        const int64_t id = ids[b];
+        if (id == pad_id) return;
+        for (int j0 = 0; j0 < b; j0 += 64) {          // an earlier slot with this id owns the sum
+            const int j = j0 + lane;
+            if (__any(j < b && ids[j] == id)) return;
+        }
+        dst = dword + (size_t)id * H;
+        for (int j = b; j < n; ++j) {
+            if (ids[j] != id) continue;               // wave-uniform
+            any = true;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; if (c < H) acc[i] += rows[(size_t)j * H + c]; }
+        }
+    } else {
+        const int p = b - n;
+        if (p == pos_pad_id) return;
+        dst = dpos + (size_t)p * H;
+        for (int j = 0; j < n; ++j) {
+            if (pos_ids[j] != p) continue;
+            any = true;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; if (c < H) acc[i] += rows[(size_t)j * H + c]; }
+        }
+    }
+    if (!any) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; if (c < H) dst[c] += acc[i]; }
 }
 
 // ------------------------------------------------------------------------------------------------ ViT input
@@ -718,6 +776,9 @@ hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s) {
     if (a.partial) {
         launch_reduce_partials(a.partial, (int)(grid.x * grid.y), a.H, a.dgamma, s, a.alpha == 0.f ? 1.f : a.alpha, a.dbeta, a.dtype);
     }
+    if (a.det_rows)
+        hipLaunchKernelGGL(embed_scatter_det_kernel, dim3(a.posts * a.T + a.max_pos), dim3(64), 0, s, a.ids, a.pos_ids, a.det_rows, a.dword, a.dpos,
+                           a.posts * a.T, a.H, a.pad_id, a.pos_pad_id);
     return hipGetLastError();
 }
 hipError_t launch_cast_pad(const float* src, void* dst, int rows, int cols, int ld, int dtype, hipStream_t s) {

@@ -147,6 +147,7 @@ cfg = types.SimpleNamespace(batch_size=4, num_labels=3, use_clip_loss=True, beta
 arch = dict(layers_txt=2, layers_img=1, vocab=300, max_pos=130)
 ids, mask, px, oh = synthetic_batch(300, 3, 4, 64, 77, pad=True)
 os.environ["MMHIP_NATIVE_STEP"] = "0"      # both runs take the staged step, so the gradient can be captured in front of AdamW
+os.environ["MMHIP_DETERMINISTIC"] = "1"    # single-writer reductions: identical runs are bit-identical, so three steps can be compared exactly
 out = []
 for force in ("1", "0"):
     os.environ["MMHIP_FORCE_EXCHANGE"] = force
@@ -166,13 +167,13 @@ for force in ("1", "0"):
             w0 = m._word_info["offset"]
             first = (torch.cat([snap["dense"][:w0], snap["rows"][w0:]]), m._flat_train.clone(), m._word_row_state.clone())
         losses.append(float(loss[0]))
-    out.append((first, losses))
-(g1, p1, r1), l1 = out[0]
-(g0, p0, r0), l0 = out[1]
+    out.append((first, losses, m._flat_train.clone()))
+(g1, p1, r1), l1, f1 = out[0]
+(g0, p0, r0), l0, f0 = out[1]
 gerr = (g1 - g0).abs().max().item()
 perr = (p1 - p0).abs().max().item()
 lerr = max(abs(a - b) / abs(b) for a, b in zip(l1, l0))
-print("RCCL_ERR", gerr, perr, lerr, bool(torch.equal(r1, r0)), torch.distributed.get_backend(), float(g0.abs().max()))
+print("RCCL_ERR", gerr, perr, lerr, bool(torch.equal(r1, r0)), torch.distributed.get_backend(), float(g0.abs().max()), bool(torch.equal(f1, f0)), l1 == l0)
 torch.distributed.destroy_process_group()
 '''
 
@@ -182,17 +183,16 @@ def test_rccl_call_pattern_at_world_size_one(tmp_path):
     forced): the gradient AdamW sees is the one of the run without any collective -- the one-GPU box cannot host two RCCL
     ranks, so this pins the backend's call pattern (slices of the flat gradient, async work handles, int64 / fp32 all_gather)
     and tests/test_dist_cpu.py + the gloo test above pin the arithmetic across ranks.
-    Compared: the step-1 gradient (the fp32 atomics of the LayerNorm / embedding backward make ANY two runs differ by their
-    summation order, ~3e-8 here), the parameters and row flags after that step, and the 3-step loss trajectory.  Parameters
-    after several steps are not compared at 1e-5: a 1e-8 parameter difference now and then flips one bf16 rounding of a CLS
-    activation, which moves the step-3 loss by 1e-4 and -- through Adam's g / sqrt(v) -- elements with near-zero gradient by
-    up to lr (seen in ~15 % of repeated runs, with or without the exchange: tools/dbg_flaky.py)."""
+    Both runs use MMHIP_DETERMINISTIC=1 (round 3: single-writer reductions instead of fp32 atomics in the LayerNorm / embedding
+    backward), so identical arithmetic gives identical bits: compared are the step-1 gradient, the parameters and row flags after
+    that step, and -- exactly -- the parameters and the loss trajectory after three steps."""
     script = tmp_path / "rccl.py"
     script.write_text(RCCL_SCRIPT)
     r = run([sys.executable, str(script)], env={"ROOT": ROOT, "PORT": str(29900 + os.getpid() % 90), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_ERR")][0].split()
     gerr, perr, lerr, gmax = float(line[1]), float(line[2]), float(line[3]), float(line[6])
-    assert gmax > 1e-2 and gerr < 1e-6 and perr < 2e-5 and lerr < 2e-3 and line[4] == "True" and line[5] == "nccl", line
+    assert gmax > 1e-2 and gerr == 0.0 and perr == 0.0 and lerr == 0.0 and line[4] == "True" and line[5] == "nccl", line
+    assert line[7] == "True" and line[8] == "True", line          # three steps later: still bit-identical
 
 
 def test_cli_two_ranks_shard_the_real_data(tmp_path):

@@ -406,11 +406,25 @@ def test_trainer_word_table_equals_dense_adamw():
                                               0.9, 0.999, 1e-8, wd, step, 1.0, 1, _lib.stream_ptr()))
     import ctypes as C
     b._adamw = types.MethodType(dense, b)
+    calls = {"n": 0}
+    orig_dense = b._adamw
+
+    def counted(*args, **kw):
+        calls["n"] += 1
+        return orig_dense(*args, **kw)
+    b._adamw = counted
     for step in range(1, 5):
         ids, mask, pixels, onehot = O.synthetic_batch(ocfg, 4, 32, 100 + step, True)
         for tr in (a, b):
             tr.model._calls = step               # same dropout stream in both trainers
-            tr.train_step(ids.cuda(), mask.cuda(), pixels, onehot, None, 1e-3, 0.01, step)
+            # trainer a: the default native step (mmhip_train_step: per-layer AdamW on the side stream, row-lazy word table);
+            # trainer b: the staged step, the only one that goes through _adamw -- here ONE dense AdamW over every active range
+            os.environ["MMHIP_NATIVE_STEP"] = "1" if tr is a else "0"
+            try:
+                tr.train_step(ids.cuda(), mask.cuda(), pixels, onehot, None, 1e-3, 0.01, step)
+            finally:
+                os.environ.pop("MMHIP_NATIVE_STEP", None)
+    assert calls["n"] == 8, calls                # two _adamw calls (dense ranges, word rows) per staged step: the dense closure really ran
     # the backward's fp32 atomics are not run-to-run bit-stable, so touched values are compared closely, not bitwise
     assert (a.model._flat_train - b.model._flat_train).abs().max().item() < 2e-5
     assert (a._opt[0] - b._opt[0]).abs().max().item() < 1e-5 and (a._opt[1] - b._opt[1]).abs().max().item() < 1e-5
@@ -423,6 +437,67 @@ def test_trainer_word_table_equals_dense_adamw():
     tb = b.model._flat_train[w["offset"]: w["offset"] + w["numel"]].view(w["shape"])
     assert torch.equal(ta[st == 0], tb[st == 0])            # decay-only rows: bit-identical to the dense update
     assert a._opt[0][w["offset"]: w["offset"] + w["numel"]].view(w["shape"])[st == 0].abs().max().item() == 0.0
+
+
+def _fresh_trainer(seed=3, itc=True, itm=True):
+    import types
+    cfgd = types.SimpleNamespace(batch_size=4, num_labels=3, use_clip_loss=itc, beta_itc=0.1, use_tim_loss=itm, beta_itm=0.1,
+                                 max_length=32, dropout=0.05)
+    arch = dict(layers_txt=2, layers_img=1, vocab=3000, max_pos=130)
+    return MMLate_Model(cfgd, "bernice", "vit", "attention", arch=arch, seed=seed)
+
+
+def _run_steps(tr, n, env):
+    ocfg = O.OracleConfig(layers_txt=2, layers_img=1, vocab=3000, max_pos=130, num_labels=3)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        losses = []
+        for step in range(1, n + 1):
+            ids, mask, pixels, onehot = O.synthetic_batch(ocfg, 4, 32, 100 + step, True)
+            tr.model._calls = step
+            np.random.seed(30 + step)                # the ITM sampling draws from numpy's global stream (reference mm_late.py:389-414)
+            loss, _ = tr.train_step(ids.cuda(), mask.cuda(), pixels, onehot, None, 1e-3, 0.01, step)
+            losses.append(loss.clone())
+        torch.cuda.synchronize()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return torch.stack(losses).cpu()
+
+
+def test_deterministic_mode_is_bitwise_reproducible():
+    """MMHIP_DETERMINISTIC=1: no fp32 atomic decides the last bits of a sum (single-writer second stage of the column reductions, word /
+    position rows summed in slot order): two runs of three steps -- dropout on, ITC + ITM on, the default native step with its side
+    streams -- end on bit-identical parameters, moments, row flags and losses.  A stream race (a missing wait between the side-stream
+    AdamW / weight refresh and the kernels that read those weights) would show up here; rounding noise can not."""
+    res = []
+    for _ in range(2):
+        tr = _fresh_trainer()
+        losses = _run_steps(tr, 3, {"MMHIP_DETERMINISTIC": "1"})
+        res.append((tr.model._flat_train.clone(), tr._opt[0].clone(), tr._opt[1].clone(), tr.model._word_row_state.clone(), losses))
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+    assert res[0][0].isfinite().all() and float(res[0][4][-1][0]) > 0
+
+
+def test_native_and_staged_steps_agree_bitwise_in_deterministic_mode():
+    """one parameter update three ways from identical state: the native step with each text layer's AdamW + 16-bit weight refresh on the
+    side stream behind that layer's weight-gradient GEMM (default), the native step with the optimizer after the whole backward
+    (MMHIP_EARLY_ADAMW=0), and the staged Python step (MMHIP_NATIVE_STEP=0).  Same kernels, same elementwise AdamW: with the deterministic
+    reductions the parameters, moments and row flags after TWO steps are bit-identical -- the second step's forward reads the 16-bit
+    weight copies the first step's (side-stream) refresh wrote, so a missing wait there cannot hide."""
+    res = []
+    for env in ({"MMHIP_EARLY_ADAMW": "1"}, {"MMHIP_EARLY_ADAMW": "0"}, {"MMHIP_NATIVE_STEP": "0"}):
+        tr = _fresh_trainer()
+        losses = _run_steps(tr, 2, dict(env, MMHIP_DETERMINISTIC="1"))
+        res.append((tr.model._flat_train.clone(), tr._opt[0].clone(), tr._opt[1].clone(), tr.model._word_row_state.clone(), losses))
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            assert torch.equal(x, y), (x.float() - y.float()).abs().max()
 
 
 def test_trainer_step_and_itm_sampling():
