@@ -24,13 +24,45 @@ GF_PER_POST = {"plain": 103.798, "aux": 171.528,
                # Hv = 1024, Iv = 4096, P = 257 (224 px) / 577 (336 px); + text forward 22.347 + text backward 44.695 + heads 0.01
                "clip224": 229.1, "clip336": 448.9}
 PEAK_TFLOPS = 2500.0        # bf16 / f16 dense MFMA, MI355X_MICROARCH.md "Chip-level parameters"
-# measured parity per numerics mode (not re-measured by bench.py: `pytest -m gpu tests/test_gpu_model.py` on MI355X, round 2,
-# log in profiles/r02_parity.txt): max|got-ref|/max|ref| against the reference's golden vectors, worst of the four forward goldens
-PARITY = {"metric": "max|got-ref|/max|ref| vs the reference's fp32 golden vectors (4 forward goldens, worst); loss: relative",
-          "north_star_tolerance": 1e-3, "source": "profiles/r02_parity.txt (tests/test_gpu_model.py, MI355X)",
-          "bf16x3": {"out_cls": 1.6e-5, "logits_per_text": 1.4e-5, "out_tim": 1.8e-5, "mm_features": 7.4e-6, "loss": 4e-7, "grad_worst": 2.8e-5, "meets_1e-3": True},
-          "f16": {"out_cls": 1.6e-3, "logits_per_text": 2.5e-3, "out_tim": 1.4e-3, "mm_features": 1.4e-3, "loss": 1e-4, "grad_worst": 1.3e-2, "meets_1e-3": False},
-          "bf16": {"out_cls": 8.1e-3, "logits_per_text": 1.9e-2, "out_tim": 1.5e-2, "mm_features": 1.15e-2, "loss": 2e-4, "grad_worst": 0.25, "meets_1e-3": False}}
+METRIC = {2: "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion, bs=64",                      # BASELINE.json's metric, quoted on config 2
+          3: "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion + ITC+ITM, bs=64",
+          4: "posts/sec (fwd+bwd) CLIP-ViT-L/14 + Bernice concat-fusion, bs=32",
+          5: "posts/sec (fwd+bwd) LXMERT early-fusion, bs=32"}
+
+
+def measure_parity(dtype):
+    """the reference's four forward goldens (tests/golden/fwd_*.npz: XLM-R, BERT, concat, full depth; vectors produced by the reference's own
+    MM_Model) through the HIP path in THIS run's dtype: max|got - ref| / max|ref| per output, worst over the goldens.  The oracle module is
+    used as the checker only (deterministic parameter recipe + synthetic batch of the goldens)."""
+    import ast
+    import numpy as np
+    import torch
+    from oracle import mm_oracle as O
+    from smtc_amd.mm_late import MM_Model
+    worst = {"out_cls": 0.0, "logits_per_text": 0.0, "out_tim": 0.0, "mm_features": 0.0}
+    for name, txt in (("fwd_small_xlmr", "bernice"), ("fwd_small_bert", "bert"), ("fwd_small_concat", "bernice"), ("fwd_full_xlmr", "bernice")):
+        z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False)
+        cfg = O.OracleConfig(**ast.literal_eval(str(z["cfg"])))
+        B, T = int(z["B"]), int(z["T"])
+        arch = dict(layers_txt=cfg.layers_txt, layers_img=cfg.layers_img, vocab=cfg.vocab, max_pos=cfg.max_pos, type_vocab=cfg.type_vocab,
+                    p_hidden=cfg.p_hidden, p_attn=cfg.p_attn)
+        m = MM_Model(cfg.num_labels, txt, "vit", cfg.p_head, cfg.fusion, arch=arch, dtype=dtype, max_posts=B, max_text_len=T)
+        m.load_state_dict(O.make_params(cfg, int(z["seed_w"])), strict=False)
+        m.eval()
+        pixels = O.synthetic_batch(cfg, B, T, int(z["seed_x"]), bool(z["pad"]))[2]
+        with torch.no_grad():
+            o = m(torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"]), pixels, tim_inputs=(torch.from_numpy(z["tim_ids"]), torch.from_numpy(z["tim_mask"])))
+        for k, v in (("out_cls", o[0]), ("logits_per_text", o[1]), ("out_tim", o[2]), ("mm_features", o[4])):
+            ref = torch.from_numpy(z[k])
+            worst[k] = max(worst[k], (v.float().cpu() - ref).abs().max().item() / ref.abs().max().item())
+        del m
+    torch.cuda.empty_cache()
+    out = {k: float("%.3g" % v) for k, v in worst.items()}
+    out["meets_1e-3"] = all(v < 1e-3 for v in worst.values())
+    return {"metric": "max|got-ref|/max|ref| vs the reference's fp32 golden vectors (4 forward goldens, worst), measured in this run",
+            "north_star_tolerance": 1e-3, "dtype": dtype, "measured": out,
+            "note": "no single-pass 16-bit policy meets 1e-3 on all four goldens (profiles/r03_numerics_study.txt); the strict-parity dtype is bf16x3 "
+                    "(python bench.py --dtype bf16x3 measures the same block at <= 2e-5)"}
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -115,7 +147,29 @@ def bench_early(args):
     fwd = (9 * layer + 5 * xlayer) * T + (5 * layer + 5 * xlayer) * NB + 2.0 * NB * (2048 + 4) * H
     gf_post = 3 * fwd * (2 if args.aux else 1) / 1e9
     tf = B * args.steps / el * gf_post / 1e3                     # per GPU
-    out = {"metric": "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion, bs=64", "value": round(world * B * args.steps / el, 1), "unit": "posts/s", "n_gpus": world,
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the LXMERT oracle (kind "port") on the box's CPU share: forward + backward on a bounded sample (B = 4 posts of the same shape)
+        from oracle import lxmert_oracle as L
+        cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+        torch.set_num_threads(cores)
+        lc = L.LxmertConfig(num_labels=C)
+        LP = {k: v.requires_grad_(True) for k, v in L.make_params(lc, 0).items()}
+        c_ids, c_mask, c_tt, c_feats, c_boxes, c_oh = L.synthetic_batch(lc, 4, T, 1234)
+
+        def cstep():
+            for q in LP.values():
+                q.grad = None
+            o_, et, ev_, ot = L.early_forward(LP, c_ids, c_mask, c_tt, c_feats, c_boxes, lc)
+            L.mix_loss(LP, o_, c_oh, None, et, ev_, ot, None, False, False).backward()
+        cstep()
+        tc, n = time.time(), 0
+        while n < 1 or (time.time() - tc < 15.0 and n < 4):
+            cstep()
+            n += 1
+        cpu = {"value": round(4 * n / (time.time() - tc), 3), "unit": "posts/s", "cores": cores, "kind": "port",
+               "sample": f"{n} fwd+bwd steps of B=4 posts (T=128, 36 x 2048 ROI features), fp32 torch CPU oracle (oracle/lxmert_oracle.py), optimizer excluded"}
+    out = {"metric": METRIC[5] + (" + ITC+ITM" if args.aux else ""), "workload_id": "config5", "value": round(world * B * args.steps / el, 1), "unit": "posts/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "BASELINE config 5: LXMERT early fusion (mm_early.py), 36 x 2048 ROI features, bs=32/GPU" + (", ITC + ITM" if args.aux else ""),
@@ -124,7 +178,7 @@ def bench_early(args):
            "final_loss": round(float(loss), 5),
            "roofline": {"bound": "mfma", "kernel": "whole step (no per-kernel timing on this path)", "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / PEAK_TFLOPS, 4), "traffic": None},
-           "cpu_baseline": None}
+           "cpu_baseline": cpu}
     if world > 1:
         out["multi_gpu"] = "one all-reduce of the flat gradient per step (unmeasured on hardware: the development box has one GPU)"
         torch.distributed.barrier()
@@ -147,6 +201,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="posts per GPU (default: 64; 32 for config 4)")
     ap.add_argument("--txt_model_name", default="bernice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity measurement against the reference's forward goldens")
     ap.add_argument("--gemm-shapes", default="", help="append the per-shape table of the timed NT GEMM launches to this file")
     args = ap.parse_args()
     if args.config == 3:
@@ -317,8 +372,12 @@ def main():
                 "launches_per_step": gl // 2, "avg_launch_us": round(gms * 1e3 / max(1, gl), 2),
                 "gemm_ms_per_step": round(gms / 2, 3), "gemm_ms_per_step_serial": round(gms_serial / 2, 3)}
     mode = ("clip224" if args.image == 224 else "clip336") if args.config == 4 else ("aux" if args.aux else "plain")
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity:
+        parity = measure_parity(args.dtype)
     out = {
-        "metric": "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion, bs=64",
+        "metric": METRIC[4] if args.config == 4 else (METRIC[3] if args.aux else METRIC[2]),
+        "workload_id": "config4" if args.config == 4 else ("config3" if args.aux else "config2"),
         "value": round(posts_s, 1), "unit": "posts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
@@ -333,8 +392,7 @@ def main():
         "model_tflops": round(posts_s * GF_PER_POST[mode] / 1e3, 1),
         "model_frac_of_peak": round(posts_s / world * GF_PER_POST[mode] / 1e3 / PEAK_TFLOPS, 4),
         "final_loss": round(final_loss, 5), "spans_ms": spans, "roofline": roofline,
-        "parity": {"metric": PARITY["metric"], "north_star_tolerance": PARITY["north_star_tolerance"], "source": PARITY["source"],
-                   "this_dtype": PARITY[args.dtype], "parity_mode_bf16x3": PARITY["bf16x3"]},
+        "parity": parity,
     }
     if exch is not None:
         out["exchange"] = exch

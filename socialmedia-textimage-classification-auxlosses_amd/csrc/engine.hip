@@ -62,7 +62,9 @@ struct mmhip_engine {
     // heads (fp32) ----------------------------------------------------------------------
     size_t h_vpool, h_tpool, h_txt_e, h_img_e, h_txt_n, h_img_n, h_txt_inv, h_img_inv, h_logits;
     size_t h_q, h_qk, h_prob, h_xbar, h_z, h_feats, h_featd, h_out_cls, h_out_tim;
-    size_t splitk_ws = 0; bool has_splitk = false;      // fp32 scratch of the split-K path of the <= 128-row GEMMs (caller's stream only)
+    size_t splitk_ws = 0, splitk_ws_vit = 0; bool has_splitk = false;      // fp32 scratch of the split-K path of the <= 128-row GEMMs: one per stream that
+                                                                           // issues NT GEMMs (the caller's; the image tower's side stream) -- two towers' small
+                                                                           // GEMMs may run side by side
     size_t h_d_out_cls, h_d_logits, h_d_out_tim, h_dfeats, h_dpre, h_dz, h_dxcls, h_dxbar, h_dqk, h_dq, h_dtxt_e, h_dimg_e,
         h_dtpool, h_dprepool, h_loss;
     // state of the last forward --------------------------------------------------------
@@ -344,6 +346,7 @@ void build_workspace(mmhip_engine& e) {
     e.h_q = f(Bt * H); e.h_qk = f(Bt * H); e.h_prob = f(Bt * P); e.h_xbar = f(Bt * H); e.h_z = f(Bt * (H + Hv)); e.h_feats = f(Bt * H);
     e.h_featd = f(Bm * H); e.h_out_cls = f(Bm * C); e.h_out_tim = f(Bm * 2);
     e.splitk_ws = f((size_t)(I / 384 + 1) * 128 * (size_t)(I > 3 * H ? I : 3 * H)); e.has_splitk = true;
+    e.splitk_ws_vit = f((size_t)(Iv / 384 + 1) * 128 * (size_t)(Iv > 3 * Hv ? Iv : 3 * Hv));
     e.h_d_out_cls = f(Bm * C); e.h_d_logits = f(Bm * Bm); e.h_d_out_tim = f(Bm * 2); e.h_dfeats = f(Bt * H); e.h_dpre = f(Bt * H);
     e.h_dz = f(Bt * (H + Hv)); e.h_dxcls = f(Bt * H); e.h_dxbar = f(Bt * H); e.h_dqk = f(Bt * H); e.h_dq = f(Bt * H);
     e.h_dtxt_e = f(Bm * E); e.h_dimg_e = f(Bm * E); e.h_dtpool = f(Bm * H); e.h_dprepool = f(Bm * H); e.h_loss = f(8);
@@ -386,10 +389,14 @@ inline void part_gemm(const mmhip_engine& e, G& g, int which) {
     if (n > 0 && !g.a.tile && g.a.M >= 2048 && g.a.N % 256 == 0 && g.a.K % 64 == 0 && (e.dt() == DT_BF16 || e.dt() == DT_F16)) { g.a.tile = 20; g.a.grid = n; }
 }
 int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
-    // CLS-row GEMMs of the last text layer (<= 128 rows, K = 3072): split along K (gemm.hip launch_nt_splitk).  They are issued on
-    // the caller's stream only (the image tower's and the weight-gradient GEMMs have thousands of rows): one scratch buffer.
-    if (e.has_splitk && g.a.M <= 128 && (size_t)(g.a.K / 384) * g.a.M * g.a.N <= (size_t)(e.cfg.inter / 384 + 1) * 128 * (size_t)(e.cfg.inter > 3 * e.cfg.hidden ? e.cfg.inter : 3 * e.cfg.hidden))
-        g.a.splitk_ws = e.wsp<float>(e.splitk_ws);
+    // GEMMs of <= 128 rows with K >= 1536 (the CLS-row GEMMs of the last text layer; a tiny image tower) are split along K
+    // (gemm.hip launch_nt_splitk) through an fp32 scratch: the image tower's side stream has its own, every other stream shares the caller's
+    {
+        const bool on_vit = e.side_vit[0] != nullptr && (s == e.side_vit[0] || s == e.side_vit[1]);
+        const int h = on_vit ? e.Hv() : e.cfg.hidden, in = on_vit ? e.Iv() : e.cfg.inter;
+        if (e.has_splitk && g.a.M <= 128 && (size_t)(g.a.K / 384) * g.a.M * g.a.N <= (size_t)(in / 384 + 1) * 128 * (size_t)(in > 3 * h ? in : 3 * h))
+            g.a.splitk_ws = e.wsp<float>(on_vit ? e.splitk_ws_vit : e.splitk_ws);
+    }
     if (e.timing) {
         if (e.ev_used == e.evs.size()) {
             mmhip_engine::Ev ev;

@@ -500,6 +500,27 @@ def test_native_and_staged_steps_agree_bitwise_in_deterministic_mode():
             assert torch.equal(x, y), (x.float() - y.float()).abs().max()
 
 
+def test_tiny_image_tower_splits_k_beside_the_text_tower():
+    """image 32 / patch 16: the image tower has B * 5 <= 128 rows, so its FC2 (K = 3072) takes the split-K path on the tower's side
+    stream while the CLS-row GEMMs of the last text layer take it on the caller's stream -- each stream has its own fp32 scratch
+    (they used to share one).  Outputs match the oracle and repeat bit for bit."""
+    cfg = O.OracleConfig(layers_txt=2, layers_img=2, vocab=1000, max_pos=130, num_labels=3, image=32, patch=16, p_hidden=0.0, p_attn=0.0, p_head=0.0)
+    arch = dict(layers_txt=2, layers_img=2, vocab=1000, max_pos=130, image=32, patch=16, p_hidden=0.0, p_attn=0.0)
+    B, T = 8, 32
+    model = MM_Model(3, "bernice", "vit", 0.0, "attention", arch=arch, dtype="bf16", max_posts=B, max_text_len=T)
+    P = O.make_params(cfg, 11)
+    load_oracle_params(model, P)
+    model.eval()
+    ids, mask, pixels, _ = O.synthetic_batch(cfg, B, T, 5, True)
+    with torch.no_grad():
+        ref = O.mm_forward(P, ids, mask, pixels, cfg, None)
+        outs = [model(ids, mask, pixels) for _ in range(6)]
+    for k, i in (("out_cls", 0), ("logits_per_text", 1), ("mm_features", 4)):
+        assert rel_err(outs[0][i], ref[i]) < TOL_OUT["bf16"][k], (k, rel_err(outs[0][i], ref[i]))
+        for o in outs[1:]:
+            assert torch.equal(o[i], outs[0][i]), k
+
+
 def test_trainer_step_and_itm_sampling():
     """fused MMLate_Model.train_step: loss goes down on a fixed batch; parameters outside the active set stay untouched;
     prepare_itm_inputs reproduces the reference's numpy RNG stream (tests/golden/itm_sampling.npz)"""
