@@ -332,16 +332,25 @@ def main():
             step_no += 1
             trainer.train_step(ids, mask, pixels, onehot, None, lr, wd, step_no)
         gms, gl, gf = Ct.c_double(), Ct.c_uint64(), Ct.c_double()
+        buf = Ct.create_string_buffer(1 << 16)
+        _lib.check(lib.mmhip_gemm_timing_by_shape(m._handle, buf, len(buf)))
+        table = buf.value.decode()
         if args.gemm_shapes and rank == 0:
-            buf = Ct.create_string_buffer(1 << 16)
-            _lib.check(lib.mmhip_gemm_timing_by_shape(m._handle, buf, len(buf)))
             with open(args.gemm_shapes, "a") as f:
-                f.write("# NT GEMM launches by shape, side streams %s (2 steps)\n%s\n" % ("on" if mode == 1 else "off", buf.value.decode()))
+                f.write("# NT GEMM launches by shape, side streams %s (2 steps)\n%s\n" % ("on" if mode == 1 else "off", table))
+        # CU-share-weighted time: a launch capped at c workgroups (the forward's CU partition) occupies c of the 256 CUs
+        occ_ms = 0.0
+        for line in table.splitlines()[1:]:
+            f_ = line.split()
+            if len(f_) >= 9:
+                occ_ms += float(f_[8]) * int(f_[5]) / 256.0
         _lib.check(lib.mmhip_gemm_timing(m._handle, 0, 1, Ct.byref(gms), Ct.byref(gl), Ct.byref(gf)))
         tf = gf.value / (gms.value * 1e-3) / 1e12 if gms.value > 0 else 0.0
+        gemm_pass.occ_tf = gf.value / (occ_ms * 1e-3) / 1e12 if occ_ms > 0 else 0.0
         return tf, gms.value, int(gl.value), gf.value
 
     achieved, gms, gl, gf = gemm_pass(1)
+    occ_tf = gemm_pass.occ_tf
     serial_tf, gms_serial, _, _ = gemm_pass(2)
     # HBM bytes per launch of that kernel come from PMC passes of this very command (FETCH_SIZE x2 per the gfx950 correction and
     # WRITE_SIZE, separate rocprofv3 --pmc runs, tools/pmc_traffic.py): bench.py cannot run the profiler on itself, so the
@@ -362,10 +371,13 @@ def main():
         if tj.get("csrc_sha256_16") == src_hash and args.config == 2 and not args.aux and B == 64 and world == 1 and tj.get("dtype", "bf16") == args.dtype:
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/" + tfile
             break
-    roofline = {"bound": "mfma", "kernel": "NT GEMM family (gemm_nt_kernel / gemm_nt8_kernel, MFMA 16x16x32, LDS-DMA staged)",
+    roofline = {"bound": "mfma", "kernel": "NT GEMM family (gemm_nt8i_kernel / gemm_nt8_kernel / gemm_nt_kernel, MFMA 16x16x32, LDS-DMA staged)",
                 "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4),
                 "conditions": "HIP events around every NT launch on its own stream, side streams on (as in the timed step)",
                 "achieved_serial": round(serial_tf, 1), "frac_serial": round(serial_tf / PEAK_TFLOPS, 4),
+                "achieved_per_cu_share": round(occ_tf, 1), "frac_per_cu_share": round(occ_tf / PEAK_TFLOPS, 4),
+                "cu_share_note": "the forward's two towers run their GEMMs as persistent launches capped at 96 / 160 workgroups (a CU partition, DESIGN.md 3): "
+                                 "frac_per_cu_share weighs a launch's duration by the share of the chip it occupies; frac weighs every launch as if it had all 256 CUs",
                 "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                 "csrc_sha256_16": src_hash,
                 "algorithmic_flops_per_launch": round(gf / max(1, gl)),

@@ -104,7 +104,7 @@ struct mmhip_engine {
     }
     // GEMM timing ----------------------------------------------------------------------
     int timing = 0;            // 0 off, 1 = events around every NT GEMM with the side streams on, 2 = side streams off
-    struct Ev { hipEvent_t a, b; double flops; int M, N, K, flags, tile; };
+    struct Ev { hipEvent_t a, b; double flops; int M, N, K, flags, tile, cus; };      // cus: workgroup cap of a partitioned launch (0 = whole chip)
     std::vector<Ev> evs; size_t ev_used = 0;
 
     template <typename U> U* wsp(size_t off) const { return reinterpret_cast<U*>(ws + off); }
@@ -406,7 +406,7 @@ int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
         }
         auto& ev = e.evs[e.ev_used++];
         ev.flops = 2.0 * g.a.M * (double)g.a.N * g.a.K;
-        ev.M = g.a.M; ev.N = g.a.N; ev.K = g.a.K; ev.flags = g.a.flags; ev.tile = g.a.tile;
+        ev.M = g.a.M; ev.N = g.a.N; ev.K = g.a.K; ev.flags = g.a.flags; ev.tile = g.a.tile; ev.cus = g.a.grid;
         CHECK_HIP(hipEventRecord(ev.a, s));
         CHECK_HIP(launch_gemm_nt(g.a, e.dt(), s));
         CHECK_HIP(hipEventRecord(ev.b, s));
@@ -433,7 +433,7 @@ int run_gemm_pair(mmhip_engine& e, G& g0, G& g1, hipStream_t s) {
         CHECK_HIP(hipGetLastError());
         if (ev) {
             ev->flops = 2.0 * ((double)g0.a.M + g1.a.M) * (double)g0.a.N * g0.a.K;
-            ev->M = g0.a.M + g1.a.M; ev->N = g0.a.N; ev->K = g0.a.K; ev->flags = g0.a.flags | g1.a.flags; ev->tile = -2;     // -2: a pair
+            ev->M = g0.a.M + g1.a.M; ev->N = g0.a.N; ev->K = g0.a.K; ev->flags = g0.a.flags | g1.a.flags; ev->tile = -2; ev->cus = 0;     // -2: a pair
             CHECK_HIP(hipEventRecord(ev->b, s));
             e.ev_used++;
         }
@@ -1450,7 +1450,7 @@ int mmhip_gemm_timing(mmhip_handle h, int enable, int reset, double* ms, uint64_
 int mmhip_gemm_timing_by_shape(mmhip_handle h, char* out, uint64_t capacity) {
     if (!h || !out || capacity < 2) return MMHIP_E_INVALID;
     mmhip_engine& e = *h;
-    struct Row { int M, N, K, flags, tile; int n; double ms, flops; };
+    struct Row { int M, N, K, flags, tile, cus; int n; double ms, flops; };
     std::vector<Row> rows;
     for (size_t i = 0; i < e.ev_used; ++i) {
         const auto& ev = e.evs[i];
@@ -1458,8 +1458,8 @@ int mmhip_gemm_timing_by_shape(mmhip_handle h, char* out, uint64_t capacity) {
         float t = 0;
         CHECK_HIP(hipEventElapsedTime(&t, ev.a, ev.b));
         Row* r = nullptr;
-        for (auto& x : rows) if (x.M == ev.M && x.N == ev.N && x.K == ev.K && x.flags == ev.flags && x.tile == ev.tile) { r = &x; break; }
-        if (!r) { rows.push_back(Row{ev.M, ev.N, ev.K, ev.flags, ev.tile, 0, 0.0, 0.0}); r = &rows.back(); }
+        for (auto& x : rows) if (x.M == ev.M && x.N == ev.N && x.K == ev.K && x.flags == ev.flags && x.tile == ev.tile && x.cus == ev.cus) { r = &x; break; }
+        if (!r) { rows.push_back(Row{ev.M, ev.N, ev.K, ev.flags, ev.tile, ev.cus, 0, 0.0, 0.0}); r = &rows.back(); }
         r->n++; r->ms += t; r->flops += ev.flops;
     }
     size_t pos = 0;
@@ -1468,9 +1468,13 @@ int mmhip_gemm_timing_by_shape(mmhip_handle h, char* out, uint64_t capacity) {
         int w = snprintf(out + pos, capacity - pos, fmt, a...);
         if (w > 0) pos += (size_t)w < capacity - pos ? (size_t)w : capacity - pos - 1;
     };
-    put("%7s %6s %6s %6s %5s %6s %9s %9s %8s\n", "M", "N", "K", "flags", "tile", "n", "avg_us", "total_ms", "TFLOP/s");
-    for (const auto& r : rows)
-        put("%7d %6d %6d %6d %5d %6d %9.2f %9.3f %8.1f\n", r.M, r.N, r.K, r.flags, r.tile, r.n, 1e3 * r.ms / r.n, r.ms, r.flops / (r.ms * 1e-3) * 1e-12);
+    // cus: the launch's workgroup cap under the forward's CU partition (256 = the whole chip); TF/CU-share: TFLOP/s scaled to a whole chip of such CUs
+    put("%7s %6s %6s %6s %5s %4s %6s %9s %9s %8s %11s\n", "M", "N", "K", "flags", "tile", "cus", "n", "avg_us", "total_ms", "TFLOP/s", "TF/CU-share");
+    for (const auto& r : rows) {
+        const int cus = r.cus > 0 && r.cus < 256 ? r.cus : 256;
+        const double tf = r.flops / (r.ms * 1e-3) * 1e-12;
+        put("%7d %6d %6d %6d %5d %4d %6d %9.2f %9.3f %8.1f %11.1f\n", r.M, r.N, r.K, r.flags, r.tile, cus, r.n, 1e3 * r.ms / r.n, r.ms, tf, tf * 256.0 / cus);
+    }
     out[pos < capacity ? pos : capacity - 1] = 0;
     return 0;
 }
