@@ -17,6 +17,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import mm_oracle as O
+from smtc_amd.synthetic import synthetic_batch
 
 if torch.cuda.is_available():
     import smtc_amd  # noqa: F401
@@ -666,6 +667,88 @@ def test_full_size_backward_is_the_mean_of_half_batches():
     for b, e in model.active_ranges(False, False):
         err = (g_all[b:e] - ref[b:e]).norm().item() / max(ref[b:e].norm().item(), 1e-30)
         assert err < 2e-3, (b, e, err)            # identical per-row arithmetic; only fp32 / 16-bit summation order differs
+
+
+def test_full_size_clip_l14_tower_properties():
+    """BASELINE config 4 at its real size (CLIP-ViT-L/14: 1024 wide, 16 heads, 4096-wide quick-GELU MLP, 24 pre-LN layers, 257 tokens; concat
+    fusion, bs = 32): N and K = 1024 / 4096 GEMMs, the 640-column padded patch conv and the 257-token attention run only here under the
+    driver.  (a) finite, (b) eval determinism, (c) permuting the posts permutes the outputs, (d) the gradient of the mean loss over 32
+    posts is the mean of the gradients over its two halves (the tower is frozen: text tower + heads)."""
+    from smtc_amd import _lib
+    B, T = 32, 128
+    model = MM_Model(2, "bernice", "clip", 0.0, "concat", arch=dict(p_hidden=0.0, p_attn=0.0), max_posts=B, max_text_len=T, seed=4)
+    a = model.arch
+    assert (a["hidden_img"], a["heads_img"], a["inter_img"], a["layers_img"], a["patch"]) == (1024, 16, 4096, 24, 14)
+    ids, mask, pixels, onehot = synthetic_batch(a["vocab"], 2, B, T, 4321, a["txt_kind"], a["pad_id"], True, a["image"], "cpu")
+    model.eval()
+    with torch.no_grad():
+        x = model(ids, mask, pixels)
+        y = model(ids, mask, pixels)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
+        z_ = model(ids[perm], mask[perm], pixels[perm])
+    for v in (x[0], x[1], x[4]):
+        assert torch.isfinite(v).all()
+    assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[4], y[4])
+    assert rel_err(z_[0], x[0][perm.cuda()]) < 1e-5 and rel_err(z_[4], x[4][perm.cuda()]) < 1e-5
+    assert rel_err(z_[1], x[1][perm.cuda()][:, perm.cuda()]) < 1e-5
+    model.train()
+    dev = model.device_
+
+    def grads(sl):
+        model._flat_grad.zero_()
+        model._engine_forward(ids[sl], mask[sl], pixels[sl])
+        lo = torch.empty(4, device=dev)
+        oh = onehot[sl].to(dev).contiguous()
+        _lib.check(_lib.lib().mmhip_loss(model._handle, _lib.ptr(oh), None, None, 1.0, 0.0, 0.0, _lib.ptr(lo), None, _lib.stream_ptr()))
+        _lib.check(_lib.lib().mmhip_backward(model._handle, None, None, None, None, _lib.stream_ptr()))
+        return model._flat_grad.clone(), lo[0].item()
+
+    g_all, l_all = grads(slice(0, B))
+    g_a, l_a = grads(slice(0, B // 2))
+    g_b, l_b = grads(slice(B // 2, B))
+    assert torch.isfinite(g_all).all() and abs(l_all - 0.5 * (l_a + l_b)) < 1e-5 * abs(l_all)
+    ref = 0.5 * (g_a + g_b)
+    for b, e in model.active_ranges(False, False):
+        err = (g_all[b:e] - ref[b:e]).norm().item() / max(ref[b:e].norm().item(), 1e-30)
+        assert err < 2e-3, (b, e, err)
+
+
+def test_full_size_itc_itm_properties():
+    """BASELINE config 3 at its real size (B = 64, T = 128, 12 + 12 layers, ITC + ITM: the text tower runs 128 posts): permuting the posts --
+    with the SAME swapped-text assignment carried along -- permutes out_cls / out_tim / mm_features and permutes logits_per_text in
+    both indices (the contrastive head couples the posts, the permutation equivariance still holds); the three-term loss and every
+    active gradient range are finite and the loss does not depend on the order of the posts."""
+    from smtc_amd import _lib
+    cfg = O.OracleConfig(num_labels=3)
+    B, T = 64, 128
+    model = MM_Model(3, "bernice", "vit", 0.0, "attention", arch=dict(p_hidden=0.0, p_attn=0.0), max_posts=B, max_text_len=T, seed=6)
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, B, T, 77, True)
+    np.random.seed(30)
+    tim_ids, tim_mask, lbl = O.prepare_itm_inputs(ids, mask)
+    model.train()
+    dev = model.device_
+
+    def run(p):
+        model._flat_grad.zero_()
+        o = model._engine_forward(ids[p], mask[p], pixels[p], tim_ids[p], tim_mask[p])
+        lo = torch.empty(4, device=dev)
+        oh, lt = onehot[p].to(dev).contiguous(), lbl[p].to(dev).contiguous()
+        _lib.check(_lib.lib().mmhip_loss(model._handle, _lib.ptr(oh), None, _lib.ptr(lt), 0.8, 0.1, 0.1, _lib.ptr(lo), None, _lib.stream_ptr()))
+        _lib.check(_lib.lib().mmhip_backward(model._handle, None, None, None, None, _lib.stream_ptr()))
+        return [t_.clone() for t_ in o], lo.clone(), model._flat_grad.clone()
+
+    ident = torch.arange(B)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(2))
+    (c0, l0, t0, f0), lo0, g0 = run(ident)
+    (c1, l1, t1, f1), lo1, g1 = run(perm)
+    pc = perm.cuda()
+    assert all(torch.isfinite(v).all() for v in (c0, l0, t0, f0, lo0, g0))
+    assert rel_err(c1, c0[pc]) < 1e-5 and rel_err(t1, t0[pc]) < 1e-5 and rel_err(f1, f0[pc]) < 1e-5
+    assert rel_err(l1, l0[pc][:, pc]) < 1e-5
+    assert (lo1 - lo0).abs().max().item() < 2e-5 * lo0.abs().max().item()
+    for b, e in model.active_ranges(True, True):
+        err = (g1[b:e] - g0[b:e]).norm().item() / max(g0[b:e].norm().item(), 1e-30)
+        assert err < 2e-3, (b, e, err)            # the same sums over posts in another order: fp32 / 16-bit summation order only
 
 
 def test_vision_cache_is_bit_identical_and_skips_the_tower():
