@@ -97,8 +97,7 @@ int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, 
     if (act == 1) a.flags |= GEMM_GELU;
     if (act == 2) a.flags |= GEMM_TANH;
     if (act == 3) a.flags |= GEMM_QGELU;
-    if (aux_pre && (force_slow & 2)) { a.aux = aux_pre; a.flags |= GEMM_DEBUG_TS | ((force_slow & 4) ? GEMM_DEBUG_CYC : 0); }    // profiling hooks of gemm8.hip
-    else if (aux_pre) { a.aux = aux_pre; a.ldaux = ldaux; a.flags |= GEMM_AUX_PRE; }
+    if (aux_pre) { a.aux = aux_pre; a.ldaux = ldaux; a.flags |= GEMM_AUX_PRE; }
     if (mul_gelu_grad_of) { a.mul_in = mul_gelu_grad_of; a.ldmul = ldmul; a.flags |= GEMM_MUL_GELU_GRAD; }
     if (p_drop > 0.f) { a.drop = drop_of(p_drop, seed, stream_id); a.flags |= GEMM_DROPOUT; }
     if (residual) { a.residual = residual; a.ldres = ldres; a.flags |= GEMM_RESIDUAL; }

@@ -386,7 +386,7 @@ struct G {
 // forward GEMM of tower `which` (0 text, 1 image) under the CU partition: persistent 256 x 256 tiles on at most cur_part[which] workgroups
 inline void part_gemm(const mmhip_engine& e, G& g, int which) {
     const int n = e.cur_part[which];
-    if (n > 0 && !g.a.tile && g.a.M >= 2048 && g.a.N % 256 == 0 && g.a.K % 64 == 0 && (e.dt() == DT_BF16 || e.dt() == DT_F16)) { g.a.tile = 20; g.a.grid = n; }
+    if (n > 0 && !g.a.tile && g.a.M >= 2048 && g.a.N % 256 == 0 && g.a.K % 64 == 0 && (e.dt() == DT_BF16 || e.dt() == DT_F16)) { g.a.tile = 15; g.a.grid = n; }
 }
 int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
     // GEMMs of <= 128 rows with K >= 1536 (the CLS-row GEMMs of the last text layer; a tiny image tower) are split along K
@@ -503,12 +503,6 @@ int vit_forward(mmhip_engine& e, const float* pixels, hipStream_t s) {
         LNArgs ln{x, x, F + e.v_pre_ln_w, F + e.v_pre_ln_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
         CHECK_HIP(launch_layernorm_fwd(ln, dt, s));
     }
-    // 768-wide outputs of M = B*197 rows: 160-row tiles (474 tiles = one round of the 512 block slots, instead of 594 of
-    // 128x128 or 300 one-per-CU 256x128) are faster when this tower runs alone (serial: -0.4 ms/step) but not beside the text
-    // tower (same-box, image tower on its high-priority stream: +0.2 ms/step) -- opt-in: MMHIP_VIT_TILE160=1
-    static int t160 = -2;
-    if (t160 == -2) { const char* v = getenv("MMHIP_VIT_TILE160"); t160 = v ? atoi(v) : 0; }
-    const int narrow_tile = (t160 > 0 && Mv > 8192 && (long)((Mv + 159) / 160) * (H / 128) <= 512) ? 11 : 0;
     for (int l = 0; l < c.layers_img; ++l) {
         const LayerOff& o = e.vit[l];
         const LayerW16& w = e.vit_w16[l];
@@ -520,11 +514,11 @@ int vit_forward(mmhip_engine& e, const float* pixels, hipStream_t s) {
         at.qkv = e.ws + e.v_qkv; at.ctx = e.ws + e.v_ctx; at.posts = B; at.S = P; at.heads = e.heads_v(); at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
         at.scale = 1.0f / sqrtf((float)(H / e.heads_v()));
         CHECK_HIP(launch_attn_fwd(at, dt, s));
-        { G g(e.ws + e.v_ctx, H, e.ws + w.ao, H, x, H, Mv, H, H); g.bias(F + o.ao_b).residual(x, H); g.a.tile = narrow_tile; part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_ctx, H, e.ws + w.ao, H, x, H, Mv, H, H); g.bias(F + o.ao_b).residual(x, H); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
         LNArgs ln2{x, e.ws + e.v_ln, F + o.ln2_w, F + o.ln2_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
         CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
         { G g(e.ws + e.v_ln, H, e.ws + w.fc1, H, e.ws + e.v_h, I, Mv, I, H); g.bias(F + o.fc1_b); if (clip) g.qgelu(); else g.gelu(); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
-        { G g(e.ws + e.v_h, I, e.ws + w.fc2, I, x, H, Mv, H, I); g.bias(F + o.fc2_b).residual(x, H); g.a.tile = narrow_tile; part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_h, I, e.ws + w.fc2, I, x, H, Mv, H, I); g.bias(F + o.fc2_b).residual(x, H); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
     }
     if (clip) {
         // last_hidden_state = the encoder output as it is; pooler_output = post_layernorm(CLS row)   (CLIPVisionTransformer.forward)

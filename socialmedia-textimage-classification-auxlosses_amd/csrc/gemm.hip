@@ -616,9 +616,6 @@ static void launch_nt_splitk(const GemmNTArgs& a, int slices, hipStream_t s) {
     hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 128, 2, 2, 2, 0, true>), dim3(grid, slices), dim3(C::NTHR), C::LDS, s, a);
 }
 
-// tile choice: explicit (a.tile: 1 = 128x128 2-stage, 2 = 256x128 2-stage, 3 = 256x256 2-stage, 4 = 128x128 4-stage ring,
-// 5 = 256x128 3-stage ring, 6 = 128x192 2-stage, 7 = 256x192 2-stage, 8 = 128x128 role-specialised (4 MFMA + 4 loader
-// waves, 4-stage ring), 9 = 256x128 role-specialised (8 + 4 waves, 3-stage ring)) or measured rules
 // MMHIP_TILE_MAP="MxNxK:tile,MxNxK/FLAGS:tile,..." -- per-shape tile override for same-box A/B runs of the whole step (an entry with
 // /FLAGS matches that epilogue flag set only)
 struct TileMapEntry { int M, N, K, flags, tile; };
@@ -641,38 +638,25 @@ static int tile_map_lookup(const GemmNTArgs& a) {
         if (tab[i].M == a.M && tab[i].N == a.N && tab[i].K == a.K && (tab[i].flags < 0 || tab[i].flags == a.flags)) return tab[i].tile;
     return 0;
 }
+// tile choice: explicit (a.tile / MMHIP_NT_TILE / MMHIP_TILE_MAP) or measured rules.  Tiles: 1 = 128x128 (two blocks per CU), 6 = 128x192,
+// 9 = role-specialised 256x128, 10 = 128x96, 12 = role-specialised 256x96 (gemm.hip); 13-18 = the deep-pipelined kernel of gemm8.hip
+// (13 / 15 = 256x256 one-shot / persistent, 14 / 16 = 256x128, 17 / 18 = 256x192)
 static int choose_nt_tile(const GemmNTArgs& a) {
     { const int m = tile_map_lookup(a); if (m) return m; }
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_NT_TILE"); env = e ? atoi(e) : 0; }
     int t = a.tile ? a.tile : env;
-    if (t == 3 && a.N % 256) t = 2;
-    if ((t == 6 || t == 7) && a.N % 192) t = 0;
-    if ((t >= 1 && t <= 5) && a.N % 128) t = 0;
-    if ((t == 8 || t == 9) && a.N % 128) t = 0;
-    if (t == 10 && a.N % 96) t = 0;
-    if (t == 11 && a.N % 128) t = 0;
-    if (t == 12 && a.N % 96) t = 0;
-    if ((t == 17 || t == 18) && a.N % 192) t = 0;
-    if ((t == 19 || t == 20) && a.N % 256) t = 0;
-    if ((t == 21 || t == 22) && a.N % 192) t = 0;
-    if ((t == 23 || t == 24) && a.N % 128) t = 0;
-    if (t >= 13 && t <= 24) return t;
-    if (t >= 1 && t <= 12) return t;
-    if (a.N % 128 && a.N % 192 == 0 && a.N % 256) { /* only the 192-wide tiles divide N */ }
-    // Measured inside the training step (bench.py with MMHIP_NT_TILE forced, profiles/r01_tile_sweep.txt): 128x128 at two
-    // blocks per CU is as fast as any other tile for every shape of this model; the isolated micro-benchmark gains of the
-    // 192-wide tiles (tools/gemm_bench.py) do not survive the cold caches between dependent kernels.  The wider tiles
-    // stay selectable (a.tile / MMHIP_NT_TILE) and serve N that only 192 divides.
-    // round 2: the deep-pipelined persistent kernels (gemm8.hip).  Warm-cache micro-benchmarks (tools/gemm8_bench.py) put them
-    // 5-25 % ahead on most of the model's shapes, but inside the training step operands are cold (weights come from HBM every
-    // step) and then the many small 128 x 128 blocks of round 1, two per CU, hide the misses better than one 512-thread
-    // workgroup per CU: same-box A/B of the whole step (tools/ab_step.sh, profiles/r02_step_ab.txt) keeps gemm8 for the
-    // image-tower / ITM-sized GEMMs only (M >= 12000 rows, 256 x 256 tiles whenever 256 divides N) and the round-1 tiles for
-    // the 8192-row text GEMMs.  MMHIP_NT8=0 turns gemm8 off; MMHIP_NT8_MINM / _U256 / _U128 / _GAP move the thresholds.
-    static int nt8 = -1;
+    if ((t == 13 || t == 15) && a.N % 256) t = 0;
+    if ((t == 17 || t == 18 || t == 6) && a.N % 192) t = 0;
+    if ((t == 14 || t == 16 || t == 1 || t == 9) && a.N % 128) t = 0;
+    if ((t == 10 || t == 12) && a.N % 96) t = 0;
+    if (t == 1 || t == 6 || t == 9 || t == 10 || t == 12 || (t >= 13 && t <= 18)) return t;
+    // Rules measured inside the training step (same-box A/B of bench.py, profiles/r02_step_ab*.txt, r03_*): the image-tower-sized GEMMs
+    // (M >= 12000 rows) take the deep-pipelined persistent tile that fills the rounds of 256 workgroups best; the 8192-row text GEMMs
+    // outside the forward's CU partition (i.e. the backward's) keep 128 x 128 at two blocks per CU, and the long-K 768-wide ones the
+    // role-specialised tiles.  MMHIP_NT8=0 turns the deep-pipelined kernel off here; MMHIP_NT8_MINM moves the row threshold.
+    static int nt8 = -1, nt8_minm = -1;
     if (nt8 < 0) { const char* e = getenv("MMHIP_NT8"); nt8 = e ? atoi(e) : 1; }
-    static int nt8_minm = -1;
     if (nt8_minm < 0) { const char* e = getenv("MMHIP_NT8_MINM"); nt8_minm = e ? atoi(e) : 12000; }
     if (nt8 && a.M >= nt8_minm && a.N % 128 == 0 && a.K % 64 == 0) {
         const long tm = (a.M + 255) / 256;
@@ -680,50 +664,18 @@ static int choose_nt_tile(const GemmNTArgs& a) {
         const double u256 = t256 ? (double)t256 / (double)(((t256 + 255) / 256) * 256) : 0.0;
         const double u128 = (double)t128 / (double)(((t128 + 255) / 256) * 256);
         const bool narrow_long = a.N <= 768 && a.K >= 2048 && a.M <= 8192;
-        // thresholds are overridable for same-box A/B runs inside the training step (MMHIP_NT8_U256 / _U128 / _GAP, in percent)
-        static double th256 = -1, th128 = -1, gap = -1;
-        if (th256 < 0) {
-            const char* e1 = getenv("MMHIP_NT8_U256"); const char* e2 = getenv("MMHIP_NT8_U128"); const char* e3 = getenv("MMHIP_NT8_GAP");
-            th256 = e1 ? atof(e1) / 100.0 : 0.30; th128 = e2 ? atof(e2) / 100.0 : 0.70; gap = e3 ? atof(e3) / 100.0 : 1.00;
-        }
-        static int nl = -1;
-        if (nl < 0) { const char* e = getenv("MMHIP_NT8_NARROW"); nl = e ? atoi(e) : 0; }
-        if (!narrow_long || nl) {
+        if (!narrow_long) {
             // 256 x 192 where it fills clearly more of the chip than 256 x 256 (M = 12608, N = 768: 200 tiles instead of 150)
-            static int t192on = -1;
-            if (t192on < 0) { const char* e = getenv("MMHIP_NT8_192"); t192on = e ? atoi(e) : 1; }
-            if (t192on && a.N % 192 == 0) {
+            if (a.N % 192 == 0) {
                 const long t192 = tm * (a.N / 192);
                 const double u192 = (double)t192 / (double)(((t192 + 255) / 256) * 256);
-                if (u192 >= u256 + 0.1 && u192 >= th256) return t192 > 256 ? 18 : 17;
+                if (u192 >= u256 + 0.1 && u192 >= 0.30) return t192 > 256 ? 18 : 17;
             }
-            if (u256 >= th256 && u256 >= u128 - gap) return 15;
-            if (u128 >= th128) return 16;
+            if (u256 >= 0.30) return 15;
+            if (u128 >= 0.70) return 16;
         }
     }
-    static int rule = -1;
-    if (rule < 0) { const char* e = getenv("MMHIP_NT_RULE"); rule = e ? atoi(e) : 2; }   // 2: measured best inside the step
-    if (rule == 1 && a.N % 128 == 0 && a.N <= 768 && a.M >= 4096) return 9;        // experiment: WS 256x128 for narrow outputs
-    if (rule == 2 && a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9;
-    if (rule == 3) { if (a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9; if (a.N % 192 == 0) return 6; }
-    if (rule == 5 || rule == 6) {
-        // rounds of the 512 block slots (two blocks per CU) x bytes staged per tile and k-step
-        if (rule == 6 && a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9;
-        const long tm = (a.M + 127) / 128;
-        const long c128 = a.N % 128 == 0 ? ((tm * (a.N / 128) + 511) / 512) * 256 : (1L << 60);
-        const long c96 = a.N % 96 == 0 ? ((tm * (a.N / 96) + 511) / 512) * 224 : (1L << 60);
-        if (c96 < c128) return 10;
-    }
-    if (rule == 7 || rule == 8) {
-        // 160-row tiles where they save a round of the 512 block slots (M = 12608 x N = 768: 474 tiles instead of 594)
-        if (a.N % 128 == 0) {
-            const long n128 = a.N / 128;
-            const long c128 = (((long)((a.M + 127) / 128) * n128 + 511) / 512) * 128;
-            const long c160 = (((long)((a.M + 159) / 160) * n128 + 511) / 512) * 160;
-            if (c160 < c128 && (rule == 8 || a.K < 2048)) return 11;
-        }
-        if (a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9;
-    }
+    if (a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9;
     if (a.N % 128 == 0) return 1;
     if (a.N % 192 == 0) return 6;
     return 10;
@@ -731,31 +683,18 @@ static int choose_nt_tile(const GemmNTArgs& a) {
 
 template <typename T>
 static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
-    int tile = choose_nt_tile(a);
-    // MMHIP_NT8I=1: wherever the rules (or a caller) pick the deep-pipelined 256 x 256 tile, run its interleaved-schedule kernel
-    static int nt8i = -1;
-    if (nt8i < 0) { const char* e = getenv("MMHIP_NT8I"); nt8i = e ? atoi(e) : 1; }
-    if (nt8i && tile >= 13 && tile <= 18) tile = (tile == 13 || tile == 15) ? 19 + (tile == 15) : ((tile == 17 || tile == 18) ? 21 + (tile == 18) : 23 + (tile == 16));
-    if (tile >= 13) {      // 13 / 14: deep-pipelined 256x256 / 256x128, one tile per workgroup; 15 / 16: the same, persistent
+    const int tile = choose_nt_tile(a);
+    if (tile >= 13) {      // deep-pipelined persistent-capable tiles (gemm8.hip): 13 / 15 = 256x256, 14 / 16 = 256x128, 17 / 18 = 256x192; even >= 16 and 15: persistent
         const int dt = sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16;
-        // 17 / 18: 256x192, one-shot / persistent; 19 / 20, 21 / 22, 23 / 24: 256x256, 256x192, 256x128 with the interleaved K-loop
-        // schedule (gemm_nt8i_kernel), one-shot / persistent
-        const int bn = tile >= 23 ? 129 : (tile >= 21 ? 193 : (tile >= 19 ? 257 : (tile >= 17 ? 192 : ((tile == 13 || tile == 15) ? 256 : 128))));
-        if (launch_gemm_nt8(a, dt, bn, tile == 15 || (tile >= 16 && !(tile & 1)), s)) return;
+        const int bn = tile >= 17 ? 192 : ((tile == 13 || tile == 15) ? 256 : 128);
+        if (launch_gemm_nt8(a, dt, bn, tile == 15 || tile == 16 || tile == 18, s)) return;
     }
     switch (tile >= 13 ? 1 : tile) {
-        case 12: launch_nt_t<T, 256, 96, 4, 2, 3, 4>(a, s); break;    // role-specialised, 256 tiles for 8192 x 768: one tile per CU
-        case 11: launch_nt_t<T, 160, 128, 2, 2, 2>(a, s); break;      // 474 tiles for M = 12608 (ViT), N = 768: one round of 512 slots
-        case 10: launch_nt_t<T, 128, 96, 2, 2, 2>(a, s); break;       // 512 / 1536 tiles for N = 768 / 2304 at M = 8192: whole rounds
-        case 9: launch_nt_t<T, 256, 128, 4, 2, 3, 4>(a, s); break;    // 8 consumers + 4 loaders, 3-stage ring
-        case 8: launch_nt_t<T, 128, 128, 2, 2, 4, 4>(a, s); break;    // 4 consumers + 4 loaders, 4-stage ring
-        case 7: launch_nt_t<T, 256, 192, 4, 2, 2>(a, s); break;
-        case 6: launch_nt_t<T, 128, 192, 2, 2, 2>(a, s); break;
-        case 5: launch_nt_t<T, 256, 128, 4, 2, 3>(a, s); break;
-        case 4: launch_nt_t<T, 128, 128, 2, 2, 4>(a, s); break;
-        case 3: launch_nt_t<T, 256, 256, 2, 4, 2>(a, s); break;
-        case 2: launch_nt_t<T, 256, 128, 4, 2, 2>(a, s); break;
-        default: launch_nt_t<T, 128, 128, 2, 2, 2>(a, s); break;
+        case 12: launch_nt_t<T, 256, 96, 4, 2, 3, 4>(a, s); break;    // role-specialised (8 MFMA + 4 LDS-DMA loader waves), 256 tiles for 8192 x 768: one tile per CU
+        case 10: launch_nt_t<T, 128, 96, 2, 2, 2>(a, s); break;       // N that only 96 divides
+        case 9: launch_nt_t<T, 256, 128, 4, 2, 3, 4>(a, s); break;    // role-specialised, 3-stage ring
+        case 6: launch_nt_t<T, 128, 192, 2, 2, 2>(a, s); break;       // N that only 192 divides
+        default: launch_nt_t<T, 128, 128, 2, 2, 2>(a, s); break;      // 128 x 128, two blocks per CU
     }
 }
 

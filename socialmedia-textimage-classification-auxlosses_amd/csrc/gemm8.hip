@@ -1,21 +1,19 @@
 // Deep-pipelined NT GEMM for gfx950:  C[M,N] = epilogue(A[M,K] . B[N,K]^T), 16-bit operands, fp32 accumulate.
 //
 // One 512-thread workgroup per CU (8 waves = 4 along M x 2 along N), a 256 x BN output tile (BN = 256, 192 or 128), BK = 64.
-// Structure (cdna_hip_programming.md, "The 256^2 8-phase template", re-derived for this tile family):
-//   * operand K-tiles live in an LDS ring (2 buffers of 64 KB for BN = 256, 3 of 48 KB for BN = 128), filled by LDS-DMA
+// Common to the kernel below (cdna_hip_programming.md, "The 256^2 8-phase template", re-derived for this tile family):
+//   * operand K-tiles live in an LDS ring (2 buffers of 64 / 56 KB for BN = 256 / 192, 3 of 48 KB for BN = 128), filled by LDS-DMA
 //     (global_load_lds_dwordx4, 1 KB pieces = 8 tile rows x 128 B) that stays in flight ACROSS barriers: every wait is a
 //     counted s_waitcnt vmcnt(N), every barrier a raw s_barrier; no vmcnt(0) in the main loop;
-//   * a K-tile is consumed in NPH = BN/64 phases of 16 MFMA 16x16x32 per wave; a phase is two barrier intervals, L (this
-//     phase's ds_read_b128 fragment reads + GPP LDS-DMA pieces of a later K-tile) and C (the MFMAs).  Waves 4-7 run one
-//     interval behind waves 0-3, so on every SIMD one wave multiplies while its partner reads: the matrix pipe never
-//     waits for LDS;
-//   * every LDS slot is read in exactly one phase and restaged two phases later (WAR distance the guide asks for); a slot
-//     is read one phase after the counted wait + barrier that retired its DMA (RAW);
+//   * a K-tile is consumed in NPH = BN/64 phases of 16 MFMA 16x16x32 per wave;
 //   * swapped MFMA operands (D = B_frag . A_frag^T) with the B rows of a fragment pair permuted so that a lane ends up
 //     with 8 CONSECUTIVE output columns of one row: the fused epilogue (bias / GELU / gelu' / dropout / residual / aux)
 //     works on registers and leaves as 16-byte row stores -- no LDS round trip, no barrier, no LDS space;
 //   * persistent: a workgroup walks its list of tiles and the DMA stream runs on across tile boundaries, so the next
 //     tile's first K-tiles land while the epilogue of the current one runs (K = 768 is only 12 K-tiles).
+// Round 2 ran a phase as two barrier intervals (fragment reads + DMA issue | MFMAs) with waves 4-7 one interval behind waves 0-3;
+// round 3 replaced that schedule by the interleaved one documented at gemm_nt8_kernel (same-box: +20-25 % per tile,
+// profiles/r03_gemm8_interleaved.txt); the two-interval kernel, its BK = 32 deep-ring and four-wave variants are gone.
 #include <type_traits>
 #include "mmhip_common.h"
 #include "mmhip_kernels.h"
@@ -35,33 +33,7 @@ struct P8 {
     static constexpr int NBUF = BN == 128 ? 3 : 2;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, KT = A_BYTES + B_BYTES;
     static constexpr int LDS = NBUF * KT;
-    static constexpr int GPP = BN == 128 ? 3 : (BN == 192 ? 4 : 2);          // most LDS-DMA instructions per wave in one phase
-    // LDS-DMA instructions per wave in phase p (uniform over the waves: the counted waits rely on it)
-    static constexpr int gpp(int p) { return BN == 192 ? (p == 0 ? 2 : (p == 1 ? 1 : 4)) : GPP; }
 };
-
-// staging plan.  (phase p, slot jj) -> operand, piece index (a function of the wave), target K-tile offset
-//   BN = 256: p=2: A rows 0-127 of K-tile kt+2 | p=3: A rows 128-255 of kt+2 | p=0: B columns of phases 0,1 of kt+1 | p=1: phases 2,3 of kt+1
-//   BN = 128: p=0: A rows 0-127 + B columns of phase 0 of kt+2 | p=1: A rows 128-255 + B columns of phase 1 of kt+2
-//   BN = 192: p=0: B columns of phases 0,1 of kt+1 (2 per wave) | p=1: B columns of phase 2 of kt+1 (1) | p=2: all of A of kt+2 (4)
-//             (A is read in phase 0 only, so its slots are free from phase 2 on; a B slot is restaged >= 2 phases after its read)
-template <int BN> __device__ __forceinline__ constexpr bool st_is_b(int p, int jj) { return BN == 256 ? (p < 2) : (BN == 192 ? (p < 2) : (jj == 2)); }
-template <int BN> __device__ __forceinline__ int st_piece(int p, int jj, int w) {
-    if (BN == 192) {
-        if (p == 0) { const int q = w * 2 + jj; return q < 8 ? q : q + 4; }       // wn = 0: pieces 0-7, wn = 1: 12-19
-        if (p == 1) return w < 4 ? 8 + w : 16 + w;                                  // wn = 0: 8-11, wn = 1: 20-23
-        return w * 4 + jj;
-    }
-    if (BN == 256) {
-        const int q = w * 2 + jj;
-        if (p == 2) return q;
-        if (p == 3) return 16 + q;
-        if (p == 0) return q + (q & 8);
-        return q + 8 + (q & 8);
-    }
-    if (jj < 2) return p * 16 + w * 2 + jj;
-    return p * 4 + w + (w & 4);
-}
 
 // epilogue classes (compile-time, so that each instance carries only its own code): the flag sets the engine uses
 //   EP_PLAIN   [bias] [dropout] [residual]          (QKV / AO / FC2 forward, dX GEMMs)
@@ -140,7 +112,7 @@ __device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, 
 
 // epilogue of one 256 x (2 TN) tile from the accumulators: lane holds C[m][n .. n+7], m = m0 + wm*64 + 16 i + (lane&15),
 // n = n0 + wn*TN + 32 j' + 8 (lane>>4); values 0-3 from fragment 2j', 4-7 from fragment 2j'+1
-// lds_bias: the problem's whole bias vector in LDS (gemm_nt8i_kernel copies it there once per workgroup) or null.  From LDS the eight
+// lds_bias: the problem's whole bias vector in LDS (gemm_nt8_kernel copies it there once per workgroup) or null.  From LDS the eight
 // values of a fragment pair are read where they are used -- an LDS read does not queue behind the tile's global stores the way a
 // global load does (vmcnt retires in issue order), so nothing has to be fetched up front and held in 32 registers.
 template <typename T, int FN, int TN, int EPI, int NI = 4, bool LB = false>
@@ -203,233 +175,10 @@ __device__ __forceinline__ void tile_epilogue8(const GemmNTArgs& a, f32x4 (&acc)
         }
 }
 
-// One or two problems of equal N and K per launch (GemmNTPair): the tiles of problem 0 come first in the work list, then the
-// tiles of problem 1 -- the two towers' GEMMs of one layer share a launch, so the rounds of 256 workgroups fill up
-// (M = 8192 and M = 12608 at N = 2304: 288 + 450 = 738 tiles = 2.9 rounds instead of 2 + 2).
-template <typename T, int BN, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int persistent) {
-    using C = P8<BN>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename Vec<T>::v8 v8;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1, grp = w >> 2;
-    const int tilesN = g.p[0].N / BN;
-    const int tilesM0 = (g.p[0].M + C::BM - 1) / C::BM, tiles0 = tilesN * tilesM0;
-    const int tilesM1 = g.count > 1 ? (g.p[1].M + C::BM - 1) / C::BM : 0, ntiles = tiles0 + tilesN * tilesM1;
-    const int nk = g.p[0].K / C::BK;
-    const unsigned long long t_start = wall_clock64();
-
-    // ---- work list: tiles first, first + stride, ... in the column-group raster (see gemm.hip), XCD-contiguous
-    const int nwg = gridDim.x;
-    int first, stride, count;
-    if (persistent) {
-        // workgroups b, b+8, ... share an XCD: XCD x owns a contiguous run of the raster and its workgroups walk it round
-        // by round, so the tiles resident on an XCD at any time are neighbours
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, wpx = (nwg + 7 - x) / 8;     // workgroups on this XCD
-        const int q = ntiles >> 3, r = ntiles & 7;
-        const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, n_x = q + (x < r ? 1 : 0);
-        first = lo + j; stride = wpx; count = j < n_x ? (n_x - j + wpx - 1) / wpx : 0;
-    } else {
-        first = xcd_remap(blockIdx.x, nwg); stride = 0; count = 1;
-    }
-    if (count <= 0) return;
-    constexpr int GW = 8;
-    // -> problem index; tiles of a problem in the column-group raster
-    auto tile_origin = [&](int id, int& m0, int& n0) -> int {
-        const int which = id >= tiles0 ? 1 : 0;
-        if (which) id -= tiles0;
-        const int per_group = (which ? tilesM1 : tilesM0) * GW;
-        const int cg = id / per_group, rem = id - cg * per_group;
-        const int gw = min(GW, tilesN - cg * GW);
-        m0 = (rem / gw) * C::BM;
-        n0 = (cg * GW + rem % gw) * BN;
-        return which;
-    };
-
-    // ---- the DMA stream.  K-tiles are numbered globally over the work list (tile t, K-tile k -> t*nk + k); the staging
-    // group of phase p issues its n-th stage for global K-tile n, so each group carries its own running state (no
-    // division in the loop): per-lane source pointers (advanced 128 bytes per stage, re-based when the group enters the
-    // next tile), K-tiles left in its tile, its tile index, its LDS buffer.
-    const int lrow = lane >> 3, lslot = lane & 7;
-    const int total_kt = count * nk;
-    const char* src[C::NPH][C::GPP];
-    int g_rem[C::NPH], g_tile[C::NPH], g_buf[C::NPH], g_done[C::NPH];
-    auto rebase = [&](auto pc_, int id) {
-        constexpr int p = decltype(pc_)::value;
-        int m0, n0;
-        const GemmNTArgs& a = g.p[tile_origin(id, m0, n0)];
-        const char* __restrict__ Ab = (const char*)a.A;
-        const char* __restrict__ Bb = (const char*)a.B;
-#pragma unroll
-        for (int jj = 0; jj < C::gpp(p); ++jj) {
-            const int pc = st_piece<BN>(p, jj, w), row = pc * 8 + lrow;
-            if (st_is_b<BN>(p, jj)) {
-                const int sw = (lrow & 3) | ((pc & 1) << 2);
-                src[p][jj] = Bb + ((size_t)(n0 + row) * a.ldb + (size_t)((lslot ^ sw) * 8)) * 2;
-            } else {
-                const int gm = min(m0 + row, a.M - 1);          // rows past M read a valid row, never stored
-                src[p][jj] = Ab + ((size_t)gm * a.lda + (size_t)((lslot ^ lrow) * 8)) * 2;
-            }
-        }
-    };
-    auto stage = [&](auto pc_) {
-        constexpr int p = decltype(pc_)::value;
-        if (g_done[p] >= total_kt) return;
-        if (g_rem[p] == 0) {
-            g_tile[p] += 1;
-            g_rem[p] = nk;
-            rebase(pc_, first + g_tile[p] * stride);
-        }
-        char* base = smem + g_buf[p] * C::KT;
-#pragma unroll
-        for (int jj = 0; jj < C::gpp(p); ++jj) {
-            const int pc = st_piece<BN>(p, jj, w);
-            char* dst = base + (st_is_b<BN>(p, jj) ? C::A_BYTES : 0) + pc * 1024;
-            __builtin_amdgcn_global_load_lds(MM_GLB(src[p][jj]), MM_LDS(dst), 16, 0, 0);
-            src[p][jj] += 128;
-        }
-        g_rem[p] -= 1;
-        g_done[p] += 1;
-        g_buf[p] = (g_buf[p] + 1 == C::NBUF) ? 0 : g_buf[p] + 1;
-    };
-    auto init_group = [&](auto pc_) {
-        constexpr int p = decltype(pc_)::value;
-        g_rem[p] = nk; g_tile[p] = 0; g_buf[p] = 0; g_done[p] = 0;
-        rebase(pc_, first);
-    };
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, 2> I2;
-    typedef std::integral_constant<int, 3> I3;
-
-    f32x4 acc[4][C::FN];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    zero_acc();
-
-    // fragment read offsets.  A tile: row = wm*64 + 16 i + (lane&15); B tile (permuted): row = wn*TN + 32 j' + 8((lane&15)>>2) + 4 h + (lane&3);
-    // 16-byte chunk = (kk*4 + (lane>>4)) ^ (lane&7) in both
-    const int l15 = lane & 15, kc = lane >> 4, sw7 = lane & 7;
-    const int a_row_off = (wm * 64 + l15) * 128;
-    const int b_row_off = C::A_BYTES + (wn * C::TN + 8 * (l15 >> 2) + (lane & 3)) * 128;
-    const int ch0 = ((0 * 4 + kc) ^ sw7) << 4, ch1 = ((1 * 4 + kc) ^ sw7) << 4;
-    v8 af[4][2], bf[2][2];
-
-    // ---- prologue: the groups the steady state would have issued before K-tile 0
-    init_group(I0{});
-    init_group(I1{});
-    if constexpr (BN == 256) {
-        init_group(I2{});
-        init_group(I3{});
-        stage(I2{}); stage(I3{}); stage(I0{}); stage(I1{});
-        if (total_kt > 1) { stage(I2{}); stage(I3{}); wait_vm<6>(); }
-        else wait_vm<2>();
-    } else if constexpr (BN == 192) {
-        init_group(I2{});
-        stage(I2{}); stage(I0{}); stage(I1{});                       // A(0), B phases 0,1 (0), B phase 2 (0)
-        if (total_kt > 1) { stage(I2{}); wait_vm<5>(); }             // A(1); B phase 2 (0) + A(1) may stay in flight
-        else wait_vm<1>();
-    } else {
-        stage(I0{}); stage(I1{});
-        if (total_kt > 1) { stage(I0{}); stage(I1{}); wait_vm<6>(); }
-        else wait_vm<0>();
-    }
-    raw_barrier();
-    // profiling hook (GEMM_DEBUG_TS, tools/gemm8_ts.py): wave 0 stamps the 100 MHz wall clock at the end of the prologue and, per
-    // tile, after the K loop and after the epilogue's last store was issued
-    unsigned long long* ts = (g.p[0].flags & GEMM_DEBUG_TS) ? (unsigned long long*)g.p[0].aux + (size_t)blockIdx.x * 64 : nullptr;
-    int nts = 0;
-    auto stamp = [&]() { if (ts && tid == 0 && nts < 48) ts[nts++] = wall_clock64(); };
-    long long cyc[4] = {0, 0, 0, 0};
-    const bool cyc_on = ts && (g.p[0].flags & GEMM_DEBUG_CYC);      // second hook: where the cycles of a phase go (intrusive)
-    if (ts && tid == 0) ts[nts++] = t_start;
-    stamp();
-    if (grp == 1) raw_barrier();          // waves 4-7 run one interval behind
-
-    int gkt = 0, cbuf = 0;
-    for (int t = 0; t < count; ++t) {
-#pragma unroll 1
-        for (int k = 0; k < nk; ++k, ++gkt) {
-            const char* Ks = smem + cbuf * C::KT;
-            cbuf = (cbuf + 1 == C::NBUF) ? 0 : cbuf + 1;
-            auto phase = [&](auto pc_) {
-                constexpr int p = decltype(pc_)::value;
-                // ---- L interval: fragment reads of this phase, DMA of a later K-tile, counted wait
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    bf[h][0] = lds_read8<T>(Ks, b_row_off + (32 * p + 4 * h) * 128 + ch0);
-                    bf[h][1] = lds_read8<T>(Ks, b_row_off + (32 * p + 4 * h) * 128 + ch1);
-                }
-                if (p == 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        af[i][0] = lds_read8<T>(Ks, a_row_off + i * (16 * 128) + ch0);
-                        af[i][1] = lds_read8<T>(Ks, a_row_off + i * (16 * 128) + ch1);
-                    }
-                }
-                stage(pc_);
-                const long long c0 = cyc_on ? clock64() : 0;
-                if (BN == 256) {
-                    if (p == 1) { if (gkt + 1 < total_kt) wait_vm<8>(); else wait_vm<0>(); }
-                    if (p == 3) { if (gkt + 2 < total_kt) wait_vm<6>(); else if (gkt + 1 < total_kt) wait_vm<2>(); }
-                } else if (BN == 192) {
-                    // p=1: B phase 2 of THIS K-tile must have landed; issued after it: A(kt+1) 4, B01(kt+1) 2, B2(kt+1) 1
-                    if (p == 1) { if (gkt + 1 < total_kt) wait_vm<7>(); else wait_vm<0>(); }
-                    // p=2: A(kt+1) and B01(kt+1) for the next phase 0; issued after them: B2(kt+1) 1, A(kt+2) 4
-                    if (p == 2) { if (gkt + 2 < total_kt) wait_vm<5>(); else if (gkt + 1 < total_kt) wait_vm<1>(); }
-                } else {
-                    if (p == 1) { if (gkt + 2 < total_kt) wait_vm<6>(); else if (gkt + 1 < total_kt) wait_vm<0>(); }
-                }
-                const long long c1 = cyc_on ? clock64() : 0;
-                raw_barrier();
-                const long long c2 = cyc_on ? clock64() : 0;
-                // ---- C interval
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) acc[i][2 * p + h] = mfma16(bf[h][kk], af[i][kk], acc[i][2 * p + h]);
-                __builtin_amdgcn_s_setprio(0);
-                const long long c3 = cyc_on ? clock64() : 0;
-                raw_barrier();
-                if (cyc_on) { const long long c4 = clock64(); cyc[0] += c1 - c0; cyc[1] += c2 - c1; cyc[2] += c3 - c2; cyc[3] += c4 - c3; }
-            };
-            phase(I0{});
-            phase(I1{});
-            if constexpr (C::NPH >= 3) phase(I2{});
-            if constexpr (C::NPH == 4) phase(I3{});
-        }
-        stamp();
-        // ---- epilogue of tile t, from registers: lane holds C[m][n .. n+7], m = m0 + wm*64 + 16 i + (lane&15),
-        // n = n0 + wn*TN + 32 j' + 8 (lane>>4); values 0-3 from fragment 2j', 4-7 from fragment 2j'+1
-        int m0, n0;
-        const GemmNTArgs& a = g.p[tile_origin(first + t * stride, m0, n0)];
-        tile_epilogue8<T, C::FN, C::TN, EPI>(a, acc, m0, n0, wm, wn, l15, kc);
-        zero_acc();
-        stamp();
-    }
-    if (ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); }
-    // shader-clock cycles of wave 0 and wave 4 spent in: counted DMA wait | barrier after the L interval | MFMAs (incl. waiting for
-    // the fragments) | barrier after the C interval; slots 48.. of the workgroup's stamp row.  Intrusive: every clock read waits
-    // for the wave's outstanding LDS reads (s_memtime returns through lgkmcnt) -- read the split, not the total
-    if (cyc_on && lane == 0 && (w == 0 || w == 4)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ts[48 + (w >> 2) * 4 + i] = (unsigned long long)cyc[i];
-        if (w == 0) ts[56] = (unsigned long long)total_kt * C::NPH;
-    }
-    if (grp == 0) raw_barrier();          // matches the extra interval of waves 4-7
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
-// Round 3: the same tile, LDS image, staging pieces and register epilogue, another K-loop schedule ("interleaved").
-// In-kernel stamps of the kernel above (profiles/r02_gemm8_stamps.txt) put a phase at 770-960 cycles for 256 cycles of MFMA per
+// The K-loop schedule ("interleaved", round 3).  One or two problems of equal N and K per launch (GemmNTPair): the tiles of problem 0
+// come first in the work list, then those of problem 1.
+// In-kernel stamps of the round-2 two-interval schedule (profiles/r02_gemm8_stamps.txt) put a phase at 770-960 cycles for 256 cycles of MFMA per
 // wave: the wave group in its L interval (fragment reads, two LDS-DMA issues at 100-185 cycles each, counted wait) needs longer
 // than the 290 cycles its partner group multiplies, and the partner then stands at the barrier.  Here no wave ever sits in a
 // read-only interval:
@@ -481,7 +230,7 @@ struct I8 {
 };
 
 template <typename T, int BN, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int persistent) {
+__global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int persistent) {
     using C = P8<BN>;
     using P = I8<BN>;
     constexpr int NPH = P::NPH, NBUF = P::NBUF, GPP = BN == 256 ? 2 : (BN == 192 ? 4 : 3);
@@ -632,7 +381,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int per
     int cb = 0;                                  // buffer of the current K-tile
     constexpr int NST1 = 4 * (C::FN / 2);        // global stores of one output tensor per wave and tile
     int grace0 = 0;
-    const bool grace_on = !(g.p[0].flags & GEMM_DEBUG_CYC);      // (debug flag reused as an A/B switch: MMHIP_NT8_NOGRACE)
     for (int t = 0; t < count; ++t) {
         // one K-tile; S0 = the B register set its phase 0 multiplies (sets alternate by phase: with three phases per K-tile also by K-tile)
         auto ktile = [&](auto s0_, int grace) {
@@ -717,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8i_kernel(GemmNTPair g, int per
         zero_acc();
         // stores this wave has just issued and nothing else (a full tile: every row store executes): see `grace` in the K loop
         grace0 = 0;
-        if (grace_on && m0 + C::BM <= a.M) {
+        if (m0 + C::BM <= a.M) {
             if (EPI == EP_GELU) grace0 = (a.flags & GEMM_AUX_PRE) ? 2 * NST1 : NST1;
             else if (EPI == EP_PLAIN && !(a.flags & GEMM_RESIDUAL)) grace0 = NST1;
         }
@@ -783,63 +531,27 @@ static bool nt8_ok(const GemmNTArgs& a, int bn) {
            (!(a.flags & GEMM_BIAS) || al(a.bias)) && a.M > 0;
 }
 
-// workgroups of a persistent launch: one per CU, or (MMHIP_NT8_BALANCE=1) as many as give every workgroup the same number
-// of tiles -- 450 tiles: 225 workgroups x 2 instead of 194 x 2 + 62 x 1 (same two tile times, fewer CUs on the memory path)
-static int nt8_grid(int ntiles) {
-    static int bal = -1;
-    if (bal < 0) { const char* e = getenv("MMHIP_NT8_BALANCE"); bal = e ? atoi(e) : 0; }
-    if (ntiles <= 256) return ntiles;
-    if (!bal) return 256;
-    const int rounds = (ntiles + 255) / 256;
-    int g = (ntiles + rounds - 1) / rounds;
-    g = (g + 7) & ~7;                      // whole XCDs
-    return g > 256 ? 256 : g;
-}
+static int nt8_grid(int ntiles) { return ntiles <= 256 ? ntiles : 256; }      // workgroups of a persistent launch: one per CU
 template <typename T, int BN, int EPI>
 static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
     using C = P8<BN>;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<T, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); done = true; }
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<T, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
     int ntiles = 0;
     for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / BN);
     const int cap = g.p[0].grid > 0 ? (g.p[0].grid < ntiles ? g.p[0].grid : ntiles) : 0;
     const int grid = persistent ? (cap ? cap : nt8_grid(ntiles)) : ntiles;
-    hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI>), dim3(grid), dim3(512), C::LDS, s, g, persistent && ntiles > grid ? 1 : 0);
-}
-template <typename T, int BN, int EPI>
-static void launch_nt8i_e(const GemmNTPair& g, int persistent, hipStream_t s) {
-    using C = P8<BN>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8i_kernel<T, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    int ntiles = 0;
-    for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / BN);
-    const int cap = g.p[0].grid > 0 ? (g.p[0].grid < ntiles ? g.p[0].grid : ntiles) : 0;
-    const int grid = persistent ? (cap ? cap : nt8_grid(ntiles)) : ntiles;
-    static int nograce = -1;
-    if (nograce < 0) { const char* e = getenv("MMHIP_NT8_NOGRACE"); nograce = e ? atoi(e) : 0; }
-    GemmNTPair gg = g;
-    if (nograce) gg.p[0].flags |= GEMM_DEBUG_CYC;
     // the bias vectors live in LDS behind the K-tile buffers (nt8i_ok: they fit the CU's 160 KB)
     size_t lds = C::LDS;
     for (int i = 0; i < g.count; ++i) lds += (size_t)g.p[i].N * 4;
-    hipLaunchKernelGGL((gemm_nt8i_kernel<T, BN, EPI>), dim3(grid), dim3(512), lds, s, gg, persistent && ntiles > grid ? 1 : 0);
+    hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI>), dim3(grid), dim3(512), lds, s, g, persistent && ntiles > grid ? 1 : 0);
 }
 // epilogue class that covers a flag set (a pair uses the class that covers both)
 static int nt8_class(int f) {
-    f &= ~(GEMM_DEBUG_TS | GEMM_DEBUG_CYC);
     if (f == (GEMM_BIAS | GEMM_GELU) || f == (GEMM_BIAS | GEMM_GELU | GEMM_AUX_PRE) || f == (GEMM_BIAS | GEMM_QGELU)) return EP_GELU;
     if (f == GEMM_MUL_GELU_GRAD || f == (GEMM_MUL_GELU_GRAD | GEMM_RESIDUAL)) return EP_MULG;
     if (!(f & ~(GEMM_BIAS | GEMM_DROPOUT | GEMM_RESIDUAL))) return EP_PLAIN;
     return EP_ANY;
-}
-template <typename T, int BN>
-static void launch_nt8i_t(const GemmNTPair& g, int persistent, hipStream_t s) {
-    int c = nt8_class(g.p[0].flags);
-    if (g.count > 1 && nt8_class(g.p[1].flags) != c) c = EP_ANY;
-    if (c == EP_GELU) launch_nt8i_e<T, BN, EP_GELU>(g, persistent, s);
-    else if (c == EP_MULG) launch_nt8i_e<T, BN, EP_MULG>(g, persistent, s);
-    else if (c == EP_PLAIN) launch_nt8i_e<T, BN, EP_PLAIN>(g, persistent, s);
-    else launch_nt8i_e<T, BN, EP_ANY>(g, persistent, s);
 }
 template <typename T, int BN>
 static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
@@ -851,18 +563,6 @@ static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
     else launch_nt8_e<T, BN, EP_ANY>(g, persistent, s);
 }
 static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent, hipStream_t s) {
-    if (bn == 257 || bn == 193 || bn == 129) {             // interleaved schedule, 256 x 256 / 192 / 128
-        if (dtype == DT_BF16) {
-            if (bn == 257) launch_nt8i_t<bf16_t, 256>(g, persistent, s);
-            else if (bn == 193) launch_nt8i_t<bf16_t, 192>(g, persistent, s);
-            else launch_nt8i_t<bf16_t, 128>(g, persistent, s);
-        } else {
-            if (bn == 257) launch_nt8i_t<f16_t, 256>(g, persistent, s);
-            else if (bn == 193) launch_nt8i_t<f16_t, 192>(g, persistent, s);
-            else launch_nt8i_t<f16_t, 128>(g, persistent, s);
-        }
-        return;
-    }
     if (dtype == DT_BF16) {
         if (bn == 256) launch_nt8_t<bf16_t, 256>(g, persistent, s);
         else if (bn == 192) launch_nt8_t<bf16_t, 192>(g, persistent, s);
@@ -874,18 +574,14 @@ static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent,
     }
 }
 
-// bn: 256, 192 or 128 (two-interval schedule); 257 / 193 / 129 = the same tiles with the interleaved schedule.  Returns false when the
-// shape rules of the kernel do not hold (caller falls back).
-// interleaved kernel: bias vector(s) in LDS behind the K-tile buffers; 32-bit byte offsets into the operands
-static bool nt8i_ok(const GemmNTArgs& a, int nprob, int bn) {
+// the problems' bias vectors live in LDS behind the K-tile buffers; a piece's source is a 32-bit byte offset from the operand's base
+static bool nt8_fits(const GemmNTArgs& a, int nprob, int bn) {
     const size_t lds = (bn == 256 ? P8<256>::LDS : (bn == 192 ? P8<192>::LDS : P8<128>::LDS)) + (size_t)a.N * 4 * nprob;
     return lds <= 160 * 1024 && (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldb * 2 < (1ull << 32);
 }
+// bn: 256, 192 or 128.  Returns false when the shape rules of the kernel do not hold (caller falls back).
 bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hipStream_t s) {
-    const bool il = bn == 257 || bn == 193 || bn == 129;
-    if (il && !nt8i_ok(a, 1, bn - 1)) bn -= 1;
-    const int w = (bn == 257 || bn == 193 || bn == 129) ? bn - 1 : bn;
-    if ((w != 256 && w != 192 && w != 128) || !nt8_ok(a, w)) return false;
+    if ((bn != 256 && bn != 192 && bn != 128) || !nt8_ok(a, bn) || !nt8_fits(a, 1, bn)) return false;
     GemmNTPair g;
     g.p[0] = a; g.p[1] = a; g.count = 1;
     launch_nt8_d(g, dtype, bn, persistent, s);
@@ -906,7 +602,7 @@ bool launch_gemm_nt8_pair(const GemmNTArgs& a0, const GemmNTArgs& a1, int dtype,
             if (u > best) { best = u; bn = cand; }
         }
     }
-    if ((bn != 256 && bn != 192 && bn != 128) || !nt8_ok(a0, bn) || !nt8_ok(a1, bn)) return false;
+    if ((bn != 256 && bn != 192 && bn != 128) || !nt8_ok(a0, bn) || !nt8_ok(a1, bn) || !nt8_fits(a0, 2, bn)) return false;
     GemmNTPair g;
     g.p[0] = a0; g.p[1] = a1; g.count = 2;
     launch_nt8_d(g, dtype, bn, 1, s);

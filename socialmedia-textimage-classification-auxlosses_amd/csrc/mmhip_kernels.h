@@ -20,8 +20,6 @@ enum {
     GEMM_MUL_GELU_GRAD = 64,  // value *= gelu'(mul_in[m][n])
     GEMM_TANH = 128,
     GEMM_QGELU = 256,         // quick-GELU x * sigmoid(1.702 x)   (HF CLIP hidden_act "quick_gelu")
-    GEMM_DEBUG_TS = 1 << 20,  // gemm8.hip only (tools/gemm8_ts.py): workgroup b writes wall-clock stamps to ((u64*)aux)[b*64 ..]
-    GEMM_DEBUG_CYC = 1 << 21, // with GEMM_DEBUG_TS: also split the shader-clock cycles of every phase (slows the kernel)
 };
 struct GemmNTArgs {
     const void* A; const void* B; void* C; void* aux; const float* bias; const void* residual; const void* mul_in;

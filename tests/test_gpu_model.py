@@ -922,5 +922,6 @@ def test_gemm_timing_counts_the_steps_nt_launches():
         assert abs(fl.value - want) < 1e-6 * want, (fl.value, want)
         assert ms.value > 0
         rows = [l.split() for l in buf.value.decode().strip().splitlines()[1:]]
-        assert sum(int(r[5]) for r in rows) == n.value and all(float(r[8]) > 0 for r in rows)
+        # columns: M N K flags tile cus n avg_us total_ms TFLOP/s TF/CU-share
+        assert sum(int(r[6]) for r in rows) == n.value and all(float(r[9]) > 0 and 0 < int(r[5]) <= 256 for r in rows)
         assert {(int(r[0]), int(r[1]), int(r[2])) for r in rows} >= {(Mv, 3 * H, H), (Mv, H, I), (Mt, 3 * H, H), (Mt, I, H)}

@@ -16,7 +16,7 @@ dev = torch.device("cuda:0")
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 
-VARIANTS = [("r1 auto", 0), ("128x128", 1), ("8ph 256x256", 13), ("8ph 256x256 P", 15), ("8ph 256x128 P", 16), ("8ph 256x192 P", 18), ("il 256x256", 19), ("il 256x256 P", 20), ("il 256x192 P", 22), ("il 256x128 P", 24)]
+VARIANTS = [("r1 auto", 0), ("128x128", 1), ("role 256x128", 9), ("role 256x96", 12), ("dp 256x256", 13), ("dp 256x256 P", 15), ("dp 256x128 P", 16), ("dp 256x192 P", 18)]
 if os.environ.get("VARIANTS"):
     VARIANTS = [v for v in VARIANTS if str(v[1]) in os.environ["VARIANTS"].split(",")]
 
@@ -43,7 +43,7 @@ def main():
         bias = torch.randn(N, device=dev)
         fns = []
         for _, tile in VARIANTS:
-            if (tile in (13, 15, 19, 20) and N % 256) or (tile in (17, 18, 21, 22) and N % 192):
+            if (tile in (13, 15) and N % 256) or (tile in (17, 18) and N % 192) or (tile == 12 and N % 96):
                 fns.append(None)
                 continue
             if epi == "gelu":
