@@ -172,6 +172,24 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, float* loss,
                      int* n_correct, void* stream);
 
+/* ---- the same step under data parallelism (reference: none -- SURVEY.md 2.1; semantics "the reference's step per rank, gradients averaged").
+ * The gradient exchange belongs to the caller (torch.distributed / RCCL in smtc_amd/dist.py), the enqueue order to the library: `on_stage`
+ * is called on the host, between launches,
+ *   on_stage(user, st)  0 <= st < mmhip_num_backward_stages: the parameter gradients of backward stage st (mmhip_stage_grad_range) are final
+ *                       in `stream` order -- called while the stages below st are already enqueued, so a collective started here travels
+ *                       beside them;
+ *   on_stage(user, MMHIP_CB_WAIT_DENSE)   after the last stage: make `stream` wait for the dense collectives (Work.wait());
+ *   on_stage(user, MMHIP_CB_FINISH_ROWS)  after the dense AdamW and the 16-bit weight refresh were enqueued: finish the row-sparse
+ *                       word-table exchange (it travelled meanwhile); the row-lazy AdamW of the table follows.
+ * A non-zero return aborts the step with that code.  grad_scale = 1 / world.  Everything else as mmhip_train_step. */
+enum { MMHIP_CB_WAIT_DENSE = -1, MMHIP_CB_FINISH_ROWS = -2 };
+typedef int (*mmhip_exchange_cb)(void* user, int stage);
+int mmhip_train_step_dp(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
+                        const int64_t* tim_mask, const int64_t* lbl_tim, const int64_t* onehot, const float* class_w, int B, int T,
+                        uint64_t seed, int use_itc, int use_itm, float w_cls, float w_itc, float w_itm, float* adam_m, float* adam_v,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, float* loss,
+                        int* n_correct, void* stream, mmhip_exchange_cb on_stage, void* user);
+
 /* Debug: phase ends of the last forward / train step, in milliseconds after the forward's fork, from HIP events recorded on the
  * streams the phases run on (no profiler in the way): ms[0] image tower end, [1] text tower end, [2] forward end, [3] backward
  * end, [4] step end; -1 = not recorded.  enable != 0 arms the events for the steps that follow.  Synchronises the device.

@@ -42,6 +42,8 @@ class MMHipError(RuntimeError):
     pass
 
 
+EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)      # include/mmhip.h: mmhip_exchange_cb
+CB_WAIT_DENSE, CB_FINISH_ROWS = -1, -2
 _lib = None
 P, I, F, U64, U32, I64P = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p
 
@@ -72,6 +74,7 @@ _SIGS = {
     "mmhip_set_nonfinite_counter": (I, [P]),
     "mmhip_set_loss_scale": (I, [P, F]),
     "mmhip_train_step": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P]),
+    "mmhip_train_step_dp": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P, P, P]),
     "mmhip_image_plan_words": (U64, [I, P, P, I]),
     "mmhip_image_plan_build": (I, [I, P, P, P, I, P, U64]),
     "mmhip_image_plan_tmp_bytes": (U64, [P]),

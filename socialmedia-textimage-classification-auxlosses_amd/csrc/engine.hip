@@ -1321,11 +1321,11 @@ int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width
 // One fused training step, enqueued natively (no per-stage host round trips): forward (train mode) -> loss -> backward ->
 // AdamW over the ranges that receive gradients for this flag set (torch skips `grad is None` tensors) ->
 // 16-bit weight refresh.  Single-rank form of MMLate_Model.train_step; a data-parallel caller keeps the staged calls.
-int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
-                     const int64_t* tim_mask, const int64_t* lbl_tim, const int64_t* onehot, const float* class_w, int B, int T,
-                     uint64_t seed, int use_itc, int use_itm, float w_cls, float w_itc, float w_itm, float* adam_m, float* adam_v,
-                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, float* loss,
-                     int* n_correct, void* stream) {
+static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
+                           const int64_t* tim_mask, const int64_t* lbl_tim, const int64_t* onehot, const float* class_w, int B, int T,
+                           uint64_t seed, int use_itc, int use_itm, float w_cls, float w_itc, float w_itm, float* adam_m, float* adam_v,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, float* loss,
+                           int* n_correct, void* stream, mmhip_exchange_cb cb, void* user) {
     if (!h || !h->ws || !h->grad) return MMHIP_E_STATE;
     if (!adam_m || !adam_v || !onehot || step < 1) return MMHIP_E_INVALID;
     if (use_itm && (!tim_ids || !lbl_tim)) return MMHIP_E_INVALID;
@@ -1345,10 +1345,17 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
     const int early = early_env ? atoi(early_env) : 1;
     if (int r = mmhip_backward_begin(h, nullptr, nullptr, nullptr, nullptr, stream)) return r;
     const int L = e.cfg.layers_txt;
-    const bool layer_opt = early && use_side(e);
+    // data-parallel form (cb): the layer optimizers wait for the gradient exchange, so they run after it (below); the callback is told
+    // about stage st-1 once stage st is enqueued and st-1's weight gradients are ordered in the caller's stream -- its collective
+    // travels while the stages below compute
+    const bool layer_opt = early && use_side(e) && !cb;
     bool opt_pending = false;
     for (int st = 0; st < L + 2; ++st) {
         if (int r = mmhip_backward_stage(h, st, stream)) return r;
+        if (cb && st >= 1) {
+            if (int r = mmhip_backward_join_stage(h, st - 1, stream)) return r;
+            if (int r = cb(user, st - 1)) return r;
+        }
         if (layer_opt && st >= 1 && st <= L) {
             const int l = L - st, set = l & 1;
             const LayerOff& o = e.txt[l];
@@ -1363,23 +1370,24 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
     }
     if (int r = mmhip_backward_finish(h, stream)) return r;
     if (opt_pending) CHECK_HIP(hipStreamWaitEvent(s, e.ev_opt, 0));
+    if (cb) {
+        if (int r = cb(user, L + 1)) return r;                    // embedding stage: dense part + the row-sparse word-table exchange start
+        if (int r = cb(user, MMHIP_CB_WAIT_DENSE)) return r;      // the dense all-reduces are ordered before what follows in `stream`
+    }
     if (int r = e.span(4, s)) return r;
     // merged [begin, end) ranges of the active gradient groups, in address order (text layers already stepped: skipped)
     bool act[6] = {false, use_itc != 0, use_itm != 0, e.cfg.fusion == MMHIP_FUSION_ATTENTION, true, false};
     const uint64_t w0 = e.t_word, V = (uint64_t)e.cfg.vocab, H = (uint64_t)e.cfg.hidden;
     uint64_t rb = 0, re = 0;
     bool open = false;
+    bool rows_due = false;
     auto flush = [&]() -> int {
         if (!open || re <= rb) return 0;
         const uint64_t dense_end = re < w0 ? re : w0;
         if (dense_end > rb)
             if (int r = mmhip_adamw(e.train + rb, e.grad + rb, adam_m + rb, adam_v + rb, dense_end - rb, lr, beta1, beta2, eps, weight_decay, step,
                                     grad_scale, 1, stream)) return r;
-        if (re > w0) {
-            if (!e.word_row_state) return MMHIP_E_STATE;
-            if (int r = mmhip_adamw_rows(e.train + w0, e.grad + w0, adam_m + w0, adam_v + w0, (int)V, (int)H, e.word_row_state, lr, beta1, beta2, eps,
-                                         weight_decay, step, grad_scale, 1, stream)) return r;
-        }
+        if (re > w0) rows_due = true;          // the word table goes last: under data parallelism its rows are still travelling
         return 0;
     };
     auto in_layer = [&](uint64_t off) {
@@ -1395,8 +1403,32 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
         rb = b; re = en; open = true;
     }
     if (int r = flush()) return r;
-    if (!opt_pending) if (int r = mmhip_refresh_weights(h, 2, stream)) return r;
+    if (!opt_pending) if (int r = mmhip_refresh_weights(h, 2, stream)) return r;      // 16-bit GEMM operand copies: no word-table dependence
+    if (rows_due) {
+        if (cb) if (int r = cb(user, MMHIP_CB_FINISH_ROWS)) return r;                 // the exchanged word rows are summed into the gradient
+        if (!e.word_row_state) return MMHIP_E_STATE;
+        if (int r = mmhip_adamw_rows(e.train + w0, e.grad + w0, adam_m + w0, adam_v + w0, (int)V, (int)H, e.word_row_state, lr, beta1, beta2, eps,
+                                     weight_decay, step, grad_scale, 1, stream)) return r;
+    }
     return e.span(5, s);
+}
+
+int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
+                     const int64_t* tim_mask, const int64_t* lbl_tim, const int64_t* onehot, const float* class_w, int B, int T,
+                     uint64_t seed, int use_itc, int use_itm, float w_cls, float w_itc, float w_itm, float* adam_m, float* adam_v,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, float* loss,
+                     int* n_correct, void* stream) {
+    return train_step_impl(h, ids, mask, pixels, tim_ids, tim_mask, lbl_tim, onehot, class_w, B, T, seed, use_itc, use_itm, w_cls, w_itc, w_itm,
+                           adam_m, adam_v, lr, beta1, beta2, eps, weight_decay, step, grad_scale, loss, n_correct, stream, nullptr, nullptr);
+}
+int mmhip_train_step_dp(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
+                        const int64_t* tim_mask, const int64_t* lbl_tim, const int64_t* onehot, const float* class_w, int B, int T,
+                        uint64_t seed, int use_itc, int use_itm, float w_cls, float w_itc, float w_itm, float* adam_m, float* adam_v,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, float* loss,
+                        int* n_correct, void* stream, mmhip_exchange_cb on_stage, void* user) {
+    if (!on_stage) return MMHIP_E_INVALID;
+    return train_step_impl(h, ids, mask, pixels, tim_ids, tim_mask, lbl_tim, onehot, class_w, B, T, seed, use_itc, use_itm, w_cls, w_itc, w_itm,
+                           adam_m, adam_v, lr, beta1, beta2, eps, weight_decay, step, grad_scale, loss, n_correct, stream, on_stage, user);
 }
 
 // phase ends of the last step as milliseconds after the forward's fork (hipEvents on the streams the phases run on; no profiler):

@@ -516,6 +516,10 @@ class MMLate_Model(object):
             # single rank: the whole step is one native call (include/mmhip.h: mmhip_train_step) -- the host enqueues ~250
             # kernels from C++ instead of crossing ctypes ~40 times per step
             return self._native_step(ids, mask, pixel_values, tim_ids, tim_mask, lbl_tim, onehot, cw, lr, weight_decay, step, loss, ncorr)
+        if exchange and vision_keys is None and os.environ.get("MMHIP_NATIVE_DP", "1") != "0":
+            # data parallel: the same native enqueue (include/mmhip.h: mmhip_train_step_dp); the library calls back between launches so that
+            # this process starts / finishes the collectives (dist.py) at the points the staged loop below would
+            return self._native_step(ids, mask, pixel_values, tim_ids, tim_mask, lbl_tim, onehot, cw, lr, weight_decay, step, loss, ncorr, exchange=True)
         m._engine_forward(ids, mask, pixel_values, tim_ids, tim_mask, vision_keys=vision_keys)
         _lib.check(lib.mmhip_loss(m._handle, _lib.ptr(onehot), _lib.ptr(cw), _lib.ptr(lbl_tim), w_cls, w_itc, w_itm, _lib.ptr(loss),
                                   _lib.ptr(ncorr), s), "loss")
@@ -552,7 +556,7 @@ class MMLate_Model(object):
             m._word_row_state.bitwise_and_(1)                      # fresh moments: no row has any yet
         return self._opt
 
-    def _native_step(self, ids, mask, pixels, tim_ids, tim_mask, lbl_tim, onehot, cw, lr, weight_decay, step, loss, ncorr):
+    def _native_step(self, ids, mask, pixels, tim_ids, tim_mask, lbl_tim, onehot, cw, lr, weight_decay, step, loss, ncorr, exchange=False):
         m = self.model
         dev = self.device
         ids = ids.to(dev, torch.int64).contiguous()
@@ -566,12 +570,41 @@ class MMLate_Model(object):
         m._calls += 1
         seed = (m._seed_base * 0x9E3779B97F4A7C15 + m._calls) & 0xFFFFFFFFFFFFFFFF
         w_cls, w_itc, w_itm = self.loss_weights()
-        _lib.check(_lib.lib().mmhip_train_step(m._handle, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(pixels), _lib.ptr(tim_ids), _lib.ptr(tim_mask),
-                                               _lib.ptr(lbl_tim), _lib.ptr(onehot), _lib.ptr(cw), B, T, seed, int(bool(self.use_clip_loss)),
-                                               int(bool(self.use_tim_loss)), w_cls, w_itc, w_itm, _lib.ptr(em), _lib.ptr(ev), lr, 0.9, 0.999, 1e-8,
-                                               weight_decay, step, 1.0, _lib.ptr(loss), _lib.ptr(ncorr), _lib.stream_ptr()), "train_step")
-        m._fwd_token += 1
+        if tim_ids is not None:
+            tim_ids = tim_ids.to(dev, torch.int64).contiguous()
+            tim_mask = tim_mask.to(dev, torch.int64).contiguous()
         m._last = dict(B=B, T=T, itm=tim_ids is not None, seed=seed, ids=ids)
+        args = (m._handle, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(pixels), _lib.ptr(tim_ids), _lib.ptr(tim_mask), _lib.ptr(lbl_tim), _lib.ptr(onehot),
+                _lib.ptr(cw), B, T, seed, int(bool(self.use_clip_loss)), int(bool(self.use_tim_loss)), w_cls, w_itc, w_itm, _lib.ptr(em), _lib.ptr(ev),
+                lr, 0.9, 0.999, 1e-8, weight_decay, step, 1.0 / self.world, _lib.ptr(loss), _lib.ptr(ncorr), _lib.stream_ptr())
+        if not exchange:
+            _lib.check(_lib.lib().mmhip_train_step(*args), "train_step")
+        else:
+            works, finishers, failure = [], [], []
+            buckets = mmdist.StageBuckets(m._flat_grad)
+            n_stage = len(m._stage_ranges)
+
+            def on_stage(_user, st):
+                try:
+                    if st >= 0:
+                        works.extend(mmdist.exchange_stage(m, st, n_stage, self.use_clip_loss, self.use_tim_loss, finishers if st == n_stage - 1 else None,
+                                                           buckets=buckets))
+                    elif st == _lib.CB_WAIT_DENSE:
+                        for w in works + buckets.works:
+                            w.wait()
+                    elif st == _lib.CB_FINISH_ROWS:
+                        for f in finishers:
+                            f()
+                    return 0
+                except BaseException as exc:              # a Python exception must not unwind through the C frames
+                    failure.append(exc)
+                    return -2
+            cb = _lib.EXCHANGE_CB(on_stage)
+            rc = _lib.lib().mmhip_train_step_dp(*args, cb, None)
+            if failure:
+                raise failure[0]
+            _lib.check(rc, "train_step_dp")
+        m._fwd_token += 1
         m._flat_train._version                                        # (read only; the refresh inside the call keeps the 16-bit copies current)
         m._weights_version = (m._flat_train._version, m._flat_frozen._version)
         return loss, ncorr
