@@ -78,10 +78,11 @@ def prepare_data(data, num_labels, testing=False, nsamples=-1, seed=None):
 class MM_Dataset(torch.utils.data.Dataset):
     """item layout of reference models/datasets.py:125-190"""
 
-    def __init__(self, tweet_ids, texts, labels, tokenizer, max_length, img_file_fmt, image=224, raw_images=False):
+    def __init__(self, tweet_ids, texts, labels, tokenizer, max_length, img_file_fmt, image=224, raw_images=False, batch_tokenize=False):
         self.ids, self.texts, self.labels = tweet_ids, texts, labels
         self.tok, self.max_length, self.fmt, self.image = tokenizer, max_length, img_file_fmt, image
         self.raw_images = raw_images        # True: yield the decoded RGB bytes; resize + normalize run on the GPU per batch
+        self.batch_tokenize = batch_tokenize    # True: yield the normalised text; BatchTokenizeCollate encodes the whole batch in one call
         self._lut = None
 
     def __len__(self):
@@ -104,14 +105,44 @@ class MM_Dataset(torch.utils.data.Dataset):
         return torch.from_numpy(self._lut[np.asarray(img)]).permute(2, 0, 1).contiguous().unsqueeze(0)
 
     def __getitem__(self, i):
-        enc = self.tok(normalize_tweet(self.texts[i]), padding="max_length", truncation=True, max_length=self.max_length, return_tensors="pt")
-        item = {"input_ids": enc["input_ids"], "attention_mask": enc["attention_mask"], "labels": torch.from_numpy(self.labels[i]),
-                "data_id": torch.tensor(int(self.ids[i]))}
+        item = {"labels": torch.from_numpy(self.labels[i]), "data_id": torch.tensor(int(self.ids[i]))}
+        if self.batch_tokenize:
+            item["text"] = normalize_tweet(self.texts[i])
+        else:
+            enc = self.tok(normalize_tweet(self.texts[i]), padding="max_length", truncation=True, max_length=self.max_length, return_tensors="pt")
+            item["input_ids"], item["attention_mask"] = enc["input_ids"], enc["attention_mask"]
         if self.raw_images:
             item["image"] = np.asarray(self._open(self.ids[i]))
         else:
             item["pixel_values"] = self._pixels(self.ids[i])
         return item
+
+
+def worker_init(_worker_id):
+    """DataLoader worker: one thread per worker.  The GPU box grants a CPU share (16 cores), not the host's 256: a Rust tokenizer pool or an
+    OpenMP team sized by the host's core count inside each of 8+ workers oversubscribes that share and throttles the process that enqueues
+    the GPU step (tools/loader_bench.py)."""
+    os.environ["TOKENIZERS_PARALLELISM"] = "false"
+    os.environ["OMP_NUM_THREADS"] = "1"
+    torch.set_num_threads(1)
+
+
+class BatchTokenizeCollate:
+    """collate_fn: the batch's normalised texts -> input_ids / attention_mask [B, max_length] in ONE tokenizer call (the fast tokenizers'
+    encode_batch: Rust, all cores of the worker) instead of one Python-level call per item (reference models/datasets.py:141-146 encodes per
+    item and the default collate stacks [B, 1, T]; same ids, same padding='max_length' / truncation).  The remaining fields go to `inner`
+    (RawImageCollate for decoded images) or to the default collate."""
+
+    def __init__(self, tokenizer, max_length, inner=None):
+        self.tok, self.max_length, self.inner = tokenizer, max_length, inner
+
+    def __call__(self, items):
+        from torch.utils.data import default_collate
+        enc = self.tok([it["text"] for it in items], padding="max_length", truncation=True, max_length=self.max_length, return_tensors="pt")
+        rest = [{k: v for k, v in it.items() if k != "text"} for it in items]
+        batch = self.inner(rest) if self.inner is not None else default_collate(rest)
+        batch["input_ids"], batch["attention_mask"] = enc["input_ids"], enc["attention_mask"]
+        return batch
 
 
 def loaders_from_data_key(cfg, args, trainer):
@@ -128,12 +159,20 @@ def loaders_from_data_key(cfg, args, trainer):
     # image resize + normalize run on the GPU per batch (image_processing.py) unless --cpu_preprocess asks for the host form
     gpu = not getattr(args, "cpu_preprocess", False) and trainer.device.type == "cuda"
     size = trainer.model.arch["image"]
-    mk = lambda df, y: MM_Dataset(df.tweet_id.values, df.text.values, y, tok, cfg.max_length, cfg.img_fmt, size, raw_images=gpu)
+    # texts are encoded per batch in the collate (one encode_batch call) unless --item_tokenize keeps the reference's per-item calls
+    batch_tok = not getattr(args, "item_tokenize", False) and getattr(tok, "is_fast", False)
+    mk = lambda df, y: MM_Dataset(df.tweet_id.values, df.text.values, y, tok, cfg.max_length, cfg.img_fmt, size, raw_images=gpu, batch_tokenize=batch_tok)
     kw = dict(num_workers=int(getattr(args, "num_workers", 0) or 0))
+    if kw["num_workers"] > 0:
+        kw.update(persistent_workers=True, prefetch_factor=4, worker_init_fn=worker_init)
+    inner = None
     if gpu:
         from .image_processing import GpuImageProcessor, RawImageCollate
         trainer.image_processor = GpuImageProcessor(size=size, device=trainer.device)
-        kw["collate_fn"] = RawImageCollate(trainer.image_processor)
+        inner = RawImageCollate(trainer.image_processor)
+        kw["collate_fn"] = inner
+    if batch_tok:
+        kw["collate_fn"] = BatchTokenizeCollate(tok, cfg.max_length, inner)
     dl = lambda ds, sh: torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh, **kw)
     train_ds = mk(tr, ytr)
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:

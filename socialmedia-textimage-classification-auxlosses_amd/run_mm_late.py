@@ -63,7 +63,8 @@ def build_parser():
     p.add_argument("--results_dir", type=str, default=None, help="default ../results/mm_late/ as in the reference")
     p.add_argument("--arch_layers", type=int, default=None, help="(testing) override encoder depth")
     p.add_argument("--cpu_preprocess", action="store_true", help="resize / normalize images on the host (PIL) instead of the GPU kernels")
-    p.add_argument("--num_workers", type=int, default=0, help="DataLoader workers (reference: 0)")
+    p.add_argument("--num_workers", type=int, default=0, help="DataLoader workers (reference: 0); 8 or more keep the image decode ahead of the GPU step (tools/loader_bench.py)")
+    p.add_argument("--item_tokenize", action="store_true", help="tokenise per item like the reference instead of once per batch in the collate")
     p.add_argument("--cache_vision", type=int, default=0, metavar="POSTS",
                    help="keep the frozen image tower's outputs of up to POSTS posts in HBM (306 KB each): epochs after the first skip the tower")
     return p
@@ -83,6 +84,8 @@ def make_loaders(args, cfg, trainer):
     a = trainer.model.arch
     if cfg.data is not None and not args.synthetic:
         from .datasets import loaders_from_data_key
+        if int(getattr(args, "num_workers", 0) or 0) > 0 and trainer.device.type == "cuda":
+            trainer.warm_start()                 # the first step before the DataLoader forks its workers (MMLate_Model.warm_start)
         return loaders_from_data_key(cfg, args, trainer)
     n = 200 if args.testing else args.n_synthetic                        # --testing subsamples 200 rows (models/utils.py:135-138)
     rank = mmdist.rank()
@@ -101,6 +104,10 @@ def main(argv=None):
             # outside the hot path (DESIGN.md "Out of scope"); refused rather than silently ignored
             raise NotImplementedError(f"--{flag} is not part of this build")
     mmdist.init_from_env()
+    # the host side of a step is a handful of tiny tensor ops; torch's intra-op pool defaults to one thread per host core (256) and those
+    # threads spin after every parallel region -- measured on the 16-core CPU share of a GPU box: the training process burned 15 cores
+    # spinning and left 1.4 to the eight DataLoader workers (tools/loader_bench.py, profiles/r03_loader_bench.txt)
+    torch.set_num_threads(max(1, int(os.environ.get("MMHIP_HOST_THREADS", "4"))))
     torch.manual_seed(args.seed)                      # models/run_mm_late.py:48-49 (same on every rank: identical initial weights)
     np.random.seed(args.seed + mmdist.rank())         # ITM negative sampling draws from numpy: its own stream per rank
     results_dir = args.results_dir or results_dir_mm_late
