@@ -327,6 +327,305 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ parity mode (bf16x3)
+// The same two kernels on fp32 tensors: every MFMA operand is the pair hi = bf16(x), lo = bf16(x - hi) and every product the three MFMAs
+// lo.hi + hi.lo + hi.hi (mma3_32), fp32 everywhere else.  The K / V (backward: Q / dO / K) images are split while they are staged, so LDS
+// holds two 16-bit images per tensor; P and dS are split in registers where the 16-bit kernels convert them.  (Round 2 ran this mode's
+// attention on the vector ALUs, one query per thread, one wave per SIMD: 26 ms of a 71 ms step.)
+__device__ __forceinline__ void stage_image_x3(char* hi, char* lo, const float* src, int ld, int rows_valid, int rows_pad, bool tr_layout, int tid, int nthreads) {
+    for (int idx = tid; idx < rows_pad * 8; idx += nthreads) {
+        const int row = idx >> 3, ch = idx & 7;
+        const int gr = min(row, rows_valid - 1);
+        float v[8];
+        load8(src + (size_t)gr * ld + ch * 8, v);
+        const Frag3 f = split8(v);
+        const int off = tr_layout ? trimg_off(row, ch) : rowimg_off(row, ch);
+        *reinterpret_cast<bf16x8*>(hi + off) = f.hi;
+        *reinterpret_cast<bf16x8*>(lo + off) = f.lo;
+    }
+}
+__device__ __forceinline__ Frag3 lds_pair(const char* hi, const char* lo, int off) {
+    Frag3 f;
+    f.hi = lds_read8<bf16_t>(hi, off);
+    f.lo = lds_read8<bf16_t>(lo, off);
+    return f;
+}
+__device__ __forceinline__ Frag3 global_pair(const float* p) {
+    float v[8];
+    load8(p, v);
+    return split8(v);
+}
+
+template <int NKT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NKT * 32, IMG = SP * 128;
+    char* Kh = smem;                         // [SP][64] row images of K (hi, lo), tr images of V (hi, lo)
+    char* Kl = smem + IMG;
+    char* Vh = smem + 2 * IMG;
+    char* Vl = smem + 3 * IMG;
+    float* mb = reinterpret_cast<float*>(smem + 4 * IMG);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int head = blockIdx.x, post = blockIdx.y;
+    const int S = a.S;
+    const float* base = (const float*)a.qkv + (size_t)post * S * a.ld_qkv + head * HD;
+    stage_image_x3(Kh, Kl, base + a.hidden, a.ld_qkv, S, SP, false, tid, NW * 64);
+    stage_image_x3(Vh, Vl, base + 2 * a.hidden, a.ld_qkv, S, SP, true, tid, NW * 64);
+    for (int k = tid; k < SP; k += NW * 64) {
+        float b = (k < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f) : -INFINITY;
+        mb[k] = b * LOG2E;
+    }
+    __syncthreads();
+    const int r = lane & 31, h2 = lane >> 5;
+    const float sc = a.scale * LOG2E;
+    const int nqt = a.q_tiles > 0 ? min((S + 31) / 32, a.q_tiles) : (S + 31) / 32;
+    const bool dropping = a.drop.thresh16 != 0;
+    for (int qt = w; qt < nqt; qt += NW) {
+        const int q = qt * 32 + r;
+        const int qrow = min(q, S - 1);
+        const float* qp = base + (size_t)qrow * a.ld_qkv + 8 * h2;
+        Frag3 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = global_pair(qp + 16 * s);
+        const uint32_t ebase = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)qrow) * (uint32_t)S;
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x16 oacc[2] = {f32x16{}, f32x16{}};
+#pragma unroll 1
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x16 acc = f32x16{};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mma3_32(lds_pair(Kh, Kl, rowimg_off(kt * 32 + r, 2 * s + h2)), qf[s], acc);
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 b = *reinterpret_cast<const f32x4*>(mb + kt * 32 + 8 * g + 4 * h2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[4 * g + e] * sc + b[e];
+                    acc[4 * g + e] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);
+            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = exp2f(m_run - m_safe);
+            float psum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = exp2f(acc[e] - m_safe);
+                acc[e] = p;
+                psum += p;
+            }
+            psum += __shfl_xor(psum, 32);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int reg = 8 * s2 + j;
+                    float p = acc[reg];
+                    if (dropping) {
+                        const int key = kt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+                        p = mm_keep(ebase + (uint32_t)key, a.drop) ? p * a.drop.keep_scale : 0.f;
+                    }
+                    pv[j] = p;
+                }
+                const Frag3 pf = split8(pv);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    Frag3 vf;
+                    vf.hi = tr_frag_acc_order<bf16_t>(Vh, kt * 32 + 16 * s2, dt * 32, lane);
+                    vf.lo = tr_frag_acc_order<bf16_t>(Vl, kt * 32 + 16 * s2, dt * 32, lane);
+                    oacc[dt] = mma3_32(vf, pf, oacc[dt]);
+                }
+            }
+        }
+        if (a.lse && h2 == 0 && q < S) a.lse[((size_t)post * a.heads + head) * S + q] = (m_run + log2f(l_run)) * (1.0f / LOG2E);
+        const float inv = 1.0f / l_run;
+        if (q < S) {
+            float* op = (float*)a.ctx + ((size_t)post * S + q) * a.ld_ctx + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = oacc[dt][4 * g + e] * inv;
+                    *reinterpret_cast<f32x4*>(op + dt * 32 + 8 * g + 4 * h2) = o;
+                }
+        }
+    }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NKT * 32, IMG = SP * 128, DSI = 64 * SP * 2;
+    constexpr int SPC = SP / 8;
+    char* Qh = smem;
+    char* Ql = smem + IMG;
+    char* dOh = smem + 2 * IMG;
+    char* dOl = smem + 3 * IMG;
+    char* Kh = smem + 4 * IMG;
+    char* Kl = smem + 5 * IMG;
+    char* dSh = smem + 6 * IMG;
+    char* dSl = dSh + DSI;
+    float* lse2 = reinterpret_cast<float*>(dSl + DSI);
+    float* Dv = lse2 + SP;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int head = blockIdx.x, post = blockIdx.y;
+    const int S = a.S;
+    const size_t row0 = (size_t)post * S;
+    const float* qb = (const float*)a.qkv + row0 * a.ld_qkv + head * HD;
+    const float* kb = qb + a.hidden;
+    const float* vb = qb + 2 * a.hidden;
+    const float* dob = (const float*)a.dctx + row0 * a.ld_ctx + head * HD;
+    const float* ob = (const float*)a.ctx + row0 * a.ld_ctx + head * HD;
+    stage_image_x3(Qh, Ql, qb, a.ld_qkv, S, SP, true, tid, 256);
+    stage_image_x3(dOh, dOl, dob, a.ld_ctx, S, SP, true, tid, 256);
+    stage_image_x3(Kh, Kl, kb, a.ld_qkv, S, SP, true, tid, 256);
+    for (int q = tid; q < SP; q += 256) {
+        float d = 0.f, l = 0.f;
+        if (q < S) {
+            const float* o = ob + (size_t)q * a.ld_ctx;
+            const float* g = dob + (size_t)q * a.ld_ctx;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const f32x4 ov = *reinterpret_cast<const f32x4*>(o + c * 4), gv = *reinterpret_cast<const f32x4*>(g + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d += ov[e] * gv[e];
+            }
+            l = a.lse[((size_t)post * a.heads + head) * S + q] * LOG2E;
+        }
+        Dv[q] = d;
+        lse2[q] = l;
+    }
+    const int r = lane & 31, h2 = lane >> 5;
+    const bool has_keys = w < NKT;
+    const int key = w * 32 + r;
+    const int krow = min(key, S - 1);
+    Frag3 kf[4], vf[4];
+    float mbk = 0.f;
+    if (has_keys) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = global_pair(kb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2);
+            vf[s] = global_pair(vb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2);
+        }
+        mbk = (key < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + key] : 0.f) : -INFINITY;
+        mbk *= LOG2E;
+    }
+    __syncthreads();
+    const float sc = a.scale * LOG2E;
+    const bool dropping = a.drop.thresh16 != 0;
+    f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
+    constexpr int NQT = NKT;
+    const int qlim = a.q_tiles > 0 ? min(NQT, a.q_tiles) : NQT;
+    for (int pair = 0; pair < (qlim + 1) / 2; ++pair) {
+        if (has_keys) {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int qt = pair * 2 + t2;
+                if (qt >= qlim) break;
+                const int q0 = qt * 32;
+                f32x16 sacc = f32x16{}, pacc = f32x16{};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int off = trimg_off(q0 + r, 2 * s + h2);
+                    sacc = mma3_32(lds_pair(Qh, Ql, off), kf[s], sacc);       // S[q][key]
+                    pacc = mma3_32(lds_pair(dOh, dOl, off), vf[s], pacc);     // dP[q][key]
+                }
+                float pdv[16], dsv[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2 + q0 + 8 * g + 4 * h2);
+                    f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + q0 + 8 * g + 4 * h2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int reg = 4 * g + e;
+                        const int q = q0 + 8 * g + 4 * h2 + e;
+                        float p = exp2f(sacc[reg] * sc + mbk - l4[e]);
+                        if (q >= S) p = 0.f;
+                        float pd = p, dpd = pacc[reg];
+                        if (dropping) {
+                            const uint32_t eidx = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)min(q, S - 1)) * (uint32_t)S + (uint32_t)min(key, S - 1);
+                            const bool kp = mm_keep(eidx, a.drop);
+                            pd = kp ? p * a.drop.keep_scale : 0.f;
+                            dpd = kp ? dpd * a.drop.keep_scale : 0.f;
+                        }
+                        const float ds = p * (dpd - d4[e]) * a.scale;
+                        pdv[reg] = pd;
+                        dsv[reg] = ds;
+                        const int drow = t2 * 32 + 8 * g + 4 * h2 + e;
+                        const int doff = ds_off(drow, key >> 3, SPC) + (key & 7) * 2;
+                        const bf16_t dh = (bf16_t)ds;
+                        *reinterpret_cast<bf16_t*>(dSh + doff) = dh;
+                        *reinterpret_cast<bf16_t*>(dSl + doff) = (bf16_t)(ds - (float)dh);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const Frag3 pfrag = split8(pdv + 8 * s2), dsfrag = split8(dsv + 8 * s2);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        Frag3 gt, qtf;
+                        gt.hi = tr_frag_acc_order<bf16_t>(dOh, q0 + 16 * s2, dt * 32, lane);      // dO^T[d][q]
+                        gt.lo = tr_frag_acc_order<bf16_t>(dOl, q0 + 16 * s2, dt * 32, lane);
+                        dv[dt] = mma3_32(gt, pfrag, dv[dt]);
+                        qtf.hi = tr_frag_acc_order<bf16_t>(Qh, q0 + 16 * s2, dt * 32, lane);      // Q^T[d][q]
+                        qtf.lo = tr_frag_acc_order<bf16_t>(Ql, q0 + 16 * s2, dt * 32, lane);
+                        dk[dt] = mma3_32(qtf, dsfrag, dk[dt]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int qi = w >> 1, dt = w & 1;
+            const int qt = pair * 2 + qi;
+            if (qt < qlim) {
+                f32x16 dq = f32x16{};
+#pragma unroll
+                for (int ks = 0; ks < SP / 16; ++ks) {
+                    Frag3 ktf;
+                    ktf.hi = tr_frag_natural<bf16_t>(Kh, ks * 16, dt * 32, lane);
+                    ktf.lo = tr_frag_natural<bf16_t>(Kl, ks * 16, dt * 32, lane);
+                    dq = mma3_32(lds_pair(dSh, dSl, ds_off(qi * 32 + r, 2 * ks + h2, SPC)), ktf, dq);
+                }
+                float* dqp = (float*)a.dqkv + row0 * a.ld_qkv + head * HD + dt * 32 + r;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int q = qt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+                    if (q < S) dqp[(size_t)q * a.ld_qkv] = dq[reg];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (has_keys && key < S) {
+        float* dkp = (float*)a.dqkv + (row0 + key) * a.ld_qkv + a.hidden + head * HD;
+        float* dvp = dkp + a.hidden;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o1, o2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o1[e] = dk[dt][4 * g + e]; o2[e] = dv[dt][4 * g + e]; }
+                *reinterpret_cast<f32x4*>(dkp + dt * 32 + 8 * g + 4 * h2) = o1;
+                *reinterpret_cast<f32x4*>(dvp + dt * 32 + 8 * g + 4 * h2) = o2;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 template <typename T, int NKT, int NW>
 static void launch_fwd_t(const AttnArgs& a, hipStream_t s) {
@@ -346,9 +645,30 @@ static hipError_t launch_fwd_d(const AttnArgs& a, hipStream_t s) {
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+template <int NKT, int NW>
+static void launch_fwd_x3_t(const AttnArgs& a, hipStream_t s) {
+    const int lds = 4 * NKT * 32 * 128 + NKT * 32 * 4;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn_fwd_x3_kernel<NKT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+    hipLaunchKernelGGL((attn_fwd_x3_kernel<NKT, NW>), dim3(a.heads, a.posts), dim3(NW * 64), lds, s, a);
+}
+static bool x3_mfma_attention() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MMHIP_X3_FAST"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
 hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s) {
     if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1) return hipErrorInvalidValue;
-    if (dtype == DT_F32) return launch_attn_fwd_f32(a, s);
+    if (dtype == DT_F32) {
+        // parity mode: split operands on the matrix cores while two 16-bit images per tensor fit the CU's LDS (S <= 288: 148 KB), else fp32 ALUs
+        if (!x3_mfma_attention() || a.S > 288 || ((uintptr_t)a.qkv & 15) || ((uintptr_t)a.ctx & 15)) return launch_attn_fwd_f32(a, s);
+        if (a.S <= 32) launch_fwd_x3_t<1, 1>(a, s);
+        else if (a.S <= 64) launch_fwd_x3_t<2, 2>(a, s);
+        else if (a.S <= 128) launch_fwd_x3_t<4, 4>(a, s);
+        else if (a.S <= 224) launch_fwd_x3_t<7, 8>(a, s);
+        else launch_fwd_x3_t<9, 8>(a, s);
+        return hipGetLastError();
+    }
     return dtype == DT_BF16 ? launch_fwd_d<bf16_t>(a, s) : launch_fwd_d<f16_t>(a, s);
 }
 template <typename T, int NKT>
@@ -366,9 +686,23 @@ static hipError_t launch_bwd_d(const AttnBwdArgs& a, hipStream_t s) {
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+template <int NKT>
+static void launch_bwd_x3_t(const AttnBwdArgs& a, hipStream_t s) {
+    const int lds = 6 * NKT * 32 * 128 + 2 * 64 * NKT * 32 * 2 + 2 * NKT * 32 * 4;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn_bwd_x3_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+    hipLaunchKernelGGL((attn_bwd_x3_kernel<NKT>), dim3(a.heads, a.posts), dim3(256), lds, s, a);
+}
 hipError_t launch_attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t s) {
     if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1) return hipErrorInvalidValue;
-    if (dtype == DT_F32) return launch_attn_bwd_f32(a, s);
+    if (dtype == DT_F32) {
+        auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+        if (!x3_mfma_attention() || a.S > 128 || !al(a.qkv) || !al(a.ctx) || !al(a.dctx) || !al(a.dqkv)) return launch_attn_bwd_f32(a, s);
+        if (a.S <= 32) launch_bwd_x3_t<1>(a, s);
+        else if (a.S <= 64) launch_bwd_x3_t<2>(a, s);
+        else launch_bwd_x3_t<4>(a, s);
+        return hipGetLastError();
+    }
     return dtype == DT_BF16 ? launch_bwd_d<bf16_t>(a, s) : launch_bwd_d<f16_t>(a, s);
 }
 

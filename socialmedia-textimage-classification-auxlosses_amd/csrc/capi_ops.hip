@@ -85,6 +85,20 @@ int mmhip_op_probe_layouts(int32_t* out, void* stream) {
     return 0;
 }
 
+// parity mode through the op entry points: one process-wide split-plane scratch, grown on demand (hipFree waits for the device, so a
+// buffer still in use by an earlier launch is never pulled away).  The engine carves its own per-stream scratch from its workspace.
+static void* ops_x3_scratch(size_t bytes) {
+    static void* buf = nullptr;
+    static size_t cap = 0;
+    if (bytes > cap) {
+        if (buf) (void)hipFree(buf);
+        buf = nullptr; cap = 0;
+        if (hipMalloc(&buf, bytes) != hipSuccess) { buf = nullptr; return nullptr; }
+        cap = bytes;
+    }
+    return buf;
+}
+
 int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      const float* bias, int act, void* aux_pre, int ldaux, const void* mul_gelu_grad_of, int ldmul,
                      float p_drop, uint64_t seed, uint32_t stream_id, const void* residual, int ldres, int out_f32,
@@ -104,6 +118,10 @@ int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, 
     if (out_f32) a.flags |= GEMM_OUT_F32;
     a.force_slow = force_slow & 1;
     a.tile = force_slow >> 4;      // bits 4.. select the tile variant (test / tuning hook)
+    if (dtype == MMHIP_F32 && M > 128 && !a.force_slow) {
+        a.x3_ws_bytes = x3_nt_scratch_bytes(M, N, K);
+        a.x3_ws = ops_x3_scratch(a.x3_ws_bytes);
+    }
     CHECK_HIP(launch_gemm_nt(a, dtype, (hipStream_t)stream));
     return 0;
 }
@@ -112,7 +130,9 @@ int mmhip_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, 
                      int accumulate, int force_slow, float* colsum, void* stream) {
     if (!A || !B || !C || M < 1 || Nn < 1 || Nc < 1 || (dtype != MMHIP_BF16 && dtype != MMHIP_F16 && dtype != MMHIP_F32)) return MMHIP_E_INVALID;
     GemmTNProblem p{A, B, C, M, Nn, Nc, lda, ldb, ldc, 0, colsum};
-    CHECK_HIP(launch_gemm_tn(&p, 1, accumulate, dtype, force_slow, (hipStream_t)stream));
+    size_t xb = dtype == MMHIP_F32 && !force_slow ? x3_tn_scratch_bytes(M, Nn, Nc) : 0;
+    void* xw = xb ? ops_x3_scratch(xb) : nullptr;
+    CHECK_HIP(launch_gemm_tn(&p, 1, accumulate, dtype, force_slow, (hipStream_t)stream, 1.0f, xw, xw ? xb : 0));
     return 0;
 }
 
@@ -124,7 +144,10 @@ int mmhip_op_gemm_tn_group(int dtype, const mmhip_tn_problem* problems, int coun
         if (!q.A || !q.B || !q.C || q.M < 1 || q.Nn < 1 || q.Nc < 1) return MMHIP_E_INVALID;
         ps[i] = GemmTNProblem{q.A, q.B, q.C, q.M, q.Nn, q.Nc, q.lda, q.ldb, q.ldc, 0, q.colsum};
     }
-    if (count) CHECK_HIP(launch_gemm_tn(ps.data(), count, accumulate, dtype, 0, (hipStream_t)stream));
+    size_t xb = 0;
+    if (dtype == MMHIP_F32) for (int i = 0; i < count; ++i) xb += x3_tn_scratch_bytes(ps[i].M, ps[i].Nn, ps[i].Nc);
+    void* xw = xb ? ops_x3_scratch(xb) : nullptr;
+    if (count) CHECK_HIP(launch_gemm_tn(ps.data(), count, accumulate, dtype, 0, (hipStream_t)stream, 1.0f, xw, xw ? xb : 0));
     return 0;
 }
 

@@ -50,6 +50,7 @@ struct mmhip_engine {
     char* ws = nullptr; size_t ws_bytes = 0, ws_need = 0;
     // workspace offsets (bytes) --------------------------------------------------------
     std::vector<LayerW16> vit_w16, txt_w16;
+    size_t x3_ws[3] = {0, 0, 0}, x3_bytes[3] = {0, 0, 0};      // parity mode: split-plane scratch of the caller's stream | side stream | image-tower stream
     size_t patch_w16;
     std::vector<TextAct> tact;
     size_t ids_all, mask_all, pos_ids, maskbias, x0, xhat_emb, rstd_emb;
@@ -347,6 +348,24 @@ void build_workspace(mmhip_engine& e) {
     e.h_featd = f(Bm * H); e.h_out_cls = f(Bm * C); e.h_out_tim = f(Bm * 2);
     e.splitk_ws = f((size_t)(I / 384 + 1) * 128 * (size_t)(I > 3 * H ? I : 3 * H)); e.has_splitk = true;
     e.splitk_ws_vit = f((size_t)(Iv / 384 + 1) * 128 * (size_t)(Iv > 3 * Hv ? Iv : 3 * Hv));
+    if (c.dtype == MMHIP_BF16X3) {
+        // split planes of the operands of one GEMM call at a time per stream (x3.hip): the widest NT problem of a tower, or the four
+        // weight-gradient problems of a text layer together
+        auto nt = [](size_t M, size_t H, size_t I) {
+            size_t b = 0;
+            const size_t nk[5][2] = {{3 * H, H}, {H, H}, {I, H}, {H, I}, {H, 3 * H}};
+            for (auto& q : nk) { const size_t v = x3_nt_scratch_bytes((int)M, (int)q[0], (int)q[1]); if (v > b) b = v; }
+            return b;
+        };
+        const size_t tn = x3_tn_scratch_bytes((int)Mt, (int)H, (int)I) + x3_tn_scratch_bytes((int)Mt, (int)I, (int)H) + x3_tn_scratch_bytes((int)Mt, (int)(3 * H), (int)H) +
+                          x3_tn_scratch_bytes((int)Mt, (int)H, (int)H);
+        size_t vit = nt(Mv, Hv, Iv);
+        { const size_t pe = x3_nt_scratch_bytes((int)(Bm * (P - 1)), (int)Hv, (int)Kpp); if (pe > vit) vit = pe; }
+        size_t txt = nt(Mt, H, I);
+        if (tn > txt) txt = tn;
+        e.x3_bytes[0] = txt > vit ? txt : vit; e.x3_bytes[1] = txt; e.x3_bytes[2] = vit;
+        for (int i = 0; i < 3; ++i) e.x3_ws[i] = w.take(e.x3_bytes[i]);
+    }
     e.h_d_out_cls = f(Bm * C); e.h_d_logits = f(Bm * Bm); e.h_d_out_tim = f(Bm * 2); e.h_dfeats = f(Bt * H); e.h_dpre = f(Bt * H);
     e.h_dz = f(Bt * (H + Hv)); e.h_dxcls = f(Bt * H); e.h_dxbar = f(Bt * H); e.h_dqk = f(Bt * H); e.h_dq = f(Bt * H);
     e.h_dtxt_e = f(Bm * E); e.h_dimg_e = f(Bm * E); e.h_dtpool = f(Bm * H); e.h_dprepool = f(Bm * H); e.h_loss = f(8);
@@ -396,6 +415,11 @@ int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
         const int h = on_vit ? e.Hv() : e.cfg.hidden, in = on_vit ? e.Iv() : e.cfg.inter;
         if (e.has_splitk && g.a.M <= 128 && (size_t)(g.a.K / 384) * g.a.M * g.a.N <= (size_t)(in / 384 + 1) * 128 * (size_t)(in > 3 * h ? in : 3 * h))
             g.a.splitk_ws = e.wsp<float>(on_vit ? e.splitk_ws_vit : e.splitk_ws);
+        if (e.x3_bytes[0]) {
+            const int i = on_vit ? 2 : (e.side && s == e.side ? 1 : 0);
+            g.a.x3_ws = e.ws + e.x3_ws[i];
+            g.a.x3_ws_bytes = e.x3_bytes[i];
+        }
     }
     if (e.timing) {
         if (e.ev_used == e.evs.size()) {
@@ -725,6 +749,11 @@ void choose_partition(mmhip_engine& e) {
         auto gemm = [&](int n, int k) { const long tiles = rows * (n / 256); return (double)((tiles + cap - 1) / cap) * (k / 64 + 5); };
         return layers * (gemm(3 * h, h) + gemm(h, h) + gemm(inter, h) + gemm(h, inter));
     };
+    // Same-box A/B of the step (profiles/r03_step_ab.txt): the split pays where the image tower is clearly the longer one (CLIP-L/14 beside
+    // 32 posts of text: 12.8 vs 13.2 ms), is neutral at config 2 (12608 image rows beside 8192 text rows: 10.24-10.30 either way) and LOSES
+    // where the text tower is the longer one (config 3, 16384 text rows with ITM: 15.95 vs 15.3 ms) -- free sharing then fills the tails of
+    // the short tower's launches with the long tower's workgroups, which a fixed split forbids.
+    if (tower(rv, Hv, Iv, c.layers_img, 256) < 1.3 * tower(rt, H, I, c.layers_txt, 256)) return;
     double best = 1e30; int bt = 0;
     for (int t = 32; t <= 224; t += 8) {
         const double ct = tower(rt, H, I, c.layers_txt, t), cv = tower(rv, Hv, Iv, c.layers_img, 256 - t);
@@ -954,7 +983,10 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mr, I, H, I, H, H, 0, Gd + o.fc1_b};          // dW1[I,H]   = du^T a1
     pr[2] = GemmTNProblem{dqkv, x_in, Gd + o.qkv_w, Mt, 3 * H, H, 3 * H, H, H, 0, Gd + o.qkv_b};       // dWqkv[3H,H] = dqkv^T x_in
     pr[3] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mr, H, H, H, rs, H, 0, Gd + o.ao_b};        // dWo[H,H]   = dout^T ctx (CLS rows: stride T*H)
-    CHECK_HIP(launch_gemm_tn(pr, 4, 0, dt, 0, ps, 1.0f / e.gscale()));
+    {
+        const int i = e.side && ps == e.side ? 1 : 0;
+        CHECK_HIP(launch_gemm_tn(pr, 4, 0, dt, 0, ps, 1.0f / e.gscale(), e.x3_bytes[i] ? e.ws + e.x3_ws[i] : nullptr, e.x3_bytes[i]));
+    }
     if (side) {
         CHECK_HIP(hipEventRecord(e.ev_tn[set], e.side));
         e.tn_pending[set] = true;

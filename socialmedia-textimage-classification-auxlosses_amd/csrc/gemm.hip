@@ -734,8 +734,8 @@ static void launch_tn_t(const GemmTNGroup& g, int tiles, hipStream_t s) {
 // variant: 1 = 128x128 2-stage, 4 (default, fastest inside the step: 13.5 vs 14.2 ms) = role-specialised 256x128,
 // 2 = 128x128 4-stage ring, 3 = 256x128 3-stage ring, 4 = role-specialised 256x128 (8 MFMA + 4 loader waves, 3-stage
 // ring), 5 = role-specialised 128x128 (4 + 4, 4-stage ring); env MMHIP_TN_TILE overrides
-hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha) {
-    if (dtype == DT_F32) return launch_gemm_tn_x3(probs, count, accumulate, s, alpha);
+hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha, void* x3_ws, size_t x3_ws_bytes) {
+    if (dtype == DT_F32) return launch_gemm_tn_x3(probs, count, accumulate, s, alpha, force_slow ? nullptr : x3_ws, x3_ws_bytes);
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_TN_TILE"); env = e ? atoi(e) : 0; }
     int variant = (force_slow >> 4) ? (force_slow >> 4) : (env ? env : 4);

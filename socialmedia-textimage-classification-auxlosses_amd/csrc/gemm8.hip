@@ -229,7 +229,9 @@ struct I8 {
     }
 };
 
-template <typename T, int BN, int EPI>
+// ET = element type of everything the epilogue touches (C, aux, residual, mul_in): T, or float in the parity mode (bf16x3), whose 16-bit
+// operands are the split planes of fp32 tensors (x3.hip) -- the K loop is the same
+template <typename T, int BN, int EPI, typename ET = T>
 __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int persistent) {
     using C = P8<BN>;
     using P = I8<BN>;
@@ -461,11 +463,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
         int m0, n0;
         const int which = tile_origin(first + t * stride, m0, n0);
         const GemmNTArgs& a = g.p[which];
-        tile_epilogue8<T, C::FN, C::TN, EPI, 4, true>(a, acc, m0, n0, wm, wn, l15, kc, lds_bias_all + which * a.N);
+        tile_epilogue8<ET, C::FN, C::TN, EPI, 4, true>(a, acc, m0, n0, wm, wn, l15, kc, lds_bias_all + which * a.N);
         zero_acc();
         // stores this wave has just issued and nothing else (a full tile: every row store executes): see `grace` in the K loop
         grace0 = 0;
-        if (m0 + C::BM <= a.M) {
+        if (std::is_same<T, ET>::value && m0 + C::BM <= a.M) {          // (fp32 stores are two instructions each: no grace in the parity mode)
             if (EPI == EP_GELU) grace0 = (a.flags & GEMM_AUX_PRE) ? 2 * NST1 : NST1;
             else if (EPI == EP_PLAIN && !(a.flags & GEMM_RESIDUAL)) grace0 = NST1;
         }
@@ -532,11 +534,11 @@ static bool nt8_ok(const GemmNTArgs& a, int bn) {
 }
 
 static int nt8_grid(int ntiles) { return ntiles <= 256 ? ntiles : 256; }      // workgroups of a persistent launch: one per CU
-template <typename T, int BN, int EPI>
+template <typename T, int BN, int EPI, typename ET = T>
 static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
     using C = P8<BN>;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<T, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<T, BN, EPI, ET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
     int ntiles = 0;
     for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / BN);
     const int cap = g.p[0].grid > 0 ? (g.p[0].grid < ntiles ? g.p[0].grid : ntiles) : 0;
@@ -544,7 +546,7 @@ static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
     // the bias vectors live in LDS behind the K-tile buffers (nt8i_ok: they fit the CU's 160 KB)
     size_t lds = C::LDS;
     for (int i = 0; i < g.count; ++i) lds += (size_t)g.p[i].N * 4;
-    hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI>), dim3(grid), dim3(512), lds, s, g, persistent && ntiles > grid ? 1 : 0);
+    hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI, ET>), dim3(grid), dim3(512), lds, s, g, persistent && ntiles > grid ? 1 : 0);
 }
 // epilogue class that covers a flag set (a pair uses the class that covers both)
 static int nt8_class(int f) {
@@ -553,17 +555,21 @@ static int nt8_class(int f) {
     if (!(f & ~(GEMM_BIAS | GEMM_DROPOUT | GEMM_RESIDUAL))) return EP_PLAIN;
     return EP_ANY;
 }
-template <typename T, int BN>
+template <typename T, int BN, typename ET = T>
 static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
     int c = nt8_class(g.p[0].flags);
     if (g.count > 1 && nt8_class(g.p[1].flags) != c) c = EP_ANY;
-    if (c == EP_GELU) launch_nt8_e<T, BN, EP_GELU>(g, persistent, s);
-    else if (c == EP_MULG) launch_nt8_e<T, BN, EP_MULG>(g, persistent, s);
-    else if (c == EP_PLAIN) launch_nt8_e<T, BN, EP_PLAIN>(g, persistent, s);
-    else launch_nt8_e<T, BN, EP_ANY>(g, persistent, s);
+    if (c == EP_GELU) launch_nt8_e<T, BN, EP_GELU, ET>(g, persistent, s);
+    else if (c == EP_MULG) launch_nt8_e<T, BN, EP_MULG, ET>(g, persistent, s);
+    else if (c == EP_PLAIN) launch_nt8_e<T, BN, EP_PLAIN, ET>(g, persistent, s);
+    else launch_nt8_e<T, BN, EP_ANY, ET>(g, persistent, s);
 }
 static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent, hipStream_t s) {
-    if (dtype == DT_BF16) {
+    if (dtype == DT_F32) {          // parity mode: bf16 split planes in, fp32 epilogue
+        if (bn == 256) launch_nt8_t<bf16_t, 256, float>(g, persistent, s);
+        else if (bn == 192) launch_nt8_t<bf16_t, 192, float>(g, persistent, s);
+        else launch_nt8_t<bf16_t, 128, float>(g, persistent, s);
+    } else if (dtype == DT_BF16) {
         if (bn == 256) launch_nt8_t<bf16_t, 256>(g, persistent, s);
         else if (bn == 192) launch_nt8_t<bf16_t, 192>(g, persistent, s);
         else launch_nt8_t<bf16_t, 128>(g, persistent, s);

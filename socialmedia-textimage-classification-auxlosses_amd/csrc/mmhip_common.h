@@ -38,6 +38,29 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __bu
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+// ---------------------------------------------------------------- parity mode (bf16x3): an fp32 value as two bf16, x ~= hi + lo
+struct Frag3 { bf16x8 hi, lo; };
+__device__ __forceinline__ Frag3 split8(const float* v) {
+    Frag3 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bf16_t h = (bf16_t)v[e];
+        f.hi[e] = h;
+        f.lo[e] = (bf16_t)(v[e] - (float)h);
+    }
+    return f;
+}
+__device__ __forceinline__ void load8(const float* p, float* v) {
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(p), x1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+}
+__device__ __forceinline__ f32x16 mma3_32(const Frag3& a, const Frag3& b, f32x16 c) {      // the two small products first
+    c = mfma32(a.lo, b.hi, c);
+    c = mfma32(a.hi, b.lo, c);
+    return mfma32(a.hi, b.hi, c);
+}
+
 // 16-byte LDS read of 8 elements
 template <typename T> __device__ __forceinline__ typename Vec<T>::v8 lds_read8(const char* lds, int byte_off) {
     return *reinterpret_cast<const typename Vec<T>::v8*>(lds + byte_off);

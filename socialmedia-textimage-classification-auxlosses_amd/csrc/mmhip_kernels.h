@@ -34,6 +34,8 @@ struct GemmNTArgs {
                               // partitions the chip between its two towers this way: each workgroup holds a CU's LDS, so 96 + 160
                               // resident workgroups of two concurrent launches ARE a 96 / 160 CU split, and 256-row tiles of the
                               // 8192-row text GEMMs come in multiples of 96
+    void* x3_ws;              // parity mode (bf16x3) only: scratch for the operands' split planes (x3.hip, x3_nt_scratch_bytes); null = the direct kernel
+    size_t x3_ws_bytes;
     float* splitk_ws;         // optional fp32 scratch [K/384][M][N]: a GEMM of <= 128 rows with K >= 1536 (the CLS-row GEMMs of the last
                               // text layer) is cut along K into slices that run side by side; a second kernel sums them and applies the epilogue
 };
@@ -62,10 +64,13 @@ bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hip
 // split-K finish: C = epilogue(sum over `slices` partial products in a.splitk_ws), same flags as the fused epilogue
 hipError_t launch_splitk_finish(const GemmNTArgs& a, int dtype, int slices, hipStream_t s);
 bool launch_gemm_nt8_pair(const GemmNTArgs& a0, const GemmNTArgs& a1, int dtype, int bn, hipStream_t s);
-hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha = 1.0f);
+hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate, int dtype, int force_slow, hipStream_t s, float alpha = 1.0f,
+                          void* x3_ws = nullptr, size_t x3_ws_bytes = 0);
 // parity mode (fp32 activations, three bf16 MFMA products of split operands / fp32 attention): csrc/x3.hip
 hipError_t launch_gemm_nt_x3(const GemmNTArgs& a, hipStream_t s);
-hipError_t launch_gemm_tn_x3(const GemmTNProblem* probs, int count, int accumulate, hipStream_t s, float alpha);
+hipError_t launch_gemm_tn_x3(const GemmTNProblem* probs, int count, int accumulate, hipStream_t s, float alpha, void* ws = nullptr, size_t ws_bytes = 0);
+size_t x3_nt_scratch_bytes(int M, int N, int K);      // split planes of one NT problem's operands / of one TN problem's
+size_t x3_tn_scratch_bytes(int M, int Nn, int Nc);
 hipError_t launch_small_nt(const SmallGemmArgs& a, int a_dtype, hipStream_t s);   // out[M,N] = act(A[M,K] W[N,K]^T + b)
 hipError_t launch_small_nn(const SmallGemmArgs& a, hipStream_t s);                // out[M,N] = A[M,K] W[K,N]
 hipError_t launch_small_tn(const SmallGemmArgs& a, int b_dtype, int n_rows, hipStream_t s);  // out[n_rows,N] = A[M,n_rows]^T B[M,N]

@@ -11,27 +11,11 @@
 
 namespace mmhip {
 
-struct Frag3 { bf16x8 hi, lo; };
-__device__ __forceinline__ Frag3 split8(const float* v) {
-    Frag3 f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const bf16_t h = (bf16_t)v[e];
-        f.hi[e] = h;
-        f.lo[e] = (bf16_t)(v[e] - (float)h);
-    }
-    return f;
-}
 // D += A.B with both operands split; the two small products first
 __device__ __forceinline__ f32x4 mma3(const Frag3& a, const Frag3& b, f32x4 c) {
     c = mfma16(a.lo, b.hi, c);
     c = mfma16(a.hi, b.lo, c);
     return mfma16(a.hi, b.hi, c);
-}
-__device__ __forceinline__ void load8(const float* p, float* v) {
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(p), x1 = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
 }
 
 // ------------------------------------------------------------------------------------------------ NT
@@ -144,8 +128,67 @@ __global__ __launch_bounds__(256) void slow_nt_f32_kernel(GemmNTArgs a) {
     ((float*)a.C)[(size_t)m * a.ldc + n] = v;
 }
 
+// ------------------------------------------------------------------------------------------------ split planes
+// The fast form of the parity mode: an fp32 operand is written once as bf16 planes hi = bf16(x), lo = bf16(x - hi), three copies laid out so
+// that ONE ordinary bf16 GEMM over a three times longer reduction index computes  hi.hi + lo.hi + hi.lo :
+//   NT (reduction along the row):     A' = [hi | lo | hi]  (M x 3K),   B' = [hi | hi | lo]  (N x 3K)   -> gemm_nt8_kernel, fp32 epilogue
+//   TN (reduction over the rows):     A' = [hi ; lo ; hi]  (3M x Nn),  B' = [hi ; hi ; lo]  (3M x Nc)  -> gemm_tn_kernel
+// so the deep-pipelined kernels of gemm8.hip / gemm.hip run unchanged (fp32 accumulation of the three products in the MFMA accumulators).
+// Cost of the copies: 4 B read + 6 B written per operand element, a few per cent of the three-pass product.
+// Thread = 8 consecutive elements of a row; the three copies of the row go to dst + o[k] + row * dld.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, int ld, int rows, int cols, bf16_t* __restrict__ dst, int dld,
+                                                     size_t o_hi0, size_t o_lo, size_t o_hi1) {
+    const int per_row = cols >> 3;
+    const size_t total = (size_t)rows * per_row;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / per_row), c = (int)(idx - (size_t)r * per_row) << 3;
+        float v[8];
+        load8(src + (size_t)r * ld + c, v);
+        const Frag3 f = split8(v);
+        bf16_t* d = dst + (size_t)r * dld + c;
+        *reinterpret_cast<bf16x8*>(d + o_hi0) = f.hi;
+        *reinterpret_cast<bf16x8*>(d + o_lo) = f.lo;
+        *reinterpret_cast<bf16x8*>(d + o_hi1) = f.hi;
+    }
+}
+static void launch_split3(const float* src, int ld, int rows, int cols, void* dst, int dld, size_t o_hi0, size_t o_lo, size_t o_hi1, hipStream_t s) {
+    const size_t threads = (size_t)rows * (cols >> 3);
+    const int grid = (int)((threads + 255) / 256 > 16384 ? 16384 : (threads + 255) / 256);
+    hipLaunchKernelGGL(split3_kernel, dim3(grid), dim3(256), 0, s, src, ld, rows, cols, (bf16_t*)dst, dld, o_hi0, o_lo, o_hi1);
+}
+static inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+size_t x3_nt_scratch_bytes(int M, int N, int K) { return up256((size_t)M * 3 * K * 2) + up256((size_t)N * 3 * K * 2); }
+size_t x3_tn_scratch_bytes(int M, int Nn, int Nc) { return up256((size_t)3 * M * Nn * 2) + up256((size_t)3 * M * Nc * 2); }
+
+// the split-plane form through the deep-pipelined kernel; false = rules not met
+static bool nt_x3_fast(const GemmNTArgs& a, hipStream_t s) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MMHIP_X3_FAST"); on = e ? atoi(e) : 1; }
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (!on || !a.x3_ws || a.force_slow || a.M <= 128 || a.N % 128 || a.K % 64 || a.lda % 4 || a.ldb % 4 || !al(a.A) || !al(a.B)) return false;
+    if (x3_nt_scratch_bytes(a.M, a.N, a.K) > a.x3_ws_bytes) return false;
+    int bn = 0;
+    double best = 0;
+    const long tm = (a.M + 255) / 256;
+    for (int cand : {256, 192, 128}) {
+        if (a.N % cand) continue;
+        const long t = tm * (a.N / cand);
+        const double u = (double)t / (double)(((t + 255) / 256) * 256) + (cand == 256 ? 0.08 : (cand == 192 ? 0.04 : 0.0));      // near ties -> wider
+        if (u > best) { best = u; bn = cand; }
+    }
+    GemmNTArgs b = a;
+    char* pa = (char*)a.x3_ws;
+    char* pb = pa + up256((size_t)a.M * 3 * a.K * 2);
+    b.A = pa; b.lda = 3 * a.K; b.B = pb; b.ldb = 3 * a.K; b.K = 3 * a.K; b.x3_ws = nullptr; b.splitk_ws = nullptr;
+    launch_split3((const float*)a.A, a.lda, a.M, a.K, pa, 3 * a.K, 0, (size_t)a.K, (size_t)2 * a.K, s);
+    launch_split3((const float*)a.B, a.ldb, a.N, a.K, pb, 3 * a.K, 0, (size_t)2 * a.K, (size_t)a.K, s);
+    if (launch_gemm_nt8(b, DT_F32, bn, 1, s)) return true;
+    return false;          // (the two copies above are harmless: the caller falls back to the direct kernel)
+}
+
 hipError_t launch_gemm_nt_x3(const GemmNTArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
+    if (nt_x3_fast(a, s)) return hipGetLastError();
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     const bool fast = !a.force_slow && a.K % 32 == 0 && a.N % 4 == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.ldc % 4 == 0 && al(a.A) && al(a.B) && al(a.C) &&
                       (!(a.flags & GEMM_RESIDUAL) || (a.ldres % 4 == 0 && al(a.residual))) && (!(a.flags & GEMM_AUX_PRE) || (a.ldaux % 4 == 0 && al(a.aux))) &&
@@ -231,9 +274,41 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(GemmTNProblem P, int ac
     }
 }
 
-hipError_t launch_gemm_tn_x3(const GemmTNProblem* probs, int count, int accumulate, hipStream_t s, float alpha) {
+hipError_t launch_gemm_tn_x3(const GemmTNProblem* probs, int count, int accumulate, hipStream_t s, float alpha, void* ws, size_t ws_bytes) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MMHIP_X3_FAST"); on = e ? atoi(e) : 1; }
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    // split-plane form: the problems that fit the grouped bf16 kernel's shape rules (gemm.hip) go through it with three times the rows;
+    // their bias gradients (column sums of dY) come from the fp32 tensor itself
+    GemmTNProblem fastp[GEMM_TN_MAX_GROUP];
+    int nfast = 0;
+    size_t used = 0;
+    bool taken[64] = {false};
+    for (int i = 0; i < count && i < 64 && on && ws; ++i) {
+        const GemmTNProblem& P = probs[i];
+        if (P.M <= 0 || P.M % 64 || P.Nn % 256 || P.Nc % 128 || P.lda % 4 || P.ldb % 4 || !al(P.A) || !al(P.B) || nfast == GEMM_TN_MAX_GROUP) continue;
+        const size_t need = x3_tn_scratch_bytes(P.M, P.Nn, P.Nc);
+        if (used + need > ws_bytes) continue;
+        char* pa = (char*)ws + used;
+        char* pb = pa + up256((size_t)3 * P.M * P.Nn * 2);
+        used += need;
+        const size_t pla = (size_t)P.M * P.Nn, plb = (size_t)P.M * P.Nc;
+        launch_split3((const float*)P.A, P.lda, P.M, P.Nn, pa, P.Nn, 0, pla, 2 * pla, s);
+        launch_split3((const float*)P.B, P.ldb, P.M, P.Nc, pb, P.Nc, 0, 2 * plb, plb, s);
+        if (P.colsum) {
+            if (accumulate != 1) { hipError_t e = hipMemsetAsync(P.colsum, 0, (size_t)P.Nn * 4, s); if (e != hipSuccess) return e; }
+            hipError_t e = launch_colsum(P.A, P.M, P.Nn, P.lda, P.colsum, DT_F32, s, nullptr, alpha);
+            if (e != hipSuccess) return e;
+        }
+        GemmTNProblem Q = P;
+        Q.A = pa; Q.lda = P.Nn; Q.B = pb; Q.ldb = P.Nc; Q.M = 3 * P.M; Q.colsum = nullptr;
+        fastp[nfast++] = Q;
+        taken[i] = true;
+    }
+    if (nfast) { hipError_t e = launch_gemm_tn(fastp, nfast, accumulate, DT_BF16, 0, s, alpha); if (e != hipSuccess) return e; }
     for (int i = 0; i < count; ++i) {
         const GemmTNProblem& P = probs[i];
+        if (i < 64 && taken[i]) continue;
         if (P.M <= 0 || P.Nn <= 0 || P.Nc <= 0) continue;
         hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((P.Nc + 127) / 128, (P.Nn + 127) / 128), dim3(256), 0, s, P, accumulate, alpha);
     }

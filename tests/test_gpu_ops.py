@@ -212,7 +212,7 @@ def test_attention_fwd_bwd(dt, posts, S, heads, masked, p):
 
 
 # ---- parity mode (dtype code MMHIP_F32 at the op level): the same operators on fp32 tensors
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (200, 128, 64), (1000, 768, 768), (96, 48, 40), (8192, 2304, 768), (64, 768, 3072), (300, 132, 96), (130, 512, 768)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (200, 128, 64), (1000, 768, 768), (96, 48, 40), (8192, 2304, 768), (64, 768, 3072), (300, 132, 96), (130, 512, 768), (12608, 768, 3072), (700, 384, 192)])
 def test_x3_gemm_nt(M, N, K):
     test_gemm_nt_epilogues("x3", M, N, K, 0)
 

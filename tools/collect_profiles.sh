@@ -12,6 +12,7 @@ python3 $R/bench.py --config 4 --no-cpu-baseline > $O/bench_cfg4_224.json 2>/dev
 python3 $R/bench.py --config 4 --image 336 --no-cpu-baseline > $O/bench_cfg4_336.json 2>/dev/null || exit 1
 python3 $R/bench.py --dtype f16 --no-cpu-baseline > $O/bench_cfg2_f16.json 2>/dev/null || exit 1
 python3 $R/bench.py --dtype bf16x3 --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_cfg2_bf16x3.json 2>/dev/null || exit 1
+python3 $R/bench.py --config 5 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null || exit 1
 step kernel stats
 rocprofv3 --kernel-trace --stats -d /tmp/ks_on -o ks --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1 || exit 1
 cp $(find /tmp/ks_on -name "*kernel_stats.csv" | head -1) $O/kernel_stats_on.csv
@@ -31,8 +32,8 @@ python3 $R/tools/pmc_mfma.py /tmp/pmc_m > $O/mfma_busy.txt
 step diagnostics
 cd $R
 python3 tools/vendor_gemm_bench.py > $O/vendor_gemm.txt 2>/dev/null
-{ python3 tools/gemm8_ts.py 12608 2304 768 15; python3 tools/gemm8_ts.py 12608 768 3072 17 resid; python3 tools/gemm8_ts.py 8192 8192 8192 15; python3 tools/gemm8_ts.py 12608 2304 768 15 cycles; python3 tools/gemm8_ts.py 8192 8192 8192 15 cycles; } > $O/gemm8_stamps.txt 2>/dev/null
-{ tools/pmc_l2.sh 12608 2304 768 15 5 cold; tools/pmc_l2.sh 12608 2304 768 1 5 cold; tools/pmc_l2.sh 12608 2304 768 20 5 cold; tools/pmc_l2.sh 8192 8192 8192 15 3; } > $O/l2_hit.txt 2>/dev/null
-{ tools/ab_env.sh "MMHIP_LOCKSTEP=0" "MMHIP_LOCKSTEP=1" "MMHIP_EARLY_ADAMW=0" "MMHIP_NT8_192=0" "MMHIP_VIT_PRIO=0" "MMHIP_OVERLAP=0"; BENCH_ARGS="--config 3" tools/ab_env.sh "MMHIP_EARLY_ADAMW=1" "MMHIP_EARLY_ADAMW=0"; } > $O/step_ab2.txt 2>/dev/null
+VARIANTS=1,9,13,15,16,18 python3 tools/gemm8_bench.py > $O/gemm8_microbench.txt 2>/dev/null
+{ tools/pmc_l2.sh 12608 2304 768 15 5 cold; tools/pmc_l2.sh 12608 2304 768 1 5 cold; tools/pmc_l2.sh 8192 8192 8192 15 3; } > $O/l2_hit.txt 2>/dev/null
+{ tools/ab_env.sh "BASE=1" "MMHIP_PART=0" "MMHIP_PART=128,128" "MMHIP_EARLY_ADAMW=0" "MMHIP_VIT_PRIO=0" "MMHIP_OVERLAP=0" "MMHIP_DETERMINISTIC=1"; BENCH_ARGS="--config 3" tools/ab_env.sh "BASE=1" "MMHIP_PART=0" "MMHIP_EARLY_ADAMW=0"; BENCH_ARGS="--config 4" tools/ab_env.sh "BASE=1" "MMHIP_PART=0"; } > $O/step_ab.txt 2>/dev/null
 python3 -m pytest tests/test_gpu_model.py -q -s -k "train_losses_and_grads or dropout_train_step or forward_matches or config4 or eval_loop" 2>&1 | grep -v "^$" > $O/parity.txt
 echo done >&2
