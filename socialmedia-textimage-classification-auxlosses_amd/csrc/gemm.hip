@@ -384,6 +384,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
 
     // transposed-read addressing: lane = 16 g + 4 q + p; rows 8g+q (and +4), columns col16 + 4p..4p+3
     const int gq = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    bool cs_now = with_colsum;
     auto compute = [&](int buf) {
         const char* As = smem + buf * C::STAGE;
         const char* Bs = As + C::A_BYTES;
@@ -406,13 +407,14 @@ void gemm_tn_kernel(GemmTNGroup g) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
-            if (with_colsum) {
+            if (cs_now) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) accb[i] = mfma16(af[i], ones, accb[i]);
             }
         }
     };
     const int nsteps = P.M / 64;
+    const int cs_steps = P.colsum_rows > 0 ? P.colsum_rows / 64 : nsteps;      // the column sums may cover the first rows only (parity mode: x3.hip)
     if constexpr (NL > 0) {
         // role-specialised ring (see gemm_nt_kernel): loader waves stream, consumer waves multiply, one barrier per step
         if (w >= C::NW) {
@@ -435,6 +437,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
         for (int t = 0; t < nsteps; ++t) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            cs_now = with_colsum && t < cs_steps;
             compute(buf);
             buf = (buf + 1 == NS) ? 0 : buf + 1;
         }
@@ -444,6 +447,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
         for (int t = 0; t < nsteps; ++t) {
             const int cur = t & 1;
             if (t + 1 < nsteps) stage(cur ^ 1, t + 1);
+            cs_now = with_colsum && t < cs_steps;
             compute(cur);
             __syncthreads();
         }
@@ -459,6 +463,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (t + NS - 1 < nsteps) stage(sbuf, t + NS - 1);
+            cs_now = with_colsum && t < cs_steps;
             compute(buf);
             buf = (buf + 1 == NS) ? 0 : buf + 1;
             sbuf = (sbuf + 1 == NS) ? 0 : sbuf + 1;

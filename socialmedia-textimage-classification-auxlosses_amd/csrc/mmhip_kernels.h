@@ -46,6 +46,7 @@ struct GemmTNProblem {
     int M, Nn, Nc, lda, ldb, ldc, tile_start;
     float* colsum;            // optional [Nn]: (+)= alpha * sum_m A[m][n] -- the bias gradient that goes with dW = dY^T X, taken
                               // from the same operand tiles by one extra MFMA column (B = ones), no extra pass, no atomics
+    int colsum_rows;          // > 0: the column sums cover rows 0 .. colsum_rows-1 only (a multiple of 64)
 };
 struct GemmTNGroup {
     GemmTNProblem p[GEMM_TN_MAX_GROUP];

@@ -278,8 +278,7 @@ hipError_t launch_gemm_tn_x3(const GemmTNProblem* probs, int count, int accumula
     static int on = -1;
     if (on < 0) { const char* e = getenv("MMHIP_X3_FAST"); on = e ? atoi(e) : 1; }
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    // split-plane form: the problems that fit the grouped bf16 kernel's shape rules (gemm.hip) go through it with three times the rows;
-    // their bias gradients (column sums of dY) come from the fp32 tensor itself
+    // split-plane form: the problems that fit the grouped bf16 kernel's shape rules (gemm.hip) go through it with three times the rows
     GemmTNProblem fastp[GEMM_TN_MAX_GROUP];
     int nfast = 0;
     size_t used = 0;
@@ -295,13 +294,9 @@ hipError_t launch_gemm_tn_x3(const GemmTNProblem* probs, int count, int accumula
         const size_t pla = (size_t)P.M * P.Nn, plb = (size_t)P.M * P.Nc;
         launch_split3((const float*)P.A, P.lda, P.M, P.Nn, pa, P.Nn, 0, pla, 2 * pla, s);
         launch_split3((const float*)P.B, P.ldb, P.M, P.Nc, pb, P.Nc, 0, 2 * plb, plb, s);
-        if (P.colsum) {
-            if (accumulate != 1) { hipError_t e = hipMemsetAsync(P.colsum, 0, (size_t)P.Nn * 4, s); if (e != hipSuccess) return e; }
-            hipError_t e = launch_colsum(P.A, P.M, P.Nn, P.lda, P.colsum, DT_F32, s, nullptr, alpha);
-            if (e != hipSuccess) return e;
-        }
         GemmTNProblem Q = P;
-        Q.A = pa; Q.lda = P.Nn; Q.B = pb; Q.ldb = P.Nc; Q.M = 3 * P.M; Q.colsum = nullptr;
+        Q.A = pa; Q.lda = P.Nn; Q.B = pb; Q.ldb = P.Nc; Q.M = 3 * P.M;
+        Q.colsum_rows = 2 * P.M;          // bias gradient = column sums of dY = of its hi and lo planes: the first two of the three stacked blocks
         fastp[nfast++] = Q;
         taken[i] = true;
     }
