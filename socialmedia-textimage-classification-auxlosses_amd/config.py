@@ -26,7 +26,8 @@ RES_PATH = "../results/"
 results_dir_mm_late = RES_PATH + "mm_late/"
 MODEL_DIR_DICT = {"bert": "../../../BERT-base/", "bertweet": "../../../BERTWEET-base/", "roberta": "../../../RoBERTa-base/",
                   "bernice": "../../../BERNICE/", "vit": "../../../ViT/", "beit": "../../../BEiT/", "deit": "../../../DEiT/",
-                  "clip": "../../../CLIP-ViT-L-14/", "clip336": "../../../CLIP-ViT-L-14-336/"}
+                  "clip": "../../../CLIP-ViT-L-14/", "clip336": "../../../CLIP-ViT-L-14-336/",
+                  "lxmert": "../../../LXMERT-base/"}      # the reference names the hub id "unc-nlp/lxmert-base-uncased" (config.py:148): no network here
 
 # task -> (num_labels, batch_size), reference models/config.py:13-48
 _TASK_SHAPE = {0: (2, 8), 1: (2, 8), 2: (4, 8), 3: (3, 16), 4: (4, 8), 5: (2, 16), 6: (2, 16)}

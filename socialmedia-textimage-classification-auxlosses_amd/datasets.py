@@ -118,6 +118,68 @@ class MM_Dataset(torch.utils.data.Dataset):
         return item
 
 
+class Lxmert_Dataset(torch.utils.data.Dataset):
+    """Item layout and file layout of the reference's Lxmert_Dataset (models/datasets.py:255-301): the tweet text tokenised per item
+    ([1, T] ids / attention mask / token types) and the post's 36 pre-extracted region features and normalised boxes, one `torch.save`d
+    tensor per post and kind:
+        <data_path><task_name>_img_feats/features/feat_<data_id>     float [1, 36, 2048] (or [36, 2048])
+        <data_path><task_name>_img_feats/boxes/nbox_<data_id>        float [1, 36, 4]
+    (the reference extracts them offline with a Faster-RCNN; here they are only read).  Task "fig" carries file names as ids (`123.jpg`):
+    the numeric part is the reported data id (:259-262).  Labels are one-hot rows (prepare_data)."""
+
+    def __init__(self, data_ids, text, labels, tokenizer, max_length, task_name, normalization=True, data_path=None):
+        from .config import DATA_PATH
+        self.data_ids, self.text, self.labels = data_ids, text, labels
+        self.task_name = task_name
+        self.data_ids_num = [float(str(x).split(".")[0]) for x in data_ids] if task_name == "fig" else data_ids
+        self.tokenizer, self.max_length, self.normalization = tokenizer, max_length, normalization
+        self.root = (DATA_PATH if data_path is None else data_path) + "{}_img_feats/".format(task_name)
+
+    def __len__(self):
+        return len(self.labels)
+
+    def _load(self, kind, stem, data_id):
+        path = self.root + "{}/{}_{}".format(kind, stem, data_id)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"ROI-feature file {path!r} not found (layout of models/datasets.py:291-294)")
+        try:
+            t = torch.load(path, map_location="cpu", weights_only=True)
+        except TypeError:                                     # older torch: no weights_only
+            t = torch.load(path, map_location="cpu")
+        return t.to(torch.float32)
+
+    def __getitem__(self, index):
+        text = normalize_tweet(self.text[index]) if self.normalization else self.text[index]
+        enc = self.tokenizer(text, padding="max_length", max_length=self.max_length, truncation=True, return_token_type_ids=True,
+                             return_attention_mask=True, add_special_tokens=True, return_tensors="pt")
+        data_id = self.data_ids[index]
+        feats, boxes = self._load("features", "feat", data_id), self._load("boxes", "nbox", data_id)
+        if feats.shape[-2:] != (36, 2048) or boxes.shape[-2:] != (36, 4):
+            raise ValueError(f"post {data_id}: features {tuple(feats.shape)} / boxes {tuple(boxes.shape)}, expected [.., 36, 2048] / [.., 36, 4]")
+        return {"input_ids": enc["input_ids"], "attention_mask": enc["attention_mask"], "token_type_ids": enc["token_type_ids"],
+                "features": feats.reshape(36, 2048), "normalized_boxes": boxes.reshape(36, 4),
+                "labels": torch.as_tensor(self.labels[index], dtype=torch.long), "data_id": torch.tensor(int(self.data_ids_num[index]), dtype=torch.long)}
+
+
+def lxmert_loaders_from_data_key(cfg, args, tokenizer, data_path=None):
+    """reference MMEarly_Model.load_data, LXMERT branch (models/mm_early.py:228-258): prepare_data -> three Lxmert_Datasets -> loaders
+    (train shuffled).  Data parallel: the training set is sharded by a DistributedSampler, validation / test stay whole."""
+    multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    tr, ytr, va, yva, te, yte, w = prepare_data(cfg.data, cfg.num_labels, args.testing, -1, args.seed if multi else None)
+    mk = lambda df, y: Lxmert_Dataset(df.tweet_id.values, df.text.values, y, tokenizer, cfg.max_length, cfg.task_name, data_path=data_path)
+    kw = dict(num_workers=int(getattr(args, "num_workers", 0) or 0))
+    if kw["num_workers"] > 0:
+        kw.update(persistent_workers=True, prefetch_factor=4, worker_init_fn=worker_init)
+    dl = lambda ds, sh: torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh, **kw)
+    train_ds = mk(tr, ytr)
+    if multi:
+        sampler = torch.utils.data.distributed.DistributedSampler(train_ds, shuffle=True, seed=int(args.seed), drop_last=False)
+        train_loader = torch.utils.data.DataLoader(train_ds, batch_size=cfg.batch_size, sampler=sampler, **kw)
+    else:
+        train_loader = dl(train_ds, True)
+    return train_loader, dl(mk(va, yva), False), dl(mk(te, yte), False), w
+
+
 def worker_init(_worker_id):
     """DataLoader worker: one thread per worker.  The GPU box grants a CPU share (16 cores), not the host's 256: a Rust tokenizer pool or an
     OpenMP team sized by the host's core count inside each of 8+ workers oversubscribes that share and throttles the process that enqueues

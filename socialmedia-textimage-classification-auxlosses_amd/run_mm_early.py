@@ -1,8 +1,9 @@
 """Command line of the early-fusion runs -- flags, defaults and file names of the reference's models/run_mm_early.py:17-118, LXMERT branch.
 The reference reads 36 x 2048 ROI features and boxes per post from `<DATA>/<task>_img_feats/{features,boxes}/...` (models/datasets.py:291-294),
-files produced by its offline Faster-RCNN extraction; none exist here, so this build serves --synthetic posts only (additive flag, as in
-run_mm_late.py) and refuses the data-key path rather than pretending.  Additive flags: --synthetic / --n_synthetic, --batch_size, --dtype,
---results_dir, --arch_layers.  Data parallel: `python -m torch.distributed.run --nproc-per-node N -m smtc_amd.run_mm_early ...`.
+files produced by its offline Faster-RCNN extraction.  The data-key path reads exactly those files (datasets.Lxmert_Dataset) with the
+tokenizer of config.MODEL_DIR_DICT["lxmert"]; the extraction itself is not part of this build.  --synthetic (additive flag, as in
+run_mm_late.py) serves random posts of the same shapes when no data exist (tools/make_dummy_task.py --roi writes a small real tree).
+Additive flags: --synthetic / --n_synthetic, --batch_size, --dtype, --results_dir, --arch_layers, --num_workers.  Data parallel: `python -m torch.distributed.run --nproc-per-node N -m smtc_amd.run_mm_early ...`.
 
     python -m smtc_amd.run_mm_early --model lxmert --task 3 --epochs 1 --use_clip_loss --use_tim_loss --synthetic
 """
@@ -74,7 +75,8 @@ def build_parser():
     p.add_argument("--save_model", action="store_true", help="eval test")
     p.add_argument("--use_saved_features", action="store_true", help="use preprocessed features")
     # additive
-    p.add_argument("--synthetic", action="store_true", help="synthetic posts (the only data source of this build: no ROI-feature files exist here)")
+    p.add_argument("--synthetic", action="store_true", help="synthetic posts instead of the data key + ROI-feature files")
+    p.add_argument("--num_workers", type=int, default=0, help="DataLoader worker processes of the data-key path")
     p.add_argument("--n_synthetic", type=int, default=128, help="synthetic training posts per rank")
     p.add_argument("--batch_size", type=int, default=None)
     p.add_argument("--dtype", choices=["bf16", "f16", "bf16x3"], default="bf16")
@@ -89,8 +91,6 @@ def main(argv=None):
         raise NotImplementedError("early fusion: only --model lxmert (BASELINE config 5); ViLT is out of scope")
     if args.use_loss_correction or args.use_saved_features:
         raise NotImplementedError("--use_loss_correction / --use_saved_features are not part of this build")
-    if not args.synthetic:
-        raise NotImplementedError("the ROI-feature files of the data-key path (models/datasets.py:291-294) do not exist here: use --synthetic")
     mmdist.init_from_env()
     torch.manual_seed(args.seed)                      # models/run_mm_early.py:40-41
     np.random.seed(args.seed + mmdist.rank())
@@ -105,20 +105,36 @@ def main(argv=None):
         kw["arch"] = dict(l_layers=args.arch_layers, r_layers=args.arch_layers, x_layers=args.arch_layers)
     trainer = MMEarly_Model(cfg, args.model, multilabel=cfg.multilabel, **kw)
     a = trainer.model.arch
-    n = 200 if args.testing else args.n_synthetic
-    mk = lambda cnt, seed: SyntheticLxmertPosts(cnt, a["vocab"], cfg.num_labels, cfg.max_length, seed)
-    tr, va, te = mk(n, 11 + mmdist.rank()), mk(max(cfg.batch_size, n // 4), 1011), mk(max(cfg.batch_size, n // 4), 2011)
-    dl = lambda ds, sh: torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh)
-    weight = balanced_class_weights([int(tr.labels[i].argmax()) for i in range(len(tr))], cfg.num_labels)
+    if args.synthetic:
+        n = 200 if args.testing else args.n_synthetic
+        mk = lambda cnt, seed: SyntheticLxmertPosts(cnt, a["vocab"], cfg.num_labels, cfg.max_length, seed)
+        tr, va, te = mk(n, 11 + mmdist.rank()), mk(max(cfg.batch_size, n // 4), 1011), mk(max(cfg.batch_size, n // 4), 2011)
+        dl = lambda ds, sh: torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh)
+        weight = balanced_class_weights([int(tr.labels[i].argmax()) for i in range(len(tr))], cfg.num_labels)
+        train_loader, val_loader, test_loader = dl(tr, True), dl(va, False), dl(te, False)
+    else:
+        # the reference's load_data (models/mm_early.py:228-258): data key -> prepare_data -> Lxmert_Dataset over the pre-extracted ROI files
+        from transformers import AutoTokenizer
+        from .config import MODEL_DIR_DICT
+        from .datasets import lxmert_loaders_from_data_key
+        if cfg.data is None:
+            raise FileNotFoundError("data key of task {} not found (config.PATH): run from <tree>/models/run, or use --synthetic".format(args.task))
+        tdir = MODEL_DIR_DICT["lxmert"]
+        if not os.path.isdir(tdir):
+            raise FileNotFoundError(f"tokenizer directory {tdir!r} (config.MODEL_DIR_DICT['lxmert']) not found: place the model there, or use --synthetic")
+        tok = AutoTokenizer.from_pretrained(tdir)
+        if len(tok) > a["vocab"]:
+            raise ValueError(f"tokenizer has {len(tok)} entries, the model's word table {a['vocab']}")
+        train_loader, val_loader, test_loader, weight = lxmert_loaders_from_data_key(cfg, args, tok)
     stem = results_dir + "{}_task{}_seed{}_{}_".format(args.model, args.task, args.seed, cfg.loss_str)      # :66-74
     if mmdist.rank() == 0:
         os.makedirs(results_dir, exist_ok=True)
     logger.info("Training...")
-    trainer.train(dl(tr, True), dl(va, False), args.epochs, None, cfg.lr, cfg.weight_decay, te_dataloader=dl(te, False),
+    trainer.train(train_loader, val_loader, args.epochs, None, cfg.lr, cfg.weight_decay, te_dataloader=test_loader,
                   model_path=stem + "net.pth" if args.save_model else None, val_filename=stem + "metrics_val.csv", te_filename=stem + "metrics_test.csv",
                   class_weight=weight)
     if args.evaltest and mmdist.rank() == 0:          # :88-115
-        pred = trainer.eval(dl(te, False), class_weight=weight)
+        pred = trainer.eval(test_loader, class_weight=weight)
         metrics = compute_metrics(pred, cfg.num_labels)
         print(metrics)
         if not args.testing:

@@ -136,6 +136,29 @@ def test_cli_synthetic_run_writes_the_reference_files(tmp_path):
     assert "model.encoder.x_layers.0.visual_attention.att.query.weight" in sd and "linear_fusion.weight" in sd and "logit_scale" in sd
 
 
+def test_cli_data_key_run_reads_roi_feature_files(tmp_path):
+    """run_mm_early.py on the data-key path: data key -> prepare_data -> Lxmert_Dataset over <task>_img_feats/{features,boxes} files
+    (reference models/datasets.py:255-301, mm_early.py:228-258) -> training, validation, test files"""
+    import subprocess, sys
+    import pandas as pd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_dummy_task
+    run_dir = make_dummy_task.main(str(tmp_path), 60, 1)
+    make_dummy_task.add_roi(str(tmp_path), 60)
+    res = str(tmp_path) + "/res/"
+    r = subprocess.run([sys.executable, "-m", "smtc_amd.run_mm_early", "--model", "lxmert", "--task", "2", "--epochs", "1", "--use_clip_loss",
+                        "--batch_size", "8", "--arch_layers", "1", "--results_dir", res, "--evaltest", "--num_workers", "2"],
+                       cwd=run_dir, env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    stem = res + "lxmert_task2_seed30_itc0.1_"
+    mv = pd.read_csv(stem + "metrics_val.csv")
+    assert list(mv.columns) == ["metric", "epoch-1"] and np.isfinite(mv["epoch-1"]).all()
+    preds = pd.read_csv(stem + "preds.csv")
+    key = pd.read_csv(os.path.join(run_dir, "..", "data", "data_key_imgtxt_random.csv"))
+    assert sorted(preds.data_id.tolist()) == sorted(key[key.split == "test"].tweet_id.tolist())
+
+
 DP_EARLY = r'''
 import os, sys, types, numpy as np, torch
 sys.path.insert(0, os.environ["ROOT"])

@@ -7,7 +7,11 @@
 so that  `cd <root>/work/models/run && python -m smtc_amd.run_mm_late --task 2 --testing ...`  exercises the real pipeline
 (data key -> normalize_tweet -> tokenizer -> PIL decode/resize/normalise -> model).  The shipped reference data keys are
 header-only, and no tokenizer / weights exist offline, hence this generator.
-usage: make_dummy_task.py ROOT [n_rows] [layers]"""
+With --roi also the early-fusion inputs (reference models/datasets.py:291-294, config.py:148):
+    <root>/LXMERT-base/        BERT-style tokenizer ([PAD] 0, [UNK] 100, [CLS] 101, [SEP] 102; token types)
+    <root>/work/models/data/<task>_img_feats/{features/feat_<id>, boxes/nbox_<id>}    torch.save'd [1,36,2048] / [1,36,4] per post
+    <root>/work/models/results/mm_early/testing/
+usage: make_dummy_task.py ROOT [n_rows] [layers] [--roi]"""
 import json
 import os
 import sys
@@ -69,7 +73,40 @@ def main(root, n=240, layers=2):
     return run
 
 
+def add_roi(root, n=240, task_name="tir"):
+    """ROI-feature files + a BERT-style tokenizer for run_mm_early.py's data-key path; call after main(root, n)"""
+    import torch
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    data = os.path.join(root, "work", "models", "data")
+    fdir, bdir = os.path.join(data, task_name + "_img_feats", "features"), os.path.join(data, task_name + "_img_feats", "boxes")
+    os.makedirs(fdir, exist_ok=True)
+    os.makedirs(bdir, exist_ok=True)
+    os.makedirs(os.path.join(root, "work", "models", "results", "mm_early", "testing"), exist_ok=True)
+    g = torch.Generator().manual_seed(7)
+    for i in range(n):
+        torch.save(torch.rand(1, 36, 2048, generator=g) * 2, os.path.join(fdir, f"feat_{1000 + i}"))
+        xy = torch.rand(1, 36, 2, generator=g) * 0.6
+        torch.save(torch.cat([xy, xy + 0.05 + torch.rand(1, 36, 2, generator=g) * 0.35], -1), os.path.join(bdir, f"nbox_{1000 + i}"))
+    vocab = {"[PAD]": 0}
+    for i in range(1, 100):
+        vocab[f"[unused{i}]"] = i
+    vocab.update({"[UNK]": 100, "[CLS]": 101, "[SEP]": 102, "[MASK]": 103})
+    for wd in [f"w{i}" for i in range(300)] + ["@user", "httpurl", "sarcasm", "image", "text", "adds", "nothing", "@USER", "HTTPURL"]:
+        vocab.setdefault(wd, len(vocab))
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    tok.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1", special_tokens=[("[CLS]", 101), ("[SEP]", 102)])
+    ldir = os.path.join(root, "LXMERT-base")
+    os.makedirs(ldir, exist_ok=True)
+    PreTrainedTokenizerFast(tokenizer_object=tok, pad_token="[PAD]", unk_token="[UNK]", cls_token="[CLS]", sep_token="[SEP]", mask_token="[MASK]").save_pretrained(ldir)
+    return ldir
+
+
 if __name__ == "__main__":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import smtc_amd  # noqa: F401
-    print(main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 240, int(sys.argv[3]) if len(sys.argv) > 3 else 2))
+    argv = [x for x in sys.argv[1:] if x != "--roi"]
+    print(main(argv[0], int(argv[1]) if len(argv) > 1 else 240, int(argv[2]) if len(argv) > 2 else 2))
+    if "--roi" in sys.argv:
+        print(add_roi(argv[0], int(argv[1]) if len(argv) > 1 else 240))
