@@ -15,6 +15,9 @@ namespace mmhip {
 
 static constexpr int HD = 64;          // head dim
 static constexpr float LOG2E = 1.4426950408889634f;
+// v_exp_f32 itself: exp2f() wraps it in a denormal-range rescue (compare, select, add, ldexp: five more VALU instructions per element);
+// a soft-max weight below 2^-126 of the row maximum is zero either way
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // byte offset of 16-B chunk `ch` (0..7) of row `row` in a [rows][64] 16-bit image read by rows (ds_read_b128)
 __device__ __forceinline__ int rowimg_off(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
@@ -53,7 +56,9 @@ __device__ __forceinline__ void stage_image(char* img, const T* src, int ld, int
 // ------------------------------------------------------------------------------------------------ forward
 // NW waves per (post, head); wave w takes query tiles w, w+NW, ...  Online soft-max over the key tiles keeps one 32x32
 // score tile live at a time (~100 VGPRs -> 4 waves per SIMD) instead of all of them (490 VGPRs, 1 wave per SIMD).
-template <typename T, int NKT, int NW>
+// DROP (compile time, so that neither instance branches per element): 0 = no dropout, 1 = one hash per element, 2 = one hash per PAIR of
+// consecutive keys (S even: the element index of an even key is even, mm_keep2)
+template <typename T, int NKT, int NW, int DROP>
 __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
@@ -76,7 +81,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(AttnArgs a) {
     const int r = lane & 31, h2 = lane >> 5;
     const float sc = a.scale * LOG2E;
     const int nqt = a.q_tiles > 0 ? min((S + 31) / 32, a.q_tiles) : (S + 31) / 32;
-    const bool dropping = a.drop.thresh16 != 0;
     for (int qt = w; qt < nqt; qt += NW) {
         const int q = qt * 32 + r;
         const int qrow = min(q, S - 1);
@@ -110,11 +114,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(AttnArgs a) {
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             const float m_new = fmaxf(m_run, tmax);
             const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;        // a fully masked tile contributes nothing
-            const float alpha = exp2f(m_run - m_safe);                      // first tile: exp2(-inf) = 0
+            const float alpha = fast_exp2(m_run - m_safe);                  // first tile: exp2(-inf) = 0
             float psum = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = exp2f(acc[e] - m_safe);
+                const float p = fast_exp2(acc[e] - m_safe);
                 acc[e] = p;
                 psum += p;
             }
@@ -129,14 +133,19 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(AttnArgs a) {
             for (int s2 = 0; s2 < 2; ++s2) {
                 v8 pf;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 8; j += 2) {
                     const int reg = 8 * s2 + j;
-                    float p = acc[reg];
-                    if (dropping) {
-                        const int key = kt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-                        p = mm_keep(ebase + (uint32_t)key, a.drop) ? p * a.drop.keep_scale : 0.f;
+                    float p0 = acc[reg], p1 = acc[reg + 1];
+                    if (DROP) {
+                        const int key = kt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;      // reg even: keys key, key + 1
+                        bool k0, k1;
+                        if (DROP == 2) mm_keep2(ebase + (uint32_t)key, a.drop, k0, k1);
+                        else { k0 = mm_keep(ebase + (uint32_t)key, a.drop); k1 = mm_keep(ebase + (uint32_t)key + 1u, a.drop); }
+                        p0 = k0 ? p0 * a.drop.keep_scale : 0.f;
+                        p1 = k1 ? p1 * a.drop.keep_scale : 0.f;
                     }
-                    pf[j] = from_f<T>(p);
+                    pf[j] = from_f<T>(p0);
+                    pf[j + 1] = from_f<T>(p1);
                 }
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -169,7 +178,7 @@ __device__ __forceinline__ int ds_off(int row, int ch, int sp_chunks) {   // [64
     return row * (sp_chunks * 16) + ((ch ^ (row & (sp_chunks - 1) & 15)) << 4);
 }
 
-template <typename T, int NKT>
+template <typename T, int NKT, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 v8;
@@ -227,7 +236,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
     }
     __syncthreads();
     const float sc = a.scale * LOG2E;
-    const bool dropping = a.drop.thresh16 != 0;
     f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
     constexpr int NQT = NKT;
     const int qlim = a.q_tiles > 0 ? min(NQT, a.q_tiles) : NQT;      // later tiles carry a zero d ctx: nothing to do
@@ -259,10 +267,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
                     for (int e = 0; e < 4; ++e) {
                         const int reg = 4 * g + e;
                         const int q = q0 + 8 * g + 4 * h2 + e;
-                        float p = exp2f(sacc[reg] * sc + mbk - l4[e]);
+                        float p = fast_exp2(sacc[reg] * sc + mbk - l4[e]);
                         if (q >= S) p = 0.f;
                         float pd = p, dpd = pacc[reg];
-                        if (dropping) {
+                        if (DROP) {
                             const uint32_t eidx = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)min(q, S - 1)) * (uint32_t)S + (uint32_t)min(key, S - 1);
                             const bool kp = mm_keep(eidx, a.drop);
                             pd = kp ? p * a.drop.keep_scale : 0.f;
@@ -410,11 +418,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(AttnArgs a) {
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             const float m_new = fmaxf(m_run, tmax);
             const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = exp2f(m_run - m_safe);
+            const float alpha = fast_exp2(m_run - m_safe);
             float psum = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = exp2f(acc[e] - m_safe);
+                const float p = fast_exp2(acc[e] - m_safe);
                 acc[e] = p;
                 psum += p;
             }
@@ -552,7 +560,7 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
                     for (int e = 0; e < 4; ++e) {
                         const int reg = 4 * g + e;
                         const int q = q0 + 8 * g + 4 * h2 + e;
-                        float p = exp2f(sacc[reg] * sc + mbk - l4[e]);
+                        float p = fast_exp2(sacc[reg] * sc + mbk - l4[e]);
                         if (q >= S) p = 0.f;
                         float pd = p, dpd = pacc[reg];
                         if (dropping) {
@@ -627,12 +635,18 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-template <typename T, int NKT, int NW>
-static void launch_fwd_t(const AttnArgs& a, hipStream_t s) {
+template <typename T, int NKT, int NW, int DROP>
+static void launch_fwd_td(const AttnArgs& a, hipStream_t s) {
     const int lds = 2 * NKT * 32 * 128 + NKT * 32 * 4;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
-    hipLaunchKernelGGL((attn_fwd_kernel<T, NKT, NW>), dim3(a.heads, a.posts), dim3(NW * 64), lds, s, a);
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT, NW, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+    hipLaunchKernelGGL((attn_fwd_kernel<T, NKT, NW, DROP>), dim3(a.heads, a.posts), dim3(NW * 64), lds, s, a);
+}
+template <typename T, int NKT, int NW>
+static void launch_fwd_t(const AttnArgs& a, hipStream_t s) {
+    if (!a.drop.thresh16) launch_fwd_td<T, NKT, NW, 0>(a, s);
+    else if (a.S & 1) launch_fwd_td<T, NKT, NW, 1>(a, s);
+    else launch_fwd_td<T, NKT, NW, 2>(a, s);
 }
 template <typename T>
 static hipError_t launch_fwd_d(const AttnArgs& a, hipStream_t s) {
@@ -671,12 +685,17 @@ hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s) {
     }
     return dtype == DT_BF16 ? launch_fwd_d<bf16_t>(a, s) : launch_fwd_d<f16_t>(a, s);
 }
-template <typename T, int NKT>
-static void launch_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
+template <typename T, int NKT, bool DROP>
+static void launch_bwd_td(const AttnBwdArgs& a, hipStream_t s) {
     const int lds = 3 * NKT * 32 * 128 + 64 * NKT * 32 * 2 + 2 * NKT * 32 * 4;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
-    hipLaunchKernelGGL((attn_bwd_kernel<T, NKT>), dim3(a.heads, a.posts), dim3(256), lds, s, a);
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NKT, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+    hipLaunchKernelGGL((attn_bwd_kernel<T, NKT, DROP>), dim3(a.heads, a.posts), dim3(256), lds, s, a);
+}
+template <typename T, int NKT>
+static void launch_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
+    if (a.drop.thresh16) launch_bwd_td<T, NKT, true>(a, s);
+    else launch_bwd_td<T, NKT, false>(a, s);
 }
 template <typename T>
 static hipError_t launch_bwd_d(const AttnBwdArgs& a, hipStream_t s) {
