@@ -236,6 +236,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
     }
     __syncthreads();
     const float sc = a.scale * LOG2E;
+    // dropout element index of (query q, this lane's key) = e_lane + q * S in 32-bit wrap-around arithmetic -- the forward's
+    // (uint32)(((post * heads + head) * S + q)) * S + key.  No clamps: a query or key past S has p = 0 and its mask is never used.
+    const uint32_t e_lane = (uint32_t)(((size_t)post * a.heads + head) * S) * (uint32_t)S + (uint32_t)key + (uint32_t)(4 * h2) * (uint32_t)S;
     f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
     constexpr int NQT = NKT;
     const int qlim = a.q_tiles > 0 ? min(NQT, a.q_tiles) : NQT;      // later tiles carry a zero d ctx: nothing to do
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
                 const int qt = pair * 2 + t2;
                 if (qt >= qlim) break;
                 const int q0 = qt * 32;
+                const uint32_t e_tile = e_lane + (uint32_t)q0 * (uint32_t)S;      // + (8 g + e) * S per element: wave-uniform addends
                 f32x16 sacc = f32x16{}, pacc = f32x16{};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -263,16 +267,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
                 for (int g = 0; g < 4; ++g) {
                     f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2 + q0 + 8 * g + 4 * h2);
                     f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + q0 + 8 * g + 4 * h2);
+                    uint32_t e_el = e_tile + (uint32_t)g * (8u * (uint32_t)S);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < 4; ++e, e_el += (uint32_t)S) {
                         const int reg = 4 * g + e;
                         const int q = q0 + 8 * g + 4 * h2 + e;
                         float p = fast_exp2(sacc[reg] * sc + mbk - l4[e]);
                         if (q >= S) p = 0.f;
                         float pd = p, dpd = pacc[reg];
                         if (DROP) {
-                            const uint32_t eidx = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)min(q, S - 1)) * (uint32_t)S + (uint32_t)min(key, S - 1);
-                            const bool kp = mm_keep(eidx, a.drop);
+                            const bool kp = mm_keep(e_el, a.drop);
                             pd = kp ? p * a.drop.keep_scale : 0.f;
                             dpd = kp ? dpd * a.drop.keep_scale : 0.f;
                         }
@@ -305,14 +309,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
                 for (int ks = 0; ks < SP / 16; ++ks) {
                     v8 dsf = lds_read8<T>(dSimg, ds_off(qi * 32 + r, 2 * ks + h2, SPC));
                     v8 ktf = tr_frag_natural<T>(Ktr, ks * 16, dt * 32, lane);
-                    dq = mfma32(dsf, ktf, dq);
+                    dq = mfma32(ktf, dsf, dq);          // dQ^T = K^T . dS^T: the same two fragments with the roles swapped, so the lane owns a query row
                 }
-                // dq[reg] = dQ(query qt*32 + (reg&3) + 8*(reg>>2) + 4*h2, d = dt*32 + r)
-                T* dqp = (T*)a.dqkv + row0 * a.ld_qkv + head * HD + dt * 32 + r;
+                // dq[reg] = dQ(query qt*32 + r, d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h2): four consecutive d per register quad -> 8-byte stores
+                const int q = qt * 32 + r;
+                if (q < S) {
+                    T* dqp = (T*)a.dqkv + (row0 + q) * a.ld_qkv + head * HD + dt * 32 + 4 * h2;
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int q = qt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-                    if (q < S) dqp[(size_t)q * a.ld_qkv] = from_f<T>(dq[reg]);
+                    for (int g = 0; g < 4; ++g) {
+                        v4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = from_f<T>(dq[4 * g + e]);
+                        *reinterpret_cast<v4*>(dqp + 8 * g) = o;
+                    }
                 }
             }
         }
