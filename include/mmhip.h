@@ -156,6 +156,13 @@ int mmhip_set_row_state(mmhip_handle h, uint8_t* row_state);
  * thread that met one.  The caller polls the counter when it reads the loss anyway and reacts: mmhip_set_loss_scale lowers
  * the scale (0 = back to the default); with bf16 (no scale) a count means a real divergence. */
 int mmhip_set_nonfinite_counter(uint32_t* device_counter);
+/* Whole-step form of the guard (round 3): TWO uint32 on the device, {counter, flag}.  mmhip_backward_begin clears the flag; the
+ * embedding backward -- the end of the backward's 16-bit chain, where an overflow anywhere upstream arrives as inf / NaN -- raises
+ * it and counts; every AdamW entry point that finds the flag set leaves parameters and moments alone and only clears the gradient,
+ * so an overflowed step is skipped as a whole without the host looking (the host reads the counter a step late and lowers the
+ * scale).  While armed, an f16 engine runs all its AdamW launches after the backward (no per-layer launches beside it).
+ * NULL disarms.  Like the counter it is one registration per process: the model that steps claims it. */
+int mmhip_set_step_guard(uint32_t* device_words2);
 int mmhip_set_loss_scale(mmhip_handle h, float loss_scale);
 
 /* ---- one whole training step of MMLate_Model.train (models/mm_late.py:452-491: zero_grad, forward, loss mix, backward,

@@ -72,6 +72,7 @@ _SIGS = {
     "mmhip_adamw_rows": (I, [P, P, P, P, I, I, P, F, F, F, F, F, I, F, I, P]),
     "mmhip_set_row_state": (I, [P, P]),
     "mmhip_set_nonfinite_counter": (I, [P]),
+    "mmhip_set_step_guard": (I, [P]),
     "mmhip_set_loss_scale": (I, [P, F]),
     "mmhip_train_step": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P]),
     "mmhip_train_step_dp": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P, P, P]),

@@ -1004,6 +1004,11 @@ int backward_finish(mmhip_engine& e, hipStream_t s) {
     return 0;
 }
 
+// device words of the overflow guard, claimed by the model that steps (mmhip_set_step_guard / mmhip_set_nonfinite_counter): [0] counter of
+// non-finite gradient sightings, [1] "this step is void" flag raised by the backward and honoured by the AdamW kernels
+static unsigned* g_nonfinite = nullptr;
+static unsigned* g_skip = nullptr;
+
 int embed_backward(mmhip_engine& e, hipStream_t s) {
     const mmhip_config& c = e.cfg;
     const float* W = e.train;
@@ -1020,6 +1025,7 @@ int embed_backward(mmhip_engine& e, hipStream_t s) {
     b.alpha = 1.0f / e.gscale();
     b.row_state = e.word_row_state;
     if (deterministic()) { b.det_rows = e.wsp<float>(e.g_det_rows); b.max_pos = c.max_pos; }
+    b.status = g_skip ? g_nonfinite : nullptr;
     CHECK_HIP(launch_embed_bwd(b, e.dt(), s));
     return 0;
 }
@@ -1257,6 +1263,7 @@ int mmhip_stage_grad_range(mmhip_handle h, int stage, uint64_t* begin, uint64_t*
 }
 
 int mmhip_backward_begin(mmhip_handle h, const float* d_out_cls, const float* d_logits, const float* d_out_tim, const float* d_feats, void* stream) {
+    if (g_skip) CHECK_HIP(hipMemsetAsync(g_skip, 0, 4, (hipStream_t)stream));      // the step guard's flag belongs to one backward
     (void)stream;
     if (!h || !h->fwd_done || !h->grad) return MMHIP_E_STATE;
     mmhip_engine& e = *h;
@@ -1304,11 +1311,16 @@ int mmhip_backward(mmhip_handle h, const float* d_out_cls, const float* d_logits
     return mmhip_backward_finish(h, stream);
 }
 
-// process-wide device counter of non-finite gradient elements met by the AdamW kernels (one engine per process and device)
-static unsigned* g_nonfinite = nullptr;
 int mmhip_set_nonfinite_counter(uint32_t* device_counter) {
     if ((uintptr_t)device_counter & 3) return MMHIP_E_INVALID;
     g_nonfinite = device_counter;
+    g_skip = nullptr;
+    return 0;
+}
+int mmhip_set_step_guard(uint32_t* device_words2) {
+    if ((uintptr_t)device_words2 & 3) return MMHIP_E_INVALID;
+    g_nonfinite = device_words2;
+    g_skip = device_words2 ? device_words2 + 1 : nullptr;
     return 0;
 }
 int mmhip_set_loss_scale(mmhip_handle h, float loss_scale) {
@@ -1325,7 +1337,7 @@ int mmhip_adamw(float* p, float* g, float* m, float* v, uint64_t n, float lr, fl
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
     a.bc1 = (float)(1.0 - pow((double)beta1, step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
-    a.zero_grad = zero_grad; a.grad_scale = grad_scale; a.nonfinite = g_nonfinite;
+    a.zero_grad = zero_grad; a.grad_scale = grad_scale; a.nonfinite = g_nonfinite; a.skip = g_skip;
     CHECK_HIP(launch_adamw(a, (hipStream_t)stream));
     return 0;
 }
@@ -1345,7 +1357,7 @@ int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = (size_t)rows * width; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
     a.bc1 = (float)(1.0 - pow((double)beta1, step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
-    a.zero_grad = zero_grad; a.grad_scale = grad_scale; a.nonfinite = g_nonfinite;
+    a.zero_grad = zero_grad; a.grad_scale = grad_scale; a.nonfinite = g_nonfinite; a.skip = g_skip;
     CHECK_HIP(launch_adamw_rows(a, rows, width, row_state, (hipStream_t)stream));
     return 0;
 }
@@ -1374,7 +1386,8 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
     // kernels on the caller's stream, so the side stream first waits for the event recorded behind them.
     hipStream_t s = (hipStream_t)stream;
     const char* early_env = getenv("MMHIP_EARLY_ADAMW");          // read per step: tests compare both orders in one process
-    const int early = early_env ? atoi(early_env) : 1;
+    // f16 with the step guard armed: a void step is only known when the backward has reached the embeddings, so every AdamW waits for it
+    const int early = (e.dt() == DT_F16 && g_skip) ? 0 : (early_env ? atoi(early_env) : 1);
     if (int r = mmhip_backward_begin(h, nullptr, nullptr, nullptr, nullptr, stream)) return r;
     const int L = e.cfg.layers_txt;
     // data-parallel form (cb): the layer optimizers wait for the gradient exchange, so they run after it (below); the callback is told

@@ -339,6 +339,13 @@ __device__ __forceinline__ float guard_finite(float g, bool& bad) {
 }
 __global__ __launch_bounds__(256) void adamw_kernel(AdamWArgs a) {
     const size_t n4 = a.n / 4;
+    if (a.skip && *a.skip) {          // the step is void: leave p / m / v alone, clear the gradient for the next step
+        if (a.zero_grad) {
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) reinterpret_cast<f32x4*>(a.g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) a.g[n4 * 4 + threadIdx.x] = 0.f;
+        }
+        return;
+    }
     bool bad = false;
     const float one_m_b1 = 1.f - a.beta1, one_m_b2 = 1.f - a.beta2;
     const float decay = 1.f - a.lr * a.wd, step = a.lr / a.bc1;
@@ -429,6 +436,16 @@ __global__ __launch_bounds__(256) void adamw_rows_kernel(AdamWArgs a, int rows, 
     const float one_m_b1 = 1.f - a.beta1, one_m_b2 = 1.f - a.beta2;
     const float decay = 1.f - a.lr * a.wd, step = a.lr / a.bc1;
     bool bad = false;
+    if (a.skip && *a.skip) {          // void step: rows that received a gradient lose it (and the flag), nothing else moves
+        for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+            const int st = state[row];
+            if (!(st & ROW_HAS_GRAD) || !a.zero_grad) continue;
+            f32x4* __restrict__ g4 = reinterpret_cast<f32x4*>(a.g + (size_t)row * width);
+            for (int c = lane; c < nch; c += 64) g4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (lane == 0) state[row] = (uint8_t)(st & ~ROW_HAS_GRAD);
+        }
+        return;
+    }
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         const int st = state[row];
         f32x4* __restrict__ p4 = reinterpret_cast<f32x4*>(a.p + (size_t)row * width);

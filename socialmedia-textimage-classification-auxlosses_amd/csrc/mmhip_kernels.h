@@ -146,6 +146,8 @@ struct EmbedBwdArgs {
     float* det_rows;      // optional [posts*T, H] fp32 workspace: deterministic mode -- the per-slot gradient rows are stored here and the
                           // word / position rows are summed from them in slot order by a second kernel (no fp32 atomics)
     int max_pos;          // rows of the position table (deterministic mode)
+    unsigned* status;     // optional device words {counter, skip flag} (mmhip_set_step_guard): a non-finite element of dx -- the END of the
+                          // backward's 16-bit chain, so an overflow anywhere upstream arrives here as inf / NaN -- counts and raises the flag
 };
 bool deterministic();     // MMHIP_DETERMINISTIC=1
 hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s);
@@ -222,6 +224,8 @@ struct AdamWArgs {
     int zero_grad;
     float grad_scale;     // gradients are multiplied by this before use (1/world for DP averaging)
     unsigned* nonfinite;  // optional device counter: a non-finite gradient element is treated as 0 (its moments are not poisoned) and counted
+    const unsigned* skip; // optional device word: non-zero = this step's gradients are void (the backward met a non-finite value in its
+                          // 16-bit chain): nothing is updated, the gradient is only cleared (zero_grad) -- the whole step is skipped
 };
 hipError_t launch_adamw(const AdamWArgs& a, hipStream_t s);
 // row-lazy AdamW over a [rows, width] table (a.p .. a.v, a.n = rows*width): rows whose state byte is 0 (no gradient now,

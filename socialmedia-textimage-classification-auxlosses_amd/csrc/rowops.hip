@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
         if (lane + 64 * t < nch) load4<float>(a.gamma + (lane + 64 * t) * 4, gam[t]);
     }
     int pid0 = -1;
+    bool seen_bad = false;
     const int p0 = blockIdx.y * EMB_POSTS_PER_BLOCK + w * (EMB_POSTS_PER_BLOCK / 4);
     for (int pp = 0; pp < EMB_POSTS_PER_BLOCK / 4; ++pp) {
         const int post = p0 + pp;
@@ -368,6 +369,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
             }
         }
         const float c1 = wave_sum(s1) / a.H, c2 = wave_sum(s2) / a.H;
+        // the row sums are non-finite as soon as one element of the incoming gradient row is (inf, NaN; inf * 0 = NaN): the overflow guard
+        if (!(fabsf(c1) <= 3.4028234e38f) || !(fabsf(c2) <= 3.4028234e38f)) seen_bad = true;
         const int64_t id = a.ids[row];
         const int pid = a.pos_ids[row];
         float* wrow = (id != a.pad_id && !a.det_rows) ? a.dword + (size_t)id * a.H : nullptr;
@@ -449,6 +452,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
             for (int j = i + 1; j < 4; ++j) if (wpid[j] == pi) sp += rowbuf[j][c];
             atomicAdd(a.dpos + (size_t)pi * a.H + c, sp);
         }
+    }
+    if (seen_bad && a.status && lane == 0) {
+        atomicAdd(a.status, 1u);
+        atomicOr(a.status + 1, 1u);
     }
 }
 

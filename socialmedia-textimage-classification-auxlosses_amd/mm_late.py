@@ -204,9 +204,9 @@ class MM_Model(nn.Module):
             self._word_row_state = torch.zeros((self._word_info["shape"][0] + 3) // 4 * 4, dtype=torch.uint8, device=dev)
         _lib.check(lib.mmhip_set_row_state(h, _lib.ptr(self._word_row_state)), "set_row_state")
         if first:
-            self._nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)      # include/mmhip.h: overflow guard of the AdamW kernels
+            self._nonfinite = torch.zeros(2, dtype=torch.int32, device=dev)      # include/mmhip.h mmhip_set_step_guard: {counter, void-step flag}
             self._loss_scale = 0.0
-        _lib.check(lib.mmhip_set_nonfinite_counter(_lib.ptr(self._nonfinite)), "set_nonfinite_counter")
+        _lib.check(lib.mmhip_set_step_guard(_lib.ptr(self._nonfinite)), "set_step_guard")
         if self._loss_scale > 0:
             _lib.check(lib.mmhip_set_loss_scale(h, self._loss_scale), "set_loss_scale")
         self._ws = None
@@ -247,7 +247,7 @@ class MM_Model(nn.Module):
     def __del__(self):
         try:
             if self._handle is not None:
-                _lib.lib().mmhip_set_nonfinite_counter(None)
+                _lib.lib().mmhip_set_step_guard(None)
                 _lib.lib().mmhip_destroy(self._handle)
         except Exception:
             pass
@@ -505,7 +505,16 @@ class MMLate_Model(object):
         if not m.training:
             m.train()                              # walks ~370 submodules (1.3 ms of host time): only on a mode change
         m._clean_grad()                            # an autograd-path backward before this step left its gradient in the flat buffer
-        lib.mmhip_set_nonfinite_counter(_lib.ptr(m._nonfinite))     # process-wide pointer: (re)claim it for the model that steps
+        lib.mmhip_set_step_guard(_lib.ptr(m._nonfinite))     # process-wide registration: (re)claim it for the model that steps
+        self._poll_guard()                                   # the counter as it stood a step ago (pinned copy, no host sync)
+        try:
+            return self._train_step(ids, mask, pixel_values, onehot, class_weight, lr, weight_decay, step, tim_ids, tim_mask, lbl_tim, vision_keys)
+        finally:
+            self._post_guard()
+
+    def _train_step(self, ids, mask, pixel_values, onehot, class_weight, lr, weight_decay, step, tim_ids, tim_mask, lbl_tim, vision_keys):
+        m, lib = self.model, _lib.lib()
+        s = _lib.stream_ptr()
         w_cls, w_itc, w_itm = self.loss_weights()
         onehot = onehot.to(self.device, torch.int64).contiguous()
         cw = None if class_weight is None else class_weight.to(self.device, torch.float32).contiguous()
@@ -542,6 +551,7 @@ class MMLate_Model(object):
             works += buckets.works
         for w in works:
             w.wait()
+        self._share_guard_flag(exchange)
         self._adamw(lr, weight_decay, step, rows=False)        # dense ranges first: the word-table rows are still travelling
         m._refresh_weights(2)                                  # 16-bit GEMM operand copies (no word-table dependence)
         for f in finishers:
@@ -616,6 +626,7 @@ class MMLate_Model(object):
                     elif st == _lib.CB_WAIT_DENSE:
                         for w in works + buckets.works:
                             w.wait()
+                        self._share_guard_flag(True)
                     elif st == _lib.CB_FINISH_ROWS:
                         for f in finishers:
                             f()
@@ -650,20 +661,61 @@ class MMLate_Model(object):
                                                 _lib.ptr(m._word_row_state), lr, 0.9, 0.999, 1e-8, weight_decay, step,
                                                 1.0 / self.world, 1, _lib.stream_ptr()), "adamw_rows")
 
+    # ---- overflow guard, host side.  The device skips a void step by itself (include/mmhip.h: mmhip_set_step_guard); the host only adapts
+    # the f16 loss scale, from a pinned copy of the counter taken at the end of the previous step -- no synchronisation in the step loop.
+    GROWTH_INTERVAL = 200          # clean steps before the f16 loss scale doubles again (torch.cuda.amp.GradScaler's schedule: 2000; runs here are short)
+    MAX_LOSS_SCALE = 65536.0
+
+    def _share_guard_flag(self, exchange):
+        """data parallel: a step is void on every rank if it is on one (the replicas must take the same decision)"""
+        if exchange and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.distributed.all_reduce(self.model._nonfinite[1:], op=torch.distributed.ReduceOp.MAX)
+
+    def _post_guard(self):
+        if getattr(self, "_nf_host", None) is None:
+            self._nf_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._nf_event = torch.cuda.Event()
+            self._nf_seen, self._nf_clean, self._nf_pending = 0, 0, False
+        self._nf_host.copy_(self.model._nonfinite, non_blocking=True)
+        self._nf_event.record()
+        self._nf_pending = True
+
+    def _poll_guard(self):
+        if not getattr(self, "_nf_pending", False) or not self._nf_event.query():
+            return
+        self._nf_pending = False
+        n = int(self._nf_host[0]) - self._nf_seen
+        m = self.model
+        if n <= 0:
+            self._nf_clean += 1
+            if m.dtype_name == "f16" and self._nf_clean >= self.GROWTH_INTERVAL and 0 < m._loss_scale < self.MAX_LOSS_SCALE:
+                self._nf_clean = 0
+                m._loss_scale = min(m._loss_scale * 2.0, self.MAX_LOSS_SCALE)
+                _lib.check(_lib.lib().mmhip_set_loss_scale(m._handle, m._loss_scale), "set_loss_scale")
+            return
+        self._nf_seen += n
+        self._nf_clean = 0
+        self._react_to_overflow(n)
+
+    def _react_to_overflow(self, n):
+        m = self.model
+        if m.dtype_name != "f16":
+            raise FloatingPointError(f"non-finite gradients met {n} times ({m.dtype_name}): the run has diverged")
+        cur = m._loss_scale if m._loss_scale > 0 else 1024.0
+        m._loss_scale = max(cur / 2.0, 1.0)
+        _lib.check(_lib.lib().mmhip_set_loss_scale(m._handle, m._loss_scale), "set_loss_scale")
+        logger.warning("f16 gradient overflow (%d sightings; the steps were skipped on the device): loss scale %g -> %g", n, cur, m._loss_scale)
+
     def check_overflow(self):
         """non-finite gradient elements since the last call (the AdamW kernels skipped and counted them, include/mmhip.h).
         f16: halve the loss scale (dynamic loss scaling) and go on; other dtypes: a real divergence -> FloatingPointError."""
         m = self.model
-        n = int(m._nonfinite.item())
-        if n == 0:
+        n = int(m._nonfinite[0].item()) - getattr(self, "_nf_seen", 0)
+        if n <= 0:
             return 0
         m._nonfinite.zero_()
-        if m.dtype_name != "f16":
-            raise FloatingPointError(f"{n} AdamW threads met non-finite gradients ({m.dtype_name}): the run has diverged")
-        cur = m._loss_scale if m._loss_scale > 0 else 1024.0
-        m._loss_scale = max(cur / 2.0, 1.0)
-        _lib.check(_lib.lib().mmhip_set_loss_scale(m._handle, m._loss_scale), "set_loss_scale")
-        logger.warning("f16 gradient overflow (%d AdamW threads skipped non-finite elements): loss scale %g -> %g", n, cur, m._loss_scale)
+        self._nf_seen, self._nf_clean, self._nf_pending = 0, 0, False
+        self._react_to_overflow(n)
         return n
 
     @staticmethod

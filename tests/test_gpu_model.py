@@ -336,11 +336,73 @@ def test_adamw_guards_against_nonfinite_gradients():
     arch = dict(layers_txt=1, layers_img=1, vocab=300, max_pos=130)
     tr = MMLate_Model(cfgd, "bernice", "vit", "attention", arch=arch, seed=3, dtype="f16")
     tr.model._nonfinite.fill_(3)
-    assert tr.check_overflow() == 3 and tr.model._loss_scale == 512.0 and int(tr.model._nonfinite.item()) == 0
+    assert tr.check_overflow() == 3 and tr.model._loss_scale == 512.0 and int(tr.model._nonfinite[0].item()) == 0
     tr2 = MMLate_Model(cfgd, "bernice", "vit", "attention", arch=arch, seed=3, dtype="bf16")
     tr2.model._nonfinite.fill_(1)
     with pytest.raises(FloatingPointError):
         tr2.check_overflow()
+
+
+def test_step_guard_skips_a_void_step_as_a_whole():
+    """include/mmhip.h mmhip_set_step_guard: with the flag raised the AdamW entry points leave p / m / v (and the word rows'
+    moments) alone and only clear the gradient; an f16 step whose gradient chain overflows raises the flag on the device by itself, the
+    whole step is void -- parameters, moments and row flags bit-identical to before, gradient buffer clean -- and the host, reading the
+    counter one step late and without synchronising, halves the loss scale; with a sane scale training goes on."""
+    import types
+    from smtc_amd import _lib
+    dev = torch.device("cuda:0")
+    lib = _lib.lib()
+    # ---- operator level
+    words = torch.tensor([0, 1], dtype=torch.int32, device=dev)
+    _lib.check(lib.mmhip_set_step_guard(_lib.ptr(words)))
+    n = 4099
+    p, g = torch.randn(n, device=dev), torch.randn(n, device=dev)
+    m, v = torch.rand(n, device=dev), torch.rand(n, device=dev)
+    p0, m0, v0 = p.clone(), m.clone(), v.clone()
+    _lib.check(lib.mmhip_adamw(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, 1.0, 1, _lib.stream_ptr()))
+    assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0) and g.abs().max().item() == 0.0
+    rows, width = 10, 64
+    P, G = torch.randn(rows, width, device=dev), torch.randn(rows, width, device=dev)
+    M, V = torch.rand(rows, width, device=dev), torch.rand(rows, width, device=dev)
+    st = torch.tensor([0, 1, 2, 3, 1, 0, 2, 3, 1, 1, 0, 0], dtype=torch.uint8, device=dev)
+    P0, M0, V0 = P.clone(), M.clone(), V.clone()
+    _lib.check(lib.mmhip_adamw_rows(_lib.ptr(P), _lib.ptr(G), _lib.ptr(M), _lib.ptr(V), rows, width, _lib.ptr(st), 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, 1.0, 1,
+                                    _lib.stream_ptr()))
+    assert torch.equal(P, P0) and torch.equal(M, M0) and torch.equal(V, V0)
+    had = torch.tensor([0, 1, 0, 1, 1, 0, 0, 1, 1, 1], dtype=torch.bool, device=dev)
+    assert G[had].abs().max().item() == 0.0 and st[:rows].tolist() == [0, 0, 2, 2, 0, 0, 2, 2, 0, 0]
+    words.zero_()
+    _lib.check(lib.mmhip_adamw(_lib.ptr(p), _lib.ptr(torch.ones_like(p)), _lib.ptr(m), _lib.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, 1.0, 1, _lib.stream_ptr()))
+    assert not torch.equal(p, p0)                                      # flag down: the update runs
+    _lib.check(lib.mmhip_set_step_guard(None))
+    # ---- a whole f16 step whose backward overflows
+    cfgd = types.SimpleNamespace(batch_size=4, num_labels=3, use_clip_loss=False, beta_itc=0.1, use_tim_loss=False, beta_itm=0.1, max_length=32, dropout=0.0)
+    arch = dict(layers_txt=2, layers_img=1, vocab=300, max_pos=130)
+    tr = MMLate_Model(cfgd, "bernice", "vit", "attention", arch=arch, seed=3, dtype="f16")
+    mm = tr.model
+    ids, mask, px, oh = synthetic_batch(mm.arch["vocab"], 3, 4, 32, 7, mm.arch["txt_kind"], mm.arch["pad_id"], True, mm.arch["image"], dev)
+    tr.train_step(ids, mask, px, oh, None, 1e-3, 0.01, 1)               # a normal step: moments exist, rows are flagged
+    torch.cuda.synchronize()
+    before = (mm._flat_train.clone(), tr._opt[0].clone(), tr._opt[1].clone(), mm._word_row_state.clone())
+    mm._loss_scale = 2.0 ** 40                                          # every 16-bit gradient of the chain overflows
+    _lib.check(lib.mmhip_set_loss_scale(mm._handle, mm._loss_scale))
+    tr.train_step(ids, mask, px, oh, None, 1e-3, 0.01, 2)
+    torch.cuda.synchronize()
+    assert int(mm._nonfinite[0].item()) > 0
+    assert torch.equal(mm._flat_train, before[0]) and torch.equal(tr._opt[0], before[1]) and torch.equal(tr._opt[1], before[2])
+    assert torch.equal(mm._word_row_state, before[3]) and mm._flat_grad.abs().max().item() == 0.0
+    tr.train_step(ids, mask, px, oh, None, 1e-3, 0.01, 3)               # its entry reads the counter of step 2: the scale halves
+    assert mm._loss_scale == 2.0 ** 39
+    torch.cuda.synchronize()
+    tr._poll_guard()                                                    # step 3 overflowed as well (2^39): consume its sightings
+    assert mm._loss_scale == 2.0 ** 38
+    mm._loss_scale = 1024.0
+    _lib.check(lib.mmhip_set_loss_scale(mm._handle, mm._loss_scale))
+    torch.cuda.synchronize()
+    mid = mm._flat_train.clone()
+    tr.train_step(ids, mask, px, oh, None, 1e-3, 0.01, 4)
+    torch.cuda.synchronize()
+    assert not torch.equal(mm._flat_train, mid) and torch.isfinite(mm._flat_train).all() and mm._loss_scale == 1024.0
 
 
 @pytest.mark.parametrize("lr,wd", [(1e-3, 0.01), (1e-5, 2.5e-4)])
