@@ -33,6 +33,7 @@ step diagnostics
 cd $R
 python3 tools/vendor_gemm_bench.py > $O/vendor_gemm.txt 2>/dev/null
 VARIANTS=1,9,13,15,16,18 python3 tools/gemm8_bench.py > $O/gemm8_microbench.txt 2>/dev/null
+{ tools/pmc_clock.sh 8192 8192 8192 15 8; tools/pmc_clock.sh 16384 3072 3072 15 12; tools/pmc_clock.sh 12608 2304 768 15 30; } > $O/gemm_clock.txt 2>/dev/null
 { tools/pmc_l2.sh 12608 2304 768 15 5 cold; tools/pmc_l2.sh 12608 2304 768 1 5 cold; tools/pmc_l2.sh 8192 8192 8192 15 3; } > $O/l2_hit.txt 2>/dev/null
 { tools/ab_env.sh "BASE=1" "MMHIP_PART=0" "MMHIP_PART=128,128" "MMHIP_EARLY_ADAMW=0" "MMHIP_VIT_PRIO=0" "MMHIP_OVERLAP=0" "MMHIP_DETERMINISTIC=1"; BENCH_ARGS="--config 3" tools/ab_env.sh "BASE=1" "MMHIP_PART=0" "MMHIP_EARLY_ADAMW=0"; BENCH_ARGS="--config 4" tools/ab_env.sh "BASE=1" "MMHIP_PART=0"; } > $O/step_ab.txt 2>/dev/null
 python3 -m pytest tests/test_gpu_model.py -q -s -k "train_losses_and_grads or dropout_train_step or forward_matches or config4 or eval_loop" 2>&1 | grep -v "^$" > $O/parity.txt
