@@ -371,7 +371,7 @@ def main():
         if tj.get("csrc_sha256_16") == src_hash and args.config == 2 and not args.aux and B == 64 and world == 1 and tj.get("dtype", "bf16") == args.dtype:
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/" + tfile
             break
-    roofline = {"bound": "mfma", "kernel": "NT GEMM family (gemm_nt8i_kernel / gemm_nt8_kernel / gemm_nt_kernel, MFMA 16x16x32, LDS-DMA staged)",
+    roofline = {"bound": "mfma", "kernel": "NT GEMM family (gemm_nt8_kernel / gemm_nt_kernel, MFMA 16x16x32, LDS-DMA staged)",
                 "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4),
                 "conditions": "HIP events around every NT launch on its own stream, side streams on (as in the timed step)",
                 "achieved_serial": round(serial_tf, 1), "frac_serial": round(serial_tf / PEAK_TFLOPS, 4),

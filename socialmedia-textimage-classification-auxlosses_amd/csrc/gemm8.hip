@@ -543,7 +543,7 @@ static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
     for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / BN);
     const int cap = g.p[0].grid > 0 ? (g.p[0].grid < ntiles ? g.p[0].grid : ntiles) : 0;
     const int grid = persistent ? (cap ? cap : nt8_grid(ntiles)) : ntiles;
-    // the bias vectors live in LDS behind the K-tile buffers (nt8i_ok: they fit the CU's 160 KB)
+    // the bias vectors live in LDS behind the K-tile buffers (nt8_fits: they fit the CU's 160 KB)
     size_t lds = C::LDS;
     for (int i = 0; i < g.count; ++i) lds += (size_t)g.p[i].N * 4;
     hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI, ET>), dim3(grid), dim3(512), lds, s, g, persistent && ntiles > grid ? 1 : 0);
