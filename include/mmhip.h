@@ -273,6 +273,20 @@ int mmhip_op_self_att_block_bwd(int dtype, const void* dy, const float* maskbias
                                 int heads, float p_att, float p_hid, uint64_t seed, const void* qkv, const void* att, const float* lse, const void* pre,
                                 const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dpre, void* dd, void* datt, void* dqkv, void* dx,
                                 void* stream);
+/* cross-attention block (LXMERT cross-modality layers, reference models/mm_early.py:121-127 via HF LxmertCrossAttentionLayer): queries from
+ * xq [posts*Sq, H], keys / values from xc [posts*Sk, H];  y = LayerNorm(dropout(att Wo^T + bo) + xq).  wqkv / bqkv = the fused [Wq; Wk; Wv]
+ * [3H, H] copy and bias; keybias [posts, S] additive key mask padded with -inf past Sk, S = max(Sq, Sk).  qkv [posts*S, 3H] and att
+ * [posts*S, H] are the packed tensors the attention kernels work on (saved for the backward with lse, pre, mean, rstd); tq / attq
+ * [posts*Sq, H] (needed when Sq < S) and tkv [posts*Sk, 2H] (when Sk < S) are scratch.  Backward: dxq (incl. the residual branch), dxc;
+ * weight-gradient operands: dd / attq-or-att (Wo), dq-or-dqkv[:, :H] / xq (Wq), dkv-or-dqkv[:, H:] / xc (Wk, Wv). */
+int mmhip_op_cross_att_block_fwd(int dtype, const void* xq, const void* xc, const float* keybias, const void* wqkv, const float* bqkv, const void* wo,
+                                 const float* bo, const float* gamma, const float* beta, float eps, int posts, int Sq, int Sk, int heads, float p_att,
+                                 float p_hid, uint64_t seed, void* qkv, void* att, float* lse, void* tq, void* tkv, void* attq, void* pre, float* mean,
+                                 float* rstd, void* y, void* stream);
+int mmhip_op_cross_att_block_bwd(int dtype, const void* dy, const float* keybias, const void* wqkvT, const void* woT, const float* gamma, int posts, int Sq,
+                                 int Sk, int heads, float p_att, float p_hid, uint64_t seed, const void* qkv, const void* att, const float* lse,
+                                 const void* pre, const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dpre, void* dd, void* dattq,
+                                 void* datt, void* dqkv, void* dq, void* dkv, void* dxq, void* dxc, void* stream);
 /* feed-forward block:  y = LayerNorm(dropout(GELU(x W1^T + b1) W2^T + b2) + x); saved: h (activation), u (pre-activation), pre, mean, rstd;
  * backward: du = (dd W2) * gelu'(u), dx = du W1 + dpre; weight-gradient operands: dd / h (W2), du / x (W1). */
 int mmhip_op_ffn_block_fwd(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, const float* beta,

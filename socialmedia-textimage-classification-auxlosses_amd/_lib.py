@@ -88,6 +88,8 @@ _SIGS = {
     "mmhip_op_gemm_tn_group": (I, [I, P, I, I, P]),
     "mmhip_op_cast_group": (I, [I, P, I, P]),
     "mmhip_op_self_att_block_fwd": (I, [I, P, P, P, P, P, P, P, P, F, I, I, I, F, F, U64, P, P, P, P, P, P, P, P]),
+    "mmhip_op_cross_att_block_fwd": (I, [I, P, P, P, P, P, P, P, P, P, F, I, I, I, I, F, F, U64, P, P, P, P, P, P, P, P, P, P, P]),
+    "mmhip_op_cross_att_block_bwd": (I, [I, P, P, P, P, P, I, I, I, I, F, F, U64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "mmhip_op_self_att_block_bwd": (I, [I, P, P, P, P, P, I, I, I, F, F, U64, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "mmhip_op_ffn_block_fwd": (I, [I, P, P, P, P, P, P, P, F, I, I, I, F, U64, P, P, P, P, P, P, P]),
     "mmhip_op_ffn_block_bwd": (I, [I, P, P, P, P, I, I, I, F, U64, P, P, P, P, P, P, P, P, P, P, P]),

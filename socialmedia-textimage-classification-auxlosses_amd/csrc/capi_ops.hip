@@ -222,6 +222,126 @@ int mmhip_op_self_att_block_bwd(int dtype, const void* dy, const float* maskbias
     return 0;
 }
 
+// ---- cross-attention block (LXMERT's cross-modality layers: queries from one stream, keys / values from the other).  The attention kernels
+// take ONE packed [posts * S, 3H] tensor with S = max(Sq, Sk): row (post, i) carries query i | key i | value i.  A stream whose length is S
+// is projected straight into its columns of the packed tensor; the shorter one goes through a dense temporary and a row copy; rows past a
+// stream's length stay zero, keys past Sk are masked by the (padded) key bias, query rows past Sq are dropped.
+namespace {
+// dst[(b * rps_dst + i) * ld_dst + c] = src[(b * rps_src + i) * ld_src + c], i < L, c < W  (16-byte chunks; W * esz % 16 == 0)
+__global__ __launch_bounds__(256) void copy_post_rows_kernel(const char* __restrict__ src, size_t ld_src, int rps_src, char* __restrict__ dst, size_t ld_dst,
+                                                             int rps_dst, int posts, int L, int chunks) {
+    const size_t total = (size_t)posts * L * chunks;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % chunks);
+        const size_t r = idx / chunks;
+        const int i = (int)(r % L), b = (int)(r / L);
+        *reinterpret_cast<u32x4*>(dst + ((size_t)b * rps_dst + i) * ld_dst + (size_t)c * 16) =
+            *reinterpret_cast<const u32x4*>(src + ((size_t)b * rps_src + i) * ld_src + (size_t)c * 16);
+    }
+}
+hipError_t copy_post_rows(const void* src, size_t ld_src_bytes, int rps_src, void* dst, size_t ld_dst_bytes, int rps_dst, int posts, int L, size_t row_bytes,
+                          hipStream_t s) {
+    if (posts <= 0 || L <= 0) return hipSuccess;
+    if (row_bytes % 16 || ld_src_bytes % 16 || ld_dst_bytes % 16 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return hipErrorInvalidValue;
+    const int chunks = (int)(row_bytes / 16);
+    const size_t total = (size_t)posts * L * chunks;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(copy_post_rows_kernel, dim3(grid), dim3(256), 0, s, (const char*)src, ld_src_bytes, rps_src, (char*)dst, ld_dst_bytes, rps_dst, posts, L, chunks);
+    return hipGetLastError();
+}
+inline size_t esz_of(int dtype) { return dtype == MMHIP_F32 ? 4 : 2; }
+}  // namespace
+
+int mmhip_op_cross_att_block_fwd(int dtype, const void* xq, const void* xc, const float* keybias, const void* wqkv, const float* bqkv, const void* wo,
+                                 const float* bo, const float* gamma, const float* beta, float eps, int posts, int Sq, int Sk, int heads, float p_att,
+                                 float p_hid, uint64_t seed, void* qkv, void* att, float* lse, void* tq, void* tkv, void* attq, void* pre, float* mean,
+                                 float* rstd, void* y, void* stream) {
+    if (!xq || !xc || !keybias || !wqkv || !bqkv || !wo || !bo || !gamma || !beta || !qkv || !att || !lse || !pre || !mean || !rstd || !y || posts < 1 ||
+        Sq < 1 || Sk < 1 || heads < 1)
+        return MMHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int H = heads * 64, S = Sq > Sk ? Sq : Sk, Mq = posts * Sq, Mc = posts * Sk, M = posts * S;
+    const size_t Z = esz_of(dtype);
+    if ((Sq < S && (!tq || !attq)) || (Sk < S && !tkv)) return MMHIP_E_INVALID;
+    const char* w = (const char*)wqkv;
+    if (Sq < S || Sk < S) CHECK_HIP(hipMemsetAsync(qkv, 0, (size_t)M * 3 * H * Z, s));
+    {   // Q = xq Wq^T + bq  -> columns [0, H)
+        GemmNTArgs a = Sq == S ? nt(xq, H, w, H, qkv, 3 * H, Mq, H, H) : nt(xq, H, w, H, tq, H, Mq, H, H);
+        a.bias = bqkv; a.flags = GEMM_BIAS;
+        CHECK_HIP(launch_gemm_nt(a, dtype, s));
+        if (Sq < S) CHECK_HIP(copy_post_rows(tq, (size_t)H * Z, Sq, qkv, (size_t)3 * H * Z, S, posts, Sq, (size_t)H * Z, s));
+    }
+    {   // [K | V] = xc [Wk; Wv]^T + [bk; bv]  -> columns [H, 3H)
+        char* dst = (char*)qkv + (size_t)H * Z;
+        GemmNTArgs a = Sk == S ? nt(xc, H, w + (size_t)H * H * Z, H, dst, 3 * H, Mc, 2 * H, H) : nt(xc, H, w + (size_t)H * H * Z, H, tkv, 2 * H, Mc, 2 * H, H);
+        a.bias = bqkv + H; a.flags = GEMM_BIAS;
+        CHECK_HIP(launch_gemm_nt(a, dtype, s));
+        if (Sk < S) CHECK_HIP(copy_post_rows(tkv, (size_t)2 * H * Z, Sk, dst, (size_t)3 * H * Z, S, posts, Sk, (size_t)2 * H * Z, s));
+    }
+    AttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.qkv = qkv; at.maskbias = keybias; at.ctx = att; at.lse = lse; at.posts = posts; at.S = S; at.heads = heads;
+    at.hidden = H; at.ld_qkv = 3 * H; at.ld_ctx = H; at.scale = 0.125f; at.drop = drop_of(p_att, seed, 7);
+    CHECK_HIP(launch_attn_fwd(at, dtype, s));
+    const void* aq = att;
+    if (Sq < S) { CHECK_HIP(copy_post_rows(att, (size_t)H * Z, S, attq, (size_t)H * Z, Sq, posts, Sq, (size_t)H * Z, s)); aq = attq; }
+    { GemmNTArgs a = nt(aq, H, wo, H, pre, H, Mq, H, H); a.bias = bo; a.residual = xq; a.ldres = H; a.flags = GEMM_BIAS | GEMM_RESIDUAL;
+      if (p_hid > 0.f) { a.drop = drop_of(p_hid, seed, 8); a.flags |= GEMM_DROPOUT; }
+      CHECK_HIP(launch_gemm_nt(a, dtype, s)); }
+    LNArgs ln{pre, y, gamma, beta, mean, rstd, Mq, H, H, H, eps};
+    CHECK_HIP(launch_layernorm_fwd(ln, dtype, s));
+    return 0;
+}
+
+int mmhip_op_cross_att_block_bwd(int dtype, const void* dy, const float* keybias, const void* wqkvT, const void* woT, const float* gamma, int posts, int Sq,
+                                 int Sk, int heads, float p_att, float p_hid, uint64_t seed, const void* qkv, const void* att, const float* lse,
+                                 const void* pre, const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dpre, void* dd, void* dattq,
+                                 void* datt, void* dqkv, void* dq, void* dkv, void* dxq, void* dxc, void* stream) {
+    if (!dy || !keybias || !wqkvT || !woT || !gamma || !qkv || !att || !lse || !pre || !mean || !rstd || !dgamma || !dbeta || !dpre || !dd || !datt || !dqkv ||
+        !dxq || !dxc || posts < 1 || Sq < 1 || Sk < 1 || heads < 1)
+        return MMHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int H = heads * 64, S = Sq > Sk ? Sq : Sk, Mq = posts * Sq, Mc = posts * Sk, M = posts * S;
+    const size_t Z = esz_of(dtype);
+    if ((Sq < S && (!dattq || !dq)) || (Sk < S && !dkv)) return MMHIP_E_INVALID;
+    LNBwdArgs b;
+    memset(&b, 0, sizeof(b));
+    b.dy = dy; b.x = pre; b.gamma = gamma; b.mean = mean; b.rstd = rstd; b.dx = dpre; b.dgamma = dgamma; b.dbeta = dbeta; b.rows = Mq; b.width = H; b.alpha = 1.0f;
+    const bool dropping = p_hid > 0.f;
+    if (dropping) { b.dx_drop = dd; b.drop = drop_of(p_hid, seed, 8); b.drop_row_mul = 1; }
+    CHECK_HIP(launch_layernorm_bwd(b, dtype, s));
+    const void* dsrc = dropping ? dd : dpre;
+    if (Sq == S) {
+        GemmNTArgs a = nt(dsrc, H, woT, H, datt, H, Mq, H, H);
+        CHECK_HIP(launch_gemm_nt(a, dtype, s));
+    } else {          // the gradient of the dropped query rows is zero
+        GemmNTArgs a = nt(dsrc, H, woT, H, dattq, H, Mq, H, H);
+        CHECK_HIP(launch_gemm_nt(a, dtype, s));
+        CHECK_HIP(hipMemsetAsync(datt, 0, (size_t)M * H * Z, s));
+        CHECK_HIP(copy_post_rows(dattq, (size_t)H * Z, Sq, datt, (size_t)H * Z, S, posts, Sq, (size_t)H * Z, s));
+    }
+    AttnBwdArgs ab;
+    memset(&ab, 0, sizeof(ab));
+    ab.qkv = qkv; ab.maskbias = keybias; ab.ctx = att; ab.dctx = datt; ab.lse = lse; ab.dqkv = dqkv; ab.posts = posts; ab.S = S; ab.heads = heads;
+    ab.hidden = H; ab.ld_qkv = 3 * H; ab.ld_ctx = H; ab.scale = 0.125f; ab.drop = drop_of(p_att, seed, 7);
+    CHECK_HIP(launch_attn_bwd(ab, dtype, s));
+    const char* wt = (const char*)wqkvT;              // [H, 3H]: columns [0,H) = Wq^T, [H,3H) = [Wk; Wv]^T
+    {   // d xq = dQ Wq + d pre (residual branch)
+        const void* src = dqkv; int ld = 3 * H;
+        if (Sq < S) { CHECK_HIP(copy_post_rows(dqkv, (size_t)3 * H * Z, S, dq, (size_t)H * Z, Sq, posts, Sq, (size_t)H * Z, s)); src = dq; ld = H; }
+        GemmNTArgs a = nt(src, ld, wt, 3 * H, dxq, H, Mq, H, H);
+        a.residual = dpre; a.ldres = H; a.flags = GEMM_RESIDUAL;
+        CHECK_HIP(launch_gemm_nt(a, dtype, s));
+    }
+    {   // d xc = [dK | dV] [Wk; Wv]
+        const void* src = (const char*)dqkv + (size_t)H * Z; int ld = 3 * H;
+        if (Sk < S) { CHECK_HIP(copy_post_rows(src, (size_t)3 * H * Z, S, dkv, (size_t)2 * H * Z, Sk, posts, Sk, (size_t)2 * H * Z, s)); src = dkv; ld = 2 * H; }
+        GemmNTArgs a = nt(src, ld, wt + (size_t)H * Z, 3 * H, dxc, H, Mc, H, 2 * H);
+        CHECK_HIP(launch_gemm_nt(a, dtype, s));
+    }
+    return 0;
+}
+
 int mmhip_op_ffn_block_fwd(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, const float* beta,
                            float eps, int M, int H, int I, float p_hid, uint64_t seed, void* h, void* u, void* pre, float* mean, float* rstd, void* y,
                            void* stream) {

@@ -321,6 +321,62 @@ class _SelfAttBlock(torch.autograd.Function):
         return (dx,) + (None,) * 19
 
 
+class _CrossAttBlock(torch.autograd.Function):
+    """LayerNorm(dropout(dense(attention(queries of x, keys / values of ctx))) + x) -- a cross-modality attention block of LXMERT as ONE
+    autograd node and ONE native call per direction (mmhip_op_cross_att_block_fwd / _bwd).  Returns the block output; the gradient of
+    both inputs comes back from the one backward call."""
+
+    @staticmethod
+    def forward(ctx, x, c, keybias, wq, bq, wk, bk, wv, bv, wo, bo, g, b, posts, Sq, Sk, heads, p_att, p_hid, seed, eps, oc):
+        H = x.shape[1]
+        S = max(Sq, Sk)
+        Mq, Mc, M = posts * Sq, posts * Sk, posts * S
+        e = lambda *shape: torch.empty(*shape, dtype=oc.tdt, device=x.device)
+        f = lambda n: torch.empty(n, dtype=torch.float32, device=x.device)
+        qkv, att, pre, y, lse, mean, rstd = e(M, 3 * H), e(M, H), e(Mq, H), e(Mq, H), f(posts * heads * S), f(Mq), f(Mq)
+        tq, attq = (e(Mq, H), e(Mq, H)) if Sq < S else (None, None)
+        tkv = e(Mc, 2 * H) if Sk < S else None
+        _lib.check(_lib.lib().mmhip_op_cross_att_block_fwd(oc.code, _p(x), _p(c), _p(keybias), _p(oc.weight_cat((wq, wk, wv))), _p(oc.bias_cat((bq, bk, bv))),
+                                                           _p(oc.weight(wo)), _p(bo), _p(g), _p(b), eps, posts, Sq, Sk, heads, p_att, p_hid, seed,
+                                                           _p(qkv), _p(att), _p(lse), _p(tq), _p(tkv), _p(attq), _p(pre), _p(mean), _p(rstd), _p(y), _s()),
+                   "cross_att_block_fwd")
+        ctx.save_for_backward(x, c, keybias, qkv, att, lse, pre, mean, rstd)
+        ctx.attq = attq
+        ctx.params, ctx.cfg = (wq, bq, wk, bk, wv, bv, wo, bo, g, b), (posts, Sq, Sk, heads, p_att, p_hid, seed, oc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, c, keybias, qkv, att, lse, pre, mean, rstd = ctx.saved_tensors
+        wq, bq, wk, bk, wv, bv, wo, bo, g, b = ctx.params
+        posts, Sq, Sk, heads, p_att, p_hid, seed, oc = ctx.cfg
+        gv = oc.gview
+        H = x.shape[1]
+        S = max(Sq, Sk)
+        Mq, Mc, M = posts * Sq, posts * Sk, posts * S
+        e = lambda *shape: torch.empty(*shape, dtype=oc.tdt, device=x.device)
+        dpre, datt, dqkv, dxq, dxc = e(Mq, H), e(M, H), e(M, 3 * H), e(Mq, H), e(Mc, H)
+        dd = e(Mq, H) if p_hid > 0 else dpre
+        dattq, dq = (e(Mq, H), e(Mq, H)) if Sq < S else (None, None)
+        dkv = e(Mc, 2 * H) if Sk < S else None
+        _lib.check(_lib.lib().mmhip_op_cross_att_block_bwd(oc.code, _p(dy.contiguous()), _p(keybias), _p(oc.weight_cat((wq, wk, wv), True)), _p(oc.weight(wo, True)),
+                                                           _p(g), posts, Sq, Sk, heads, p_att, p_hid, seed, _p(qkv), _p(att), _p(lse), _p(pre), _p(mean), _p(rstd),
+                                                           _p(gv[id(g)]), _p(gv[id(b)]), _p(dpre), _p(dd), _p(dattq), _p(datt), _p(dqkv), _p(dq), _p(dkv), _p(dxq),
+                                                           _p(dxc), _s()), "cross_att_block_bwd")
+        es = dqkv.element_size()
+        oc.tn(dd, ctx.attq if Sq < S else att, gv[id(wo)], gv[id(bo)], Mq, H, H)
+        if Sq < S:
+            oc.tn(dq, x, gv[id(wq)], gv[id(bq)], Mq, H, H)
+        else:
+            oc.tn(dqkv, x, gv[id(wq)], gv[id(bq)], Mq, H, H, lda=3 * H)
+        for i, (w, bb) in enumerate(((wk, bk), (wv, bv))):
+            if Sk < S:
+                oc.tn(dkv, c, gv[id(w)], gv[id(bb)], Mc, H, H, lda=2 * H, a_ptr=dkv.data_ptr() + i * H * es)
+            else:
+                oc.tn(dqkv, c, gv[id(w)], gv[id(bb)], Mc, H, H, lda=3 * H, a_ptr=dqkv.data_ptr() + (1 + i) * H * es)
+        return (dxq, dxc) + (None,) * 20
+
+
 class _FFNBlock(torch.autograd.Function):
     """LayerNorm(dropout(W2 GELU(W1 x + b1) + b2) + x) as ONE autograd node and ONE native call per direction (mmhip_op_ffn_block_fwd / _bwd)"""
 
@@ -619,8 +675,26 @@ class Lxmert(nn.Module):
                                        P(q + "value.weight"), P(q + "value.bias"), P(n + ".output.dense.weight"), P(n + ".output.dense.bias"),
                                        P(n + ".output.LayerNorm.weight"), P(n + ".output.LayerNorm.bias"), B, Sq, a["heads"], p_att,
                                        a["p_hidden"] if self.training else 0.0, self.oc.next_seed() if self.training else 0, a["ln_eps"], self.oc)
+        if x is not ctx and os.environ.get("MMHIP_EARLY_FUSED", "1") != "0":       # cross attention: one node as well
+            P, a = self._P, self.arch
+            S = max(Sq, Sk)
+            q = f"{n}.{inner}."
+            kb = ctx_bias if Sk == S else self._padded_bias(ctx_bias, S)
+            return _CrossAttBlock.apply(x.contiguous(), ctx.contiguous(), kb.contiguous(), P(q + "query.weight"), P(q + "query.bias"), P(q + "key.weight"),
+                                        P(q + "key.bias"), P(q + "value.weight"), P(q + "value.bias"), P(n + ".output.dense.weight"), P(n + ".output.dense.bias"),
+                                        P(n + ".output.LayerNorm.weight"), P(n + ".output.LayerNorm.bias"), B, Sq, Sk, a["heads"],
+                                        a["p_attn"] if self.training else 0.0, a["p_hidden"] if self.training else 0.0,
+                                        self.oc.next_seed() if self.training else 0, a["ln_eps"], self.oc)
         a = self._attend(x, ctx, ctx_bias, f"{n}.{inner}", B, Sq, Sk)
         return self._ln(self._drop(self._lin(a, n + ".output.dense"), self.arch["p_hidden"]) + x, n + ".output.LayerNorm")
+
+    def _padded_bias(self, bias, S):
+        """[B, Sk] additive key mask -> [B, S], keys past Sk masked; one pad per mask tensor and forward (the five cross layers share it)"""
+        key = (id(bias), S)
+        hit = getattr(self, "_bias_pad", None)
+        if hit is None or hit[0] != key or hit[1] is not bias:
+            object.__setattr__(self, "_bias_pad", (key, bias, F.pad(bias, (0, S - bias.shape[1]), value=float("-inf")).contiguous()))
+        return self._bias_pad[2]
 
     def _ffn(self, i_, o_, x):
         if os.environ.get("MMHIP_EARLY_FUSED", "1") != "0":

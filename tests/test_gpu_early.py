@@ -118,6 +118,31 @@ def test_train_steps_reduce_the_loss_and_leave_the_pooler_alone():
     assert res["predictions"].shape == (8,) and np.isfinite(res["loss"]) and np.array_equal(res["labels"], onehot.argmax(1).numpy())
 
 
+def test_cross_attention_block_equals_the_unfused_operators(monkeypatch):
+    """the native cross-attention block (mmhip_op_cross_att_block_*: projections straight into the packed tensor, row copies for the
+    shorter stream) against the same layer built from single operators (MMHIP_EARLY_FUSED=0), text longer than the 36 boxes -- the
+    orientation of BASELINE config 5 (the golden vectors have the text shorter): outputs and every gradient, parity mode, dropout off"""
+    c = L.LxmertConfig(l_layers=1, r_layers=1, x_layers=2, vocab=300, max_pos=64, num_labels=3)
+    arch = dict(l_layers=1, r_layers=1, x_layers=2, vocab=300, max_pos=64, p_hidden=0.0, p_attn=0.0)
+    ids, mask, tt, feats, boxes, onehot = L.synthetic_batch(c, 5, 48, 11)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MMHIP_EARLY_FUSED", fused)
+        m = Lxmert(None, 3, dropout=0.0, arch=arch, dtype="bf16x3", seed=4)
+        m.train()
+        m.zero_grad()
+        out, et, ev, _ = m(ids, mask, tt, feats, boxes)
+        (out.square().sum() + et.square().sum() + ev.square().sum()).backward()
+        m.finish_backward()
+        torch.cuda.synchronize()
+        res[fused] = (out.detach().clone(), et.detach().clone(), ev.detach().clone(), m._flat_grad.clone())
+    for a_, b_ in zip(res["1"][:3], res["0"][:3]):
+        assert rel(a_, b_) < 1e-4
+    g1, g0 = res["1"][3], res["0"][3]
+    assert torch.isfinite(g1).all() and (g1 - g0).norm().item() / g0.norm().item() < 1e-4
+    assert rel(g1, g0) < 1e-3
+
+
 def test_cli_synthetic_run_writes_the_reference_files(tmp_path):
     """run_mm_early.py mirror on synthetic posts: metrics CSVs (reference layout), checkpoint with the reference's keys, predictions"""
     import subprocess, sys
