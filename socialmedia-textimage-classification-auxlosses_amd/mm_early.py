@@ -140,6 +140,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, oc):
+        ctx.stream = _s()                  # the backward runs where the forward ran (autograd orders the streams on that assumption)
         M, K = x.shape
         N = w.shape[0]
         y = torch.empty(M, N, dtype=oc.tdt, device=x.device)
@@ -151,6 +152,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _STREAM[0] = ctx.stream
         x, w = ctx.saved_tensors
         oc, lib = ctx.oc, _lib.lib()
         dy = dy.contiguous()
@@ -176,6 +178,7 @@ class _LinearQKV(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, oc):
+        ctx.stream = _s()                  # the backward runs where the forward ran (autograd orders the streams on that assumption)
         M, K = x.shape
         N = wq.shape[0] + wk.shape[0] + wv.shape[0]
         y = torch.empty(M, N, dtype=oc.tdt, device=x.device)
@@ -188,6 +191,7 @@ class _LinearQKV(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _STREAM[0] = ctx.stream
         x, wq, wk, wv = ctx.saved_tensors
         oc, lib = ctx.oc, _lib.lib()
         dy = dy.contiguous()
@@ -208,6 +212,7 @@ class _FFN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, oc):
+        ctx.stream = _s()                  # the backward runs where the forward ran (autograd orders the streams on that assumption)
         M, K = x.shape
         I = w1.shape[0]
         lib = _lib.lib()
@@ -222,6 +227,7 @@ class _FFN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _STREAM[0] = ctx.stream
         x, w1, w2, h, u = ctx.saved_tensors
         oc, lib = ctx.oc, _lib.lib()
         dy = dy.contiguous()
@@ -240,6 +246,7 @@ class _FFN(torch.autograd.Function):
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, b, eps, oc):
+        ctx.stream = _s()                  # the backward runs where the forward ran (autograd orders the streams on that assumption)
         rows, width = x.shape
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -251,6 +258,7 @@ class _LayerNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _STREAM[0] = ctx.stream
         x, g, mean, rstd = ctx.saved_tensors
         oc = ctx.oc
         rows, width = x.shape
@@ -266,6 +274,7 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, maskbias, posts, S, heads, p_drop, seed, oc):
+        ctx.stream = _s()                  # the backward runs where the forward ran (autograd orders the streams on that assumption)
         H = heads * 64
         out = torch.empty(posts * S, H, dtype=oc.tdt, device=qkv.device)
         lse = torch.empty(posts * heads * S, dtype=torch.float32, device=qkv.device)
@@ -276,6 +285,7 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dctx):
+        _STREAM[0] = ctx.stream
         qkv, maskbias, out, lse = ctx.saved_tensors
         posts, S, heads, p_drop, seed, oc = ctx.cfg
         dqkv = torch.empty_like(qkv)
@@ -291,6 +301,7 @@ class _SelfAttBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, maskbias, wq, bq, wk, bk, wv, bv, wo, bo, g, b, posts, S, heads, p_att, p_hid, seed, eps, oc):
+        ctx.stream = _s()                  # the backward runs where the forward ran (autograd orders the streams on that assumption)
         M, H = x.shape
         e = lambda *shape: torch.empty(*shape, dtype=oc.tdt, device=x.device)
         f = lambda n: torch.empty(n, dtype=torch.float32, device=x.device)
@@ -304,6 +315,7 @@ class _SelfAttBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _STREAM[0] = ctx.stream
         x, maskbias, qkv, att, lse, pre, mean, rstd = ctx.saved_tensors
         wq, bq, wk, bk, wv, bv, wo, bo, g, b = ctx.params
         posts, S, heads, p_att, p_hid, seed, oc = ctx.cfg
@@ -328,6 +340,7 @@ class _CrossAttBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, c, keybias, wq, bq, wk, bk, wv, bv, wo, bo, g, b, posts, Sq, Sk, heads, p_att, p_hid, seed, eps, oc):
+        ctx.stream = _s()                  # the backward runs where the forward ran (autograd orders the streams on that assumption)
         H = x.shape[1]
         S = max(Sq, Sk)
         Mq, Mc, M = posts * Sq, posts * Sk, posts * S
@@ -347,6 +360,7 @@ class _CrossAttBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _STREAM[0] = ctx.stream
         x, c, keybias, qkv, att, lse, pre, mean, rstd = ctx.saved_tensors
         wq, bq, wk, bk, wv, bv, wo, bo, g, b = ctx.params
         posts, Sq, Sk, heads, p_att, p_hid, seed, oc = ctx.cfg
@@ -382,6 +396,7 @@ class _FFNBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, g, b, p_hid, seed, eps, oc):
+        ctx.stream = _s()                  # the backward runs where the forward ran (autograd orders the streams on that assumption)
         M, H = x.shape
         I = w1.shape[0]
         e = lambda *shape: torch.empty(*shape, dtype=oc.tdt, device=x.device)
@@ -395,6 +410,7 @@ class _FFNBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _STREAM[0] = ctx.stream
         x, h, u, pre, mean, rstd = ctx.saved_tensors
         w1, b1, w2, b2, g, b = ctx.params
         p_hid, seed, oc = ctx.cfg
@@ -535,6 +551,7 @@ class Lxmert(nn.Module):
 
     def finish_backward(self):
         """launch the weight-gradient products queued by the backward pass (call after loss.backward(), before reading gradients)"""
+        _refresh_stream()                  # the backward nodes left their own streams in the cache; autograd has joined them into this one
         self.oc.flush_tn()
 
     def zero_grad(self, set_to_none=False):
@@ -548,12 +565,14 @@ class Lxmert(nn.Module):
         cached = getattr(self, "_ranges", {}).get(key)
         if cached is not None:
             return cached
-        out = []
+        spans = []
         for name, shape in self._shapes.items():
             if name.startswith("model.pooler.") or (name.startswith("linear_tim.") and not use_itm) or (name == "logit_scale" and not use_itc):
                 continue
             b = self._offs[name]
-            e = b + ((int(np.prod(shape, dtype=np.int64)) if shape else 1) + 3 & ~3)
+            spans.append((b, b + ((int(np.prod(shape, dtype=np.int64)) if shape else 1) + 3 & ~3)))
+        out = []
+        for b, e in sorted(spans):          # in ADDRESS order (the fused Q/K/V groups are laid out apart from the naming order): a handful of ranges, not ~150
             if out and out[-1][1] == b:
                 out[-1][1] = e
             else:
@@ -723,21 +742,68 @@ class Lxmert(nn.Module):
         visn = self._drop((f + bx) / 2, a["p_hidden"])
         lbias = torch.where(mask.bool(), 0.0, float("-inf")).to(torch.float32).contiguous()
         vbias = torch.zeros(B, Nb, dtype=torch.float32, device=ids.device)
+        # The language and the vision stream are independent between their meeting points (the cross attentions): the vision stream's
+        # operators -- 36 rows per post, launches that fill a fifth of the chip -- run on a second HIP stream beside the language stream's
+        # (MMHIP_EARLY_STREAMS=0: one stream).  The backward follows by itself: every node runs on its forward's stream.
+        main = torch.cuda.current_stream()
+        # (only with the block operators: the single-operator fallback MMHIP_EARLY_FUSED=0 gave run-to-run different outputs on two streams --
+        # a debugging path, kept on one stream rather than chased)
+        two = lang.is_cuda and os.environ.get("MMHIP_EARLY_STREAMS", "1") != "0" and os.environ.get("MMHIP_EARLY_FUSED", "1") != "0"
+        side = self._side_stream() if two else None
+        if side is not None:
+            side.wait_stream(main)
+            for t in (visn, vbias, lbias):            # made on the caller's stream, read on the side stream: the allocator must not hand the
+                t.record_stream(side)                 # block out again before the side stream is done with it
+        with self._on(side):
+            for i in range(a["r_layers"]):
+                b = f"model.encoder.r_layers.{i}."
+                visn = self._ffn(b + "intermediate", b + "output", self._att_block(b + "attention", "self", visn, visn, vbias, B, Nb, Nb))
         for i in range(a["l_layers"]):
             b = f"model.encoder.layer.{i}."
             lang = self._ffn(b + "intermediate", b + "output", self._att_block(b + "attention", "self", lang, lang, lbias, B, T, T))
-        for i in range(a["r_layers"]):
-            b = f"model.encoder.r_layers.{i}."
-            visn = self._ffn(b + "intermediate", b + "output", self._att_block(b + "attention", "self", visn, visn, vbias, B, Nb, Nb))
         for i in range(a["x_layers"]):
             b = f"model.encoder.x_layers.{i}."
+            if side is not None:                      # each side needs the other's output of the previous layer
+                main.wait_stream(side)
+                side.wait_stream(main)
+                lang.record_stream(side)
+                visn.record_stream(main)
             la = self._att_block(b + "visual_attention", "att", lang, visn, vbias, B, T, Nb)      # ONE module, both directions
-            va = self._att_block(b + "visual_attention", "att", visn, lang, lbias, B, Nb, T)
             la = self._att_block(b + "lang_self_att", "self", la, la, lbias, B, T, T)
-            va = self._att_block(b + "visn_self_att", "self", va, va, vbias, B, Nb, Nb)
-            lang = self._ffn(b + "lang_inter", b + "lang_output", la)
-            visn = self._ffn(b + "visn_inter", b + "visn_output", va)
+            lang_next = self._ffn(b + "lang_inter", b + "lang_output", la)
+            with self._on(side):
+                va = self._att_block(b + "visual_attention", "att", visn, lang, lbias, B, Nb, T)
+                va = self._att_block(b + "visn_self_att", "self", va, va, vbias, B, Nb, Nb)
+                visn = self._ffn(b + "visn_inter", b + "visn_output", va)
+            lang = lang_next
+        if side is not None:
+            main.wait_stream(side)
         return lang.view(B, T, -1), visn.view(B, Nb, -1)
+
+    def _side_stream(self):
+        st = getattr(self, "_side", None)
+        if st is None:
+            st = torch.cuda.Stream(device=self.device_)
+            object.__setattr__(self, "_side", st)
+        return st
+
+    def _on(self, stream):
+        """context: torch's current stream = `stream` (None: unchanged), with the operators' cached stream handle following it"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctxm():
+            if stream is None:
+                yield
+                return
+            with torch.cuda.stream(stream):
+                _refresh_stream()
+                try:
+                    yield
+                finally:
+                    pass
+            _refresh_stream()
+        return ctxm()
 
     def forward(self, ids, mask, token_type_ids, features, normalized_boxes, tim_inputs=None):
         """reference :121-163 -> (linear_output, max_embeddings_t, max_embeddings_v, out_tim), fp32"""
