@@ -1,4 +1,6 @@
 // Operator-level C entry points (parity tests call the very launchers the engine uses) and the hardware-layout probe.
+#include <map>
+#include <mutex>
 #include <cstring>
 #include <cmath>
 #include "mmhip_common.h"
@@ -85,18 +87,22 @@ int mmhip_op_probe_layouts(int32_t* out, void* stream) {
     return 0;
 }
 
-// parity mode through the op entry points: one process-wide split-plane scratch, grown on demand (hipFree waits for the device, so a
-// buffer still in use by an earlier launch is never pulled away).  The engine carves its own per-stream scratch from its workspace.
-static void* ops_x3_scratch(size_t bytes) {
-    static void* buf = nullptr;
-    static size_t cap = 0;
-    if (bytes > cap) {
-        if (buf) (void)hipFree(buf);
-        buf = nullptr; cap = 0;
-        if (hipMalloc(&buf, bytes) != hipSuccess) { buf = nullptr; return nullptr; }
-        cap = bytes;
+// parity mode through the op entry points: a split-plane scratch PER STREAM, grown on demand (hipFree waits for the device, so a buffer still
+// in use by an earlier launch is never pulled away).  One shared buffer was a race as soon as two streams ran operators side by side
+// (the early-fusion path's vision stream: run-to-run different outputs in bf16x3).  The engine carves its own per-stream scratch.
+static void* ops_x3_scratch(size_t bytes, void* stream) {
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::map<void*, Buf> bufs;
+    std::lock_guard<std::mutex> lock(mu);
+    Buf& b = bufs[stream];
+    if (bytes > b.cap) {
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr; b.cap = 0;
+        if (hipMalloc(&b.p, bytes) != hipSuccess) { b.p = nullptr; return nullptr; }
+        b.cap = bytes;
     }
-    return buf;
+    return b.p;
 }
 
 int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
@@ -120,7 +126,7 @@ int mmhip_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, 
     a.tile = force_slow >> 4;      // bits 4.. select the tile variant (test / tuning hook)
     if (dtype == MMHIP_F32 && M > 128 && !a.force_slow) {
         a.x3_ws_bytes = x3_nt_scratch_bytes(M, N, K);
-        a.x3_ws = ops_x3_scratch(a.x3_ws_bytes);
+        a.x3_ws = ops_x3_scratch(a.x3_ws_bytes, stream);
     }
     CHECK_HIP(launch_gemm_nt(a, dtype, (hipStream_t)stream));
     return 0;
@@ -131,7 +137,7 @@ int mmhip_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, 
     if (!A || !B || !C || M < 1 || Nn < 1 || Nc < 1 || (dtype != MMHIP_BF16 && dtype != MMHIP_F16 && dtype != MMHIP_F32)) return MMHIP_E_INVALID;
     GemmTNProblem p{A, B, C, M, Nn, Nc, lda, ldb, ldc, 0, colsum};
     size_t xb = dtype == MMHIP_F32 && !force_slow ? x3_tn_scratch_bytes(M, Nn, Nc) : 0;
-    void* xw = xb ? ops_x3_scratch(xb) : nullptr;
+    void* xw = xb ? ops_x3_scratch(xb, stream) : nullptr;
     CHECK_HIP(launch_gemm_tn(&p, 1, accumulate, dtype, force_slow, (hipStream_t)stream, 1.0f, xw, xw ? xb : 0));
     return 0;
 }
@@ -146,7 +152,7 @@ int mmhip_op_gemm_tn_group(int dtype, const mmhip_tn_problem* problems, int coun
     }
     size_t xb = 0;
     if (dtype == MMHIP_F32) for (int i = 0; i < count; ++i) xb += x3_tn_scratch_bytes(ps[i].M, ps[i].Nn, ps[i].Nc);
-    void* xw = xb ? ops_x3_scratch(xb) : nullptr;
+    void* xw = xb ? ops_x3_scratch(xb, stream) : nullptr;
     if (count) CHECK_HIP(launch_gemm_tn(ps.data(), count, accumulate, dtype, 0, (hipStream_t)stream, 1.0f, xw, xw ? xb : 0));
     return 0;
 }

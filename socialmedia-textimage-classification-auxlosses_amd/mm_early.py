@@ -746,9 +746,7 @@ class Lxmert(nn.Module):
         # operators -- 36 rows per post, launches that fill a fifth of the chip -- run on a second HIP stream beside the language stream's
         # (MMHIP_EARLY_STREAMS=0: one stream).  The backward follows by itself: every node runs on its forward's stream.
         main = torch.cuda.current_stream()
-        # (only with the block operators: the single-operator fallback MMHIP_EARLY_FUSED=0 gave run-to-run different outputs on two streams --
-        # a debugging path, kept on one stream rather than chased)
-        two = lang.is_cuda and os.environ.get("MMHIP_EARLY_STREAMS", "1") != "0" and os.environ.get("MMHIP_EARLY_FUSED", "1") != "0"
+        two = lang.is_cuda and os.environ.get("MMHIP_EARLY_STREAMS", "1") != "0"
         side = self._side_stream() if two else None
         if side is not None:
             side.wait_stream(main)
