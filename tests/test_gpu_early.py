@@ -118,6 +118,22 @@ def test_train_steps_reduce_the_loss_and_leave_the_pooler_alone():
     assert res["predictions"].shape == (8,) and np.isfinite(res["loss"]) and np.array_equal(res["labels"], onehot.argmax(1).numpy())
 
 
+def test_adamw_ranges_are_merged_in_address_order():
+    """the ranges AdamW runs over cover exactly the parameters that receive gradients (never the pooler; linear_tim / logit_scale by flag) and
+    are merged where adjacent in the flat buffer: a handful of launches, not one per parameter group"""
+    m = Lxmert(None, 3, dropout=0.0, arch=dict(l_layers=2, r_layers=1, x_layers=1, vocab=300, max_pos=64), dtype="bf16", seed=1)
+    for itc, itm in ((False, False), (True, True)):
+        ranges = m.grad_ranges(itc, itm)
+        assert len(ranges) <= 6 and all(b < e for b, e in ranges) and all(ranges[i][1] <= ranges[i + 1][0] for i in range(len(ranges) - 1))
+        covered = torch.zeros(m._flat.numel(), dtype=torch.bool)
+        for b, e in ranges:
+            covered[b:e] = True
+        for name, shape in m._shapes.items():
+            o, n = m._offs[name], int(np.prod(shape)) if shape else 1
+            want = not (name.startswith("model.pooler.") or (name.startswith("linear_tim.") and not itm) or (name == "logit_scale" and not itc))
+            assert bool(covered[o:o + n].all()) == want and (want or not bool(covered[o:o + n].any())), name
+
+
 def test_cross_attention_block_equals_the_unfused_operators(monkeypatch):
     """the native cross-attention block (mmhip_op_cross_att_block_*: projections straight into the packed tensor, row copies for the
     shorter stream) against the same layer built from single operators (MMHIP_EARLY_FUSED=0), text longer than the 36 boxes -- the

@@ -13,6 +13,7 @@ python3 $R/bench.py --config 4 --image 336 --no-cpu-baseline > $O/bench_cfg4_336
 python3 $R/bench.py --dtype f16 --no-cpu-baseline > $O/bench_cfg2_f16.json 2>/dev/null || exit 1
 python3 $R/bench.py --dtype bf16x3 --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_cfg2_bf16x3.json 2>/dev/null || exit 1
 python3 $R/bench.py --config 5 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null || exit 1
+python3 $R/bench.py --config 5 --aux --no-cpu-baseline > $O/bench_cfg5_aux.json 2>/dev/null || exit 1
 step kernel stats
 rocprofv3 --kernel-trace --stats -d /tmp/ks_on -o ks --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1 || exit 1
 cp $(find /tmp/ks_on -name "*kernel_stats.csv" | head -1) $O/kernel_stats_on.csv
