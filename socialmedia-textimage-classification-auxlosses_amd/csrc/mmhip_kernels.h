@@ -39,7 +39,7 @@ struct GemmNTArgs {
     float* splitk_ws;         // optional fp32 scratch [K/384][M][N]: a GEMM of <= 128 rows with K >= 1536 (the CLS-row GEMMs of the last
                               // text layer) is cut along K into slices that run side by side; a second kernel sums them and applies the epilogue
 };
-struct GemmNTPair { GemmNTArgs p[2]; int count; };      // gemm8.hip: one or two problems of equal N and K per launch
+struct GemmNTPair { GemmNTArgs p[2]; int count; int gw; };      // gw: N-tiles per column group of the tile walk (0 = 8)      // gemm8.hip: one or two problems of equal N and K per launch
 static constexpr int GEMM_TN_MAX_GROUP = 8;
 struct GemmTNProblem {
     const void* A; const void* B; float* C;
