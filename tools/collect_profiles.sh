@@ -5,6 +5,11 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O; rm -rf $O/*
 cd /tmp && export TMPDIR=/tmp
 step() { echo "== $*" >&2; }
+step pmc traffic
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_f -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_w -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
+python3 $R/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $O/gemm_traffic.json > /dev/null || exit 1
+cp $O/gemm_traffic.json $R/profiles/r03_gemm_traffic.json      # bench.py reports roofline.traffic from the profile of the same kernel sources
 step bench
 python3 $R/bench.py --steps 20 --warmup 5 --gemm-shapes $O/nt_shapes.txt > $O/bench_cfg2.json 2>$O/bench_cfg2.err || exit 1
 python3 $R/bench.py --aux --no-cpu-baseline > $O/bench_cfg3_aux.json 2>/dev/null || exit 1
@@ -23,10 +28,6 @@ rocprofv3 --kernel-trace --stats -d /tmp/ks_off -o ks --output-format csv -- pyt
 unset MMHIP_OVERLAP
 cp $(find /tmp/ks_off -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial.csv
 python3 $R/tools/hbm_table.py $O/kernel_stats_serial.csv > $O/hbm_kernels.md
-step pmc traffic
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_f -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_w -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
-python3 $R/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $O/gemm_traffic.json > /dev/null || exit 1
 step pmc mfma
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_m -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
 python3 $R/tools/pmc_mfma.py /tmp/pmc_m > $O/mfma_busy.txt
