@@ -753,8 +753,9 @@ void choose_partition(mmhip_engine& e) {
     // 32 posts of text: 12.8 vs 13.2 ms), is neutral to -3 % at config 2 (12608 image rows beside 8192 text rows: 10.24-10.30 either way on two boxes, 10.0 vs 10.3 on a third) and LOSES
     // where the text tower is the longer one (config 3, 16384 text rows with ITM: 15.95 vs 15.3 ms) -- free sharing then fills the tails of
     // the short tower's launches with the long tower's workgroups, which a fixed split forbids.
-    // (model costs, image / text: config 2 1.12, config 3 0.90, config 4 > 3)
-    if (tower(rv, Hv, Iv, c.layers_img, 256) < 1.1 * tower(rt, H, I, c.layers_txt, 256)) return;
+    // (model costs, image / text: config 2 1.12, config 3 0.90, config 4 > 3.  Config 2 stays unpartitioned: nothing to gain on three boxes of
+    // four, and a capped launch is priced against the whole chip in bench.py's roofline line; MMHIP_PART=96,160 turns it on)
+    if (tower(rv, Hv, Iv, c.layers_img, 256) < 1.3 * tower(rt, H, I, c.layers_txt, 256)) return;
     double best = 1e30; int bt = 0;
     for (int t = 32; t <= 224; t += 8) {
         const double ct = tower(rt, H, I, c.layers_txt, t), cv = tower(rv, Hv, Iv, c.layers_img, 256 - t);
