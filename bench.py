@@ -376,7 +376,7 @@ def main():
                 "conditions": "HIP events around every NT launch on its own stream, side streams on (as in the timed step)",
                 "achieved_serial": round(serial_tf, 1), "frac_serial": round(serial_tf / PEAK_TFLOPS, 4),
                 "achieved_per_cu_share": round(occ_tf, 1), "frac_per_cu_share": round(occ_tf / PEAK_TFLOPS, 4),
-                "cu_share_note": "the forward's two towers run their GEMMs as persistent launches capped at 96 / 160 workgroups (a CU partition, DESIGN.md 3): "
+                "cu_share_note": "where the engine partitions the forward (image tower much longer than the text tower: config 4; MMHIP_PART elsewhere) the towers' GEMMs are persistent launches capped at c workgroups = c CUs (DESIGN.md 7c): "
                                  "frac_per_cu_share weighs a launch's duration by the share of the chip it occupies; frac weighs every launch as if it had all 256 CUs",
                 "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                 "csrc_sha256_16": src_hash,
