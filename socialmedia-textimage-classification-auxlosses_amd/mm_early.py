@@ -811,7 +811,19 @@ class Lxmert(nn.Module):
         ids, mask = ids.to(dev), mask.to(dev)
         tt = None if token_type_ids is None else token_type_ids.to(dev)
         features, boxes = features.to(dev, torch.float32), normalized_boxes.to(dev, torch.float32)
-        x_t, x_v = self.encode(ids, mask, tt, features, boxes)
+        B = ids.shape[0]
+        x_t2 = None
+        if tim_inputs is not None and os.environ.get("MMHIP_EARLY_ITM_BATCHED", "1") != "0":
+            # ITM (reference :146-161 runs the whole encoder a second time on the swapped texts): both passes as ONE pass of 2B posts -- the same
+            # per-post arithmetic (no operator mixes posts), half the launches, twice the rows per GEMM
+            t_ids, t_mask, t_tt = tim_inputs
+            t_tt = torch.zeros_like(t_ids) if t_tt is None else t_tt
+            tt0 = torch.zeros_like(ids) if tt is None else tt
+            x_t_all, x_v_all = self.encode(torch.cat([ids, t_ids.to(dev)]), torch.cat([mask, t_mask.to(dev)]), torch.cat([tt0, t_tt.to(dev)]),
+                                           torch.cat([features, features]), torch.cat([boxes, boxes]))
+            x_t, x_v, x_t2 = x_t_all[:B], x_v_all[:B], x_t_all[B:]
+        else:
+            x_t, x_v = self.encode(ids, mask, tt, features, boxes)
         xt = torch.relu(self._lin(x_t[:, 0].contiguous(), "linear_fusion"))
         out = self._lin(self._drop(xt, self.p_head).contiguous(), "linear").float()
         last = x_t.detach().float().clone()                        # :139-143: no gradient into the text embedding
@@ -820,8 +832,9 @@ class Lxmert(nn.Module):
         emb_v = x_v.float().max(1)[0]
         out_tim = None
         if tim_inputs is not None:
-            t_ids, t_mask, t_tt = tim_inputs
-            x_t2, _ = self.encode(t_ids.to(dev), t_mask.to(dev), None if t_tt is None else t_tt.to(dev), features, boxes)
+            if x_t2 is None:
+                t_ids, t_mask, t_tt = tim_inputs
+                x_t2, _ = self.encode(t_ids.to(dev), t_mask.to(dev), None if t_tt is None else t_tt.to(dev), features, boxes)
             out_tim = self._lin(x_t2[:, 0].contiguous(), "linear_tim").float()
         return out, emb_t, emb_v, out_tim
 
