@@ -173,7 +173,7 @@ def bench_early(args):
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "BASELINE config 5: LXMERT early fusion (mm_early.py), 36 x 2048 ROI features, bs=32/GPU" + (", ITC + ITM" if args.aux else ""),
-                      "implementation": "first version: HIP operators (GEMM / LayerNorm / attention / AdamW) chained by torch autograd; launch-bound",
+                      "implementation": "HIP block operators (self-/cross-attention block, feed-forward block, grouped weight gradients, AdamW) under torch autograd, vision stream on a second HIP stream, ITM pass batched with the main pass",
                       "gf_per_post": round(gf_post, 1), "posts_per_gpu": B, "text_tokens": T, "boxes": NB, "parallelism": f"dp{world}", "weights": "random-init at true shapes"},
            "final_loss": round(float(loss), 5),
            "roofline": {"bound": "mfma", "kernel": "whole step (no per-kernel timing on this path)", "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
