@@ -23,6 +23,7 @@ GF_PER_POST = {"plain": 103.798, "aux": 171.528,
                # BASELINE config 4 (CLIP-ViT-L/14 frozen tower + Bernice, concat): 24 x (2 P (4 Hv^2 + 2 Hv Iv) + 4 P^2 Hv) + patch embed,
                # Hv = 1024, Iv = 4096, P = 257 (224 px) / 577 (336 px); + text forward 22.347 + text backward 44.695 + heads 0.01
                "clip224": 229.1, "clip336": 448.9}
+STRICT_DTYPE = "bf16x3"     # the dtype whose per-post outputs meet north_star's 1e-3: timed beside the headline as `at_tolerance`
 PEAK_TFLOPS = 2500.0        # bf16 / f16 dense MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 METRIC = {2: "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion, bs=64",                      # BASELINE.json's metric, quoted on config 2
           3: "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion + ITC+ITM, bs=64",
@@ -31,8 +32,8 @@ METRIC = {2: "posts/sec (fwd+bwd) Bernice+ViT-B/16 attn-fusion, bs=64",         
 
 
 def measure_parity(dtype):
-    """the reference's four forward goldens (tests/golden/fwd_*.npz: XLM-R, BERT, concat, full depth; vectors produced by the reference's own
-    MM_Model) through the HIP path in THIS run's dtype: max|got - ref| / max|ref| per output, worst over the goldens.  The oracle module is
+    """the reference's forward goldens (tests/golden/fwd_*.npz: XLM-R and BERT, attention and concat fusion, 2 / 6 / 12 layers, several seeds,
+    batch sizes, lengths and padding patterns; vectors produced by the reference's own MM_Model) through the HIP path in THIS run's dtype: max|got - ref| / max|ref| per output, worst over the goldens.  The oracle module is
     used as the checker only (deterministic parameter recipe + synthetic batch of the goldens)."""
     import ast
     import numpy as np
@@ -40,9 +41,12 @@ def measure_parity(dtype):
     from oracle import mm_oracle as O
     from smtc_amd.mm_late import MM_Model
     worst = {"out_cls": 0.0, "logits_per_text": 0.0, "out_tim": 0.0, "mm_features": 0.0}
-    for name, txt in (("fwd_small_xlmr", "bernice"), ("fwd_small_bert", "bert"), ("fwd_small_concat", "bernice"), ("fwd_full_xlmr", "bernice")):
-        z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False)
+    gdir = os.path.join(ROOT, "tests", "golden")
+    names = sorted(f[:-4] for f in os.listdir(gdir) if f.startswith("fwd_") and f.endswith(".npz"))      # 4 of round 1 + 9 of round 4 (fwd_x_*)
+    for name in names:
+        z = np.load(os.path.join(gdir, name + ".npz"), allow_pickle=False)
         cfg = O.OracleConfig(**ast.literal_eval(str(z["cfg"])))
+        txt = "bert" if cfg.txt_kind == "bert" else "bernice"
         B, T = int(z["B"]), int(z["T"])
         arch = dict(layers_txt=cfg.layers_txt, layers_img=cfg.layers_img, vocab=cfg.vocab, max_pos=cfg.max_pos, type_vocab=cfg.type_vocab,
                     p_hidden=cfg.p_hidden, p_attn=cfg.p_attn)
@@ -59,7 +63,7 @@ def measure_parity(dtype):
     torch.cuda.empty_cache()
     out = {k: float("%.3g" % v) for k, v in worst.items()}
     out["meets_1e-3"] = all(v < 1e-3 for v in worst.values())
-    return {"metric": "max|got-ref|/max|ref| vs the reference's fp32 golden vectors (4 forward goldens, worst), measured in this run",
+    return {"metric": "max|got-ref|/max|ref| vs the reference's fp32 golden vectors (%d forward goldens, worst), measured in this run" % len(names),
             "north_star_tolerance": 1e-3, "dtype": dtype, "measured": out,
             "note": "no single-pass 16-bit policy meets 1e-3 on all four goldens (profiles/r03_numerics_study.txt); the strict-parity dtype is bf16x3 "
                     "(python bench.py --dtype bf16x3 measures the same block at <= 2e-5)"}
@@ -201,6 +205,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="posts per GPU (default: 64; 32 for config 4)")
     ap.add_argument("--txt_model_name", default="bernice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-at-tolerance", action="store_true", help="skip the second timed loop in the strict-parity dtype")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity measurement against the reference's forward goldens")
     ap.add_argument("--gemm-shapes", default="", help="append the per-shape table of the timed NT GEMM launches to this file")
     args = ap.parse_args()
@@ -408,6 +413,38 @@ def main():
     }
     if exch is not None:
         out["exchange"] = exch
+    # ---- the same step in the dtype that meets north_star's 1e-3 on the per-post outputs, timed in THIS run (VERDICT r3 #1a): the
+    # headline dtype is the throughput mode; `at_tolerance` is the throughput that satisfies the parity bar
+    if rank == 0 and world == 1 and not args.no_at_tolerance and args.config in (2, 3):
+        if parity is not None and parity["measured"]["meets_1e-3"]:
+            out["at_tolerance"] = {"dtype": args.dtype, "ms_per_step": round(ms_step, 3), "posts_per_s": round(posts_s, 1),
+                                   "model_frac_of_peak": out["model_frac_of_peak"], "parity": parity["measured"], "meets_1e-3": True,
+                                   "note": "the headline dtype itself meets the tolerance"}
+        else:
+            del trainer, m
+            torch.cuda.empty_cache()
+            t2 = MMLate_Model(cfg, args.txt_model_name, img_name, fusion, dtype=STRICT_DTYPE, seed=0)
+            np.random.seed(30 + rank)
+            sn = 0
+            for _ in range(min(args.warmup, 3)):
+                sn += 1
+                t2.train_step(ids, mask, pixels, onehot, None, lr, wd, sn)
+            sync()
+            ks = max(3, min(args.steps, 10))
+            ta = time.perf_counter()
+            for _ in range(ks):
+                sn += 1
+                t2.train_step(ids, mask, pixels, onehot, None, lr, wd, sn)
+            sync()
+            ms2 = (time.perf_counter() - ta) / ks * 1e3
+            del t2
+            torch.cuda.empty_cache()
+            p2 = measure_parity(STRICT_DTYPE)["measured"] if not args.no_parity else None
+            out["at_tolerance"] = {"dtype": STRICT_DTYPE, "steps": ks, "ms_per_step": round(ms2, 3), "posts_per_s": round(B / (ms2 * 1e-3), 1),
+                                   "model_frac_of_peak": round(B / (ms2 * 1e-3) * GF_PER_POST[mode] / 1e3 / PEAK_TFLOPS, 4),
+                                   "slowdown_vs_headline": round(ms2 / ms_step, 2), "parity": p2,
+                                   "meets_1e-3": bool(p2 and p2["meets_1e-3"]),
+                                   "note": "same workload, same full train step, same run; the dtype whose per-post outputs meet north_star's 1e-3 against the reference's golden vectors"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

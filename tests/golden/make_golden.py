@@ -295,7 +295,36 @@ def main():
     case_forward("fwd_small_concat", small_concat, "bernice", 3, 32, 2, 13, True, ref_config, False)
     case_forward("fwd_full_xlmr", full, "bernice", 2, 128, 0, 14, True, ref_config, False)
     case_train("train_small_xlmr", small, "bernice", 4, 64, 0, 21, ref_config)
+    extra_forward_cases(ref_config)
+
+
+def extra_forward_cases(ref_config):
+    """Round 4 (VERDICT r3 #1c): nine more forward goldens -- other weight / input seeds, batch sizes, sequence lengths, padding on and
+    off, BERT and XLM-R, concat and attention fusion, 2 / 6 / 12 layers -- so that a numerics policy is judged on thirteen cases, not four.
+    `python tests/golden/make_golden.py --extra` writes only these."""
+    full = O.OracleConfig(vocab=1000, max_pos=130, num_labels=2)
+    full3 = O.OracleConfig(vocab=1000, max_pos=130, num_labels=3)
+    full_bert = O.OracleConfig(vocab=1000, max_pos=512, type_vocab=2, txt_kind="bert", pad_id=0, ln_eps_txt=1e-12, num_labels=2)
+    full_concat = O.OracleConfig(vocab=1000, max_pos=130, num_labels=4, fusion="concat")
+    mid = O.OracleConfig(layers_txt=6, layers_img=6, vocab=1000, max_pos=130, num_labels=3)
+    small = O.OracleConfig(layers_txt=2, layers_img=2, vocab=1000, max_pos=130, num_labels=3)
+    small_bert = O.OracleConfig(layers_txt=2, layers_img=2, vocab=1000, max_pos=512, type_vocab=2, txt_kind="bert",
+                                pad_id=0, ln_eps_txt=1e-12, num_labels=2)
+    case_forward("fwd_x_full_xlmr_a", full, "bernice", 2, 128, 3, 31, True, ref_config, False)
+    case_forward("fwd_x_full_xlmr_b", full3, "bernice", 3, 96, 4, 32, False, ref_config, False)
+    case_forward("fwd_x_full_xlmr_c", full3, "bernice", 4, 128, 11, 39, True, ref_config, False)
+    case_forward("fwd_x_full_bert_a", full_bert, "bert", 2, 128, 5, 33, True, ref_config, False)
+    case_forward("fwd_x_full_bert_b", full_bert, "bert", 4, 64, 6, 34, False, ref_config, False)
+    case_forward("fwd_x_full_concat", full_concat, "bernice", 3, 64, 7, 35, True, ref_config, False)
+    case_forward("fwd_x_mid_xlmr", mid, "bernice", 4, 64, 10, 38, True, ref_config, False)
+    case_forward("fwd_x_small_xlmr", small, "bernice", 8, 32, 8, 36, False, ref_config, False)
+    case_forward("fwd_x_small_bert", small_bert, "bert", 5, 48, 9, 37, True, ref_config, False)
 
 
 if __name__ == "__main__":
-    main()
+    if "--extra" in sys.argv:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        extra_forward_cases(install_shim())
+    else:
+        main()

@@ -65,11 +65,18 @@ def load_oracle_params(model, P):
     assert unexpected == [] and missing == ["dual_encoder.text_model.embeddings.position_ids"]
 
 
+# round 4: nine more reference-generated forward cases (tests/golden/make_golden.py --extra): other seeds, batch sizes, lengths, padding
+# on / off, BERT and XLM-R, concat, 2 / 6 / 12 layers -- a numerics policy is judged on thirteen goldens
+FWD_GOLDENS = ["fwd_small_xlmr", "fwd_small_bert", "fwd_small_concat", "fwd_full_xlmr",
+               "fwd_x_full_xlmr_a", "fwd_x_full_xlmr_b", "fwd_x_full_xlmr_c", "fwd_x_full_bert_a", "fwd_x_full_bert_b", "fwd_x_full_concat",
+               "fwd_x_mid_xlmr", "fwd_x_small_xlmr", "fwd_x_small_bert"]
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "bf16x3"])
-@pytest.mark.parametrize("name,txt", [("fwd_small_xlmr", "bernice"), ("fwd_small_bert", "bert"), ("fwd_small_concat", "bernice"),
-                                      ("fwd_full_xlmr", "bernice")])
-def test_forward_matches_reference_golden(name, txt, dtype):
+@pytest.mark.parametrize("name", FWD_GOLDENS)
+def test_forward_matches_reference_golden(name, dtype):
     z, cfg = load(name + ".npz")
+    txt = "bert" if cfg.txt_kind == "bert" else "bernice"
     B, T = int(z["B"]), int(z["T"])
     model = build(cfg, dtype, txt, B, T)
     load_oracle_params(model, O.make_params(cfg, int(z["seed_w"])))

@@ -25,7 +25,13 @@ def pixels_of(cfg, z):
     return O.synthetic_batch(cfg, int(z["B"]), int(z["T"]), int(z["seed_x"]), bool(z["pad"]) if "pad" in z.files else True)[2]
 
 
-@pytest.mark.parametrize("name", ["fwd_small_xlmr", "fwd_small_bert", "fwd_small_concat", "fwd_full_xlmr"])
+FWD_GOLDENS = ["fwd_small_xlmr", "fwd_small_bert", "fwd_small_concat", "fwd_full_xlmr",
+               # round 4 (make_golden.py --extra): other seeds, batch sizes, lengths, padding on / off, 2 / 6 / 12 layers
+               "fwd_x_full_xlmr_a", "fwd_x_full_xlmr_b", "fwd_x_full_xlmr_c", "fwd_x_full_bert_a", "fwd_x_full_bert_b", "fwd_x_full_concat",
+               "fwd_x_mid_xlmr", "fwd_x_small_xlmr", "fwd_x_small_bert"]
+
+
+@pytest.mark.parametrize("name", FWD_GOLDENS)
 def test_forward_matches_reference(golden_dir, name):
     z, cfg = load(golden_dir, name + ".npz")
     P = O.make_params(cfg, int(z["seed_w"]))

@@ -22,7 +22,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import mm_oracle as O  # noqa: E402
 
-GOLDENS = ["fwd_small_xlmr", "fwd_small_bert", "fwd_small_concat", "fwd_full_xlmr"]
+GOLDENS = ["fwd_small_xlmr", "fwd_small_bert", "fwd_small_concat", "fwd_full_xlmr",
+           # round 4: nine more reference-generated cases (tests/golden/make_golden.py --extra): seeds, batch sizes, lengths, padding, depth
+           "fwd_x_full_xlmr_a", "fwd_x_full_xlmr_b", "fwd_x_full_xlmr_c", "fwd_x_full_bert_a", "fwd_x_full_bert_b", "fwd_x_full_concat",
+           "fwd_x_mid_xlmr", "fwd_x_small_xlmr", "fwd_x_small_bert"]
 KEYS = ["out_cls", "logits_per_text", "out_tim", "mm_features"]
 
 POLICIES = [
@@ -40,6 +43,11 @@ POLICIES = [
     ("f16 hi+lo activations (stored fp32), f16 weights: 2 passes", dict(round_operands=None, op_a="f16x2", op_w="f16"), 2),
     ("f16 activations stored f16 except fp32 LN inputs/outputs, f16 hi+lo weights: 2 passes", dict(round_operands="f16", op_w="f16x2", st_resid=None, st_ln=None), 2),
     ("bf16x3-like: hi+lo activations AND weights (3 passes), fp32 stores", dict(round_operands=None, op_a="bf16x2", op_w="bf16x2"), 3),
+    # round 4: activations STORED as 16-bit (hi, lo) pairs -- the planes the matrix cores read, written by the producers' epilogues
+    ("f16 hi+lo activations stored as f16 pairs (22 bits), f16 weights: 2 passes", dict(round_operands=None, op_a="f16x2", op_w="f16", st_act="f16x2", st_resid="f16x2", st_ln="f16x2"), 2),
+    ("bf16 hi+lo activations stored as bf16 pairs (16 bits), bf16 hi+lo weights: 3 passes", dict(round_operands=None, op_a="bf16x2", op_w="bf16x2", st_act="bf16x2", st_resid="bf16x2", st_ln="bf16x2"), 3),
+    ("bf16 pairs for GEMM-feeding tensors only (fp32 residual stream), bf16 hi+lo weights: 3 passes", dict(round_operands=None, op_a="bf16x2", op_w="bf16x2", st_act="bf16x2", st_ln="bf16x2"), 3),
+    ("f16 hi+lo activations stored as f16 pairs, f16 hi+lo weights: 3 passes", dict(round_operands=None, op_a="f16x2", op_w="f16x2", st_act="f16x2", st_resid="f16x2", st_ln="f16x2"), 3),
 ]
 
 
@@ -51,6 +59,7 @@ def load(name):
 
 def run(policy_kwargs):
     worst = {k: 0.0 for k in KEYS}
+    run.per_golden = {}
     for name in GOLDENS:
         z, cfg = load(name)
         P = O.make_params(cfg, int(z["seed_w"]))
@@ -60,23 +69,32 @@ def run(policy_kwargs):
             out_cls, lpt, out_tim, _, feats = O.mm_forward(P, ids, mask, pixels, cfg, tim)
         for got, key in ((out_cls, "out_cls"), (lpt, "logits_per_text"), (out_tim, "out_tim"), (feats, "mm_features")):
             ref = torch.from_numpy(z[key])
-            worst[key] = max(worst[key], (got - ref).abs().max().item() / ref.abs().max().item())
+            err = (got - ref).abs().max().item() / ref.abs().max().item()
+            worst[key] = max(worst[key], err)
+            run.per_golden[name] = max(run.per_golden.get(name, 0.0), err)
     return worst
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
+    ap.add_argument("--per-golden", action="store_true", help="also print the worst output error of every golden")
+    ap.add_argument("--only", default="", help="substring filter on the policy name")
     args = ap.parse_args()
     torch.set_num_threads(min(8, os.cpu_count() or 1))
-    lines = ["# numerics study: max|got - ref| / max|ref| against the reference's fp32 golden vectors, worst of 4 forward goldens (CPU emulation)",
+    lines = ["# numerics study: max|got - ref| / max|ref| against the reference's fp32 golden vectors, worst of %d forward goldens (CPU emulation)" % len(GOLDENS),
              "# north_star tolerance: 1e-3 on every per-post output",
              "%-96s %6s %10s %10s %10s %10s  %s" % ("policy", "passes", *KEYS, "meets 1e-3")]
     for name, kw, passes in POLICIES:
+        if args.only and args.only not in name:
+            continue
         w = run(kw)
         ok = all(v < 1e-3 for v in w.values())
         lines.append("%-96s %6s %10.2e %10.2e %10.2e %10.2e  %s" % (name, passes, *(w[k] for k in KEYS), "YES" if ok else "no"))
         print(lines[-1], flush=True)
+        if args.per_golden:
+            lines.append("    per golden (worst output): " + "  ".join("%s %.1e" % (g.replace("fwd_", ""), e) for g, e in run.per_golden.items()))
+            print(lines[-1], flush=True)
     if args.out:
         with open(args.out, "w") as f:
             f.write("\n".join(lines) + "\n")
