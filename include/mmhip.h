@@ -161,8 +161,25 @@ int mmhip_set_nonfinite_counter(uint32_t* device_counter);
  * it and counts; every AdamW entry point that finds the flag set leaves parameters and moments alone and only clears the gradient,
  * so an overflowed step is skipped as a whole without the host looking (the host reads the counter a step late and lowers the
  * scale).  While armed, an f16 engine runs all its AdamW launches after the backward (no per-layer launches beside it).
- * NULL disarms.  Like the counter it is one registration per process: the model that steps claims it. */
+ * NULL disarms.  Like the counter it is one registration per process; it serves the handle-less AdamW entry points above and
+ * handles that have no guard of their own (below). */
 int mmhip_set_step_guard(uint32_t* device_words2);
+/* Per-handle guard (round 4; supersedes the process-wide registration for a model that owns a handle): the same two words
+ * {counter, flag}, registered on the handle.  mmhip_backward_begin of THIS handle clears the flag, its embedding backward raises
+ * it, and the AdamW launches inside mmhip_train_step[_dp] honour it; two models in one process (late + early fusion, or two
+ * trainers) no longer share a flag.  A caller that runs the optimizer itself (staged data-parallel step) passes the same words
+ * to mmhip_adamw_guarded / mmhip_adamw_rows_guarded (NULL = unguarded).  Under data parallelism the caller MAX-reduces word [1]
+ * of ITS handle before the optimizer so that the replicas take the same decision.
+ * What the guard guarantees: in f16 (the only dtype with a loss scale) a void step is skipped as a WHOLE -- while the guard is
+ * armed every AdamW launch of an f16 engine follows the backward.  In bf16 / bf16x3 the per-layer AdamW launches run beside the
+ * backward (before the flag can be raised), so there the guard is per element (a non-finite gradient element is read as 0 and
+ * counted) and the host raises FloatingPointError one step later: a non-finite bf16 gradient is a divergence, not an overflow. */
+int mmhip_set_guard(mmhip_handle h, uint32_t* device_words2);
+int mmhip_adamw_guarded(float* p, float* g, float* m, float* v, uint64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, int zero_grad, void* stream, uint32_t* guard_words2);
+int mmhip_adamw_rows_guarded(float* p, float* g, float* m, float* v, int rows, int width, uint8_t* row_state, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream,
+                             uint32_t* guard_words2);
 int mmhip_set_loss_scale(mmhip_handle h, float loss_scale);
 
 /* ---- one whole training step of MMLate_Model.train (models/mm_late.py:452-491: zero_grad, forward, loss mix, backward,

@@ -73,6 +73,9 @@ _SIGS = {
     "mmhip_set_row_state": (I, [P, P]),
     "mmhip_set_nonfinite_counter": (I, [P]),
     "mmhip_set_step_guard": (I, [P]),
+    "mmhip_set_guard": (I, [P, P]),
+    "mmhip_adamw_guarded": (I, [P, P, P, P, U64, F, F, F, F, F, I, F, I, P, P]),
+    "mmhip_adamw_rows_guarded": (I, [P, P, P, P, I, I, P, F, F, F, F, F, I, F, I, P, P]),
     "mmhip_set_loss_scale": (I, [P, F]),
     "mmhip_train_step": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P]),
     "mmhip_train_step_dp": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P, P, P]),

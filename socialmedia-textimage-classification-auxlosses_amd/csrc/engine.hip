@@ -58,6 +58,8 @@ struct mmhip_engine {
     size_t g_partial, g_partial_side, g_det_rows = 0;
     size_t g_lnp[2][2];      // LN-backward partials per (layer parity, LN index): reduced on the side stream with the layer's dW
     uint8_t* word_row_state = nullptr;     // caller-owned row flags of the word table (mmhip_set_row_state)
+    unsigned* guard = nullptr;             // caller-owned overflow-guard words of THIS handle, {counter, void-step flag} (mmhip_set_guard); null: the
+                                           // process-wide registration of mmhip_set_step_guard, if any
     size_t g_set[2][6];      // double-buffered backward temporaries read by the side stream: dpre2, ddrop2, du, dpre1, ddrop1, dqkv
     size_t g_dx, g_dx2, g_dpre, g_ddrop, g_dpre1, g_ddrop1, g_dqkv, g_dctx, g_du;                               // backward temporaries
     // heads (fp32) ----------------------------------------------------------------------
@@ -1006,10 +1008,13 @@ int backward_finish(mmhip_engine& e, hipStream_t s) {
     return 0;
 }
 
-// device words of the overflow guard, claimed by the model that steps (mmhip_set_step_guard / mmhip_set_nonfinite_counter): [0] counter of
-// non-finite gradient sightings, [1] "this step is void" flag raised by the backward and honoured by the AdamW kernels
+// device words of the overflow guard: [0] counter of non-finite gradient sightings, [1] "this step is void" flag raised by the backward and
+// honoured by the AdamW kernels.  Per handle (mmhip_set_guard; round 4: two models in one process no longer share a flag); the process-wide
+// pair of mmhip_set_step_guard / mmhip_set_nonfinite_counter serves the handle-less AdamW entry points and handles without a guard of their own.
 static unsigned* g_nonfinite = nullptr;
 static unsigned* g_skip = nullptr;
+inline unsigned* guard_counter(const mmhip_engine& e) { return e.guard ? e.guard : g_nonfinite; }
+inline unsigned* guard_flag(const mmhip_engine& e) { return e.guard ? e.guard + 1 : g_skip; }
 
 int embed_backward(mmhip_engine& e, hipStream_t s) {
     const mmhip_config& c = e.cfg;
@@ -1027,7 +1032,7 @@ int embed_backward(mmhip_engine& e, hipStream_t s) {
     b.alpha = 1.0f / e.gscale();
     b.row_state = e.word_row_state;
     if (deterministic()) { b.det_rows = e.wsp<float>(e.g_det_rows); b.max_pos = c.max_pos; }
-    b.status = g_skip ? g_nonfinite : nullptr;
+    b.status = guard_flag(e) ? guard_counter(e) : nullptr;
     CHECK_HIP(launch_embed_bwd(b, e.dt(), s));
     return 0;
 }
@@ -1265,10 +1270,9 @@ int mmhip_stage_grad_range(mmhip_handle h, int stage, uint64_t* begin, uint64_t*
 }
 
 int mmhip_backward_begin(mmhip_handle h, const float* d_out_cls, const float* d_logits, const float* d_out_tim, const float* d_feats, void* stream) {
-    if (g_skip) CHECK_HIP(hipMemsetAsync(g_skip, 0, 4, (hipStream_t)stream));      // the step guard's flag belongs to one backward
-    (void)stream;
     if (!h || !h->fwd_done || !h->grad) return MMHIP_E_STATE;
     mmhip_engine& e = *h;
+    if (unsigned* f = guard_flag(e)) CHECK_HIP(hipMemsetAsync(f, 0, 4, (hipStream_t)stream));      // the step guard's flag belongs to one backward
     if (d_out_cls || d_logits || d_out_tim || d_feats) {
         if (!d_out_cls) return MMHIP_E_INVALID;
         e.bd_out_cls = d_out_cls; e.bd_logits = d_logits; e.bd_out_tim = d_out_tim; e.bd_feats = d_feats;
@@ -1325,14 +1329,19 @@ int mmhip_set_step_guard(uint32_t* device_words2) {
     g_skip = device_words2 ? device_words2 + 1 : nullptr;
     return 0;
 }
+int mmhip_set_guard(mmhip_handle h, uint32_t* device_words2) {
+    if (!h || ((uintptr_t)device_words2 & 3)) return MMHIP_E_INVALID;
+    h->guard = device_words2;
+    return 0;
+}
 int mmhip_set_loss_scale(mmhip_handle h, float loss_scale) {
     if (!h || !(loss_scale >= 0.f)) return MMHIP_E_INVALID;
     h->cfg.loss_scale = loss_scale;
     return 0;
 }
 
-int mmhip_adamw(float* p, float* g, float* m, float* v, uint64_t n, float lr, float beta1, float beta2, float eps,
-                float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+static int adamw_impl(float* p, float* g, float* m, float* v, uint64_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int step, float grad_scale, int zero_grad, void* stream, unsigned* g_nonfinite, const unsigned* g_skip) {
     if (!p || !g || !m || !v || step < 1) return MMHIP_E_INVALID;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MMHIP_E_INVALID;
     AdamWArgs a;
@@ -1343,6 +1352,15 @@ int mmhip_adamw(float* p, float* g, float* m, float* v, uint64_t n, float lr, fl
     CHECK_HIP(launch_adamw(a, (hipStream_t)stream));
     return 0;
 }
+int mmhip_adamw(float* p, float* g, float* m, float* v, uint64_t n, float lr, float beta1, float beta2, float eps,
+                float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+    return adamw_impl(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, stream, g_nonfinite, g_skip);
+}
+int mmhip_adamw_guarded(float* p, float* g, float* m, float* v, uint64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, int zero_grad, void* stream, uint32_t* guard_words2) {
+    if ((uintptr_t)guard_words2 & 3) return MMHIP_E_INVALID;
+    return adamw_impl(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, stream, guard_words2, guard_words2 ? guard_words2 + 1 : nullptr);
+}
 
 int mmhip_set_row_state(mmhip_handle h, uint8_t* row_state) {
     if (!h) return MMHIP_E_INVALID;
@@ -1351,8 +1369,8 @@ int mmhip_set_row_state(mmhip_handle h, uint8_t* row_state) {
     return 0;
 }
 
-int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width, uint8_t* row_state, float lr, float beta1, float beta2,
-                     float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+static int adamw_rows_impl(float* p, float* g, float* m, float* v, int rows, int width, uint8_t* row_state, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream, unsigned* g_nonfinite, const unsigned* g_skip) {
     if (!p || !g || !m || !v || !row_state || step < 1 || rows < 0 || width <= 0 || width % 4) return MMHIP_E_INVALID;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MMHIP_E_INVALID;
     AdamWArgs a;
@@ -1362,6 +1380,16 @@ int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width
     a.zero_grad = zero_grad; a.grad_scale = grad_scale; a.nonfinite = g_nonfinite; a.skip = g_skip;
     CHECK_HIP(launch_adamw_rows(a, rows, width, row_state, (hipStream_t)stream));
     return 0;
+}
+int mmhip_adamw_rows(float* p, float* g, float* m, float* v, int rows, int width, uint8_t* row_state, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+    return adamw_rows_impl(p, g, m, v, rows, width, row_state, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, stream, g_nonfinite, g_skip);
+}
+int mmhip_adamw_rows_guarded(float* p, float* g, float* m, float* v, int rows, int width, uint8_t* row_state, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream, uint32_t* guard_words2) {
+    if ((uintptr_t)guard_words2 & 3) return MMHIP_E_INVALID;
+    return adamw_rows_impl(p, g, m, v, rows, width, row_state, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, stream, guard_words2,
+                           guard_words2 ? guard_words2 + 1 : nullptr);
 }
 
 // One fused training step, enqueued natively (no per-stage host round trips): forward (train mode) -> loss -> backward ->
@@ -1389,7 +1417,13 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
     hipStream_t s = (hipStream_t)stream;
     const char* early_env = getenv("MMHIP_EARLY_ADAMW");          // read per step: tests compare both orders in one process
     // f16 with the step guard armed: a void step is only known when the backward has reached the embeddings, so every AdamW waits for it
-    const int early = (e.dt() == DT_F16 && g_skip) ? 0 : (early_env ? atoi(early_env) : 1);
+    unsigned* gc = guard_counter(e);
+    unsigned* gf = guard_flag(e);
+    const int early = (e.dt() == DT_F16 && gf) ? 0 : (early_env ? atoi(early_env) : 1);
+    if (e.dt() == DT_F16 && gf && !early_env) {
+        static bool told = false;
+        if (!told && getenv("MMHIP_VERBOSE")) { fprintf(stderr, "[mmhip] f16 with the step guard armed: every AdamW launch follows the backward (no per-layer optimizer beside it)\n"); told = true; }
+    }
     if (int r = mmhip_backward_begin(h, nullptr, nullptr, nullptr, nullptr, stream)) return r;
     const int L = e.cfg.layers_txt;
     // data-parallel form (cb): the layer optimizers wait for the gradient exchange, so they run after it (below); the callback is told
@@ -1408,8 +1442,8 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
             const LayerOff& o = e.txt[l];
             CHECK_HIP(hipEventRecord(e.ev_layer[set], s));
             CHECK_HIP(hipStreamWaitEvent(e.side, e.ev_layer[set], 0));
-            if (int r = mmhip_adamw(e.train + o.begin, e.grad + o.begin, adam_m + o.begin, adam_v + o.begin, o.end - o.begin, lr, beta1, beta2, eps,
-                                    weight_decay, step, grad_scale, 1, e.side)) return r;
+            if (int r = adamw_impl(e.train + o.begin, e.grad + o.begin, adam_m + o.begin, adam_v + o.begin, o.end - o.begin, lr, beta1, beta2, eps,
+                                   weight_decay, step, grad_scale, 1, e.side, gc, gf)) return r;
             if (int r = refresh_layer(e, e.train, o, e.txt_w16[l], true, e.side, e.cfg.hidden, e.cfg.inter)) return r;
             CHECK_HIP(hipEventRecord(e.ev_opt, e.side));
             opt_pending = true;
@@ -1432,8 +1466,8 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
         if (!open || re <= rb) return 0;
         const uint64_t dense_end = re < w0 ? re : w0;
         if (dense_end > rb)
-            if (int r = mmhip_adamw(e.train + rb, e.grad + rb, adam_m + rb, adam_v + rb, dense_end - rb, lr, beta1, beta2, eps, weight_decay, step,
-                                    grad_scale, 1, stream)) return r;
+            if (int r = adamw_impl(e.train + rb, e.grad + rb, adam_m + rb, adam_v + rb, dense_end - rb, lr, beta1, beta2, eps, weight_decay, step,
+                                   grad_scale, 1, stream, gc, gf)) return r;
         if (re > w0) rows_due = true;          // the word table goes last: under data parallelism its rows are still travelling
         return 0;
     };
@@ -1454,8 +1488,8 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
     if (rows_due) {
         if (cb) if (int r = cb(user, MMHIP_CB_FINISH_ROWS)) return r;                 // the exchanged word rows are summed into the gradient
         if (!e.word_row_state) return MMHIP_E_STATE;
-        if (int r = mmhip_adamw_rows(e.train + w0, e.grad + w0, adam_m + w0, adam_v + w0, (int)V, (int)H, e.word_row_state, lr, beta1, beta2, eps,
-                                     weight_decay, step, grad_scale, 1, stream)) return r;
+        if (int r = adamw_rows_impl(e.train + w0, e.grad + w0, adam_m + w0, adam_v + w0, (int)V, (int)H, e.word_row_state, lr, beta1, beta2, eps,
+                                    weight_decay, step, grad_scale, 1, stream, gc, gf)) return r;
     }
     return e.span(5, s);
 }

@@ -787,7 +787,8 @@ hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate,
             else hipLaunchKernelGGL(slow_tn_kernel<f16_t>, grid, dim3(256), 0, s, P, accumulate, alpha);
             if (P.colsum) {       // generic shapes: the column sums take their own pass
                 if (accumulate != 1) { hipError_t e = hipMemsetAsync(P.colsum, 0, (size_t)P.Nn * 4, s); if (e != hipSuccess) return e; }
-                hipError_t e = launch_colsum(P.A, P.M, P.Nn, P.lda, P.colsum, dtype, s, nullptr, alpha);
+                // (colsum_rows: the parity mode's stacked [hi; lo; hi] planes count hi + lo once -- x3.hip)
+                hipError_t e = launch_colsum(P.A, P.colsum_rows > 0 ? P.colsum_rows : P.M, P.Nn, P.lda, P.colsum, dtype, s, nullptr, alpha);
                 if (e != hipSuccess) return e;
             }
         }

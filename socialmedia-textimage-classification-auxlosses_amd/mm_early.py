@@ -776,6 +776,7 @@ class Lxmert(nn.Module):
             lang = lang_next
         if side is not None:
             main.wait_stream(side)
+            visn.record_stream(main)                  # allocated on the side stream, consumed on the caller's (pooling, ITM slices)
         return lang.view(B, T, -1), visn.view(B, Nb, -1)
 
     def _side_stream(self):

@@ -204,9 +204,9 @@ class MM_Model(nn.Module):
             self._word_row_state = torch.zeros((self._word_info["shape"][0] + 3) // 4 * 4, dtype=torch.uint8, device=dev)
         _lib.check(lib.mmhip_set_row_state(h, _lib.ptr(self._word_row_state)), "set_row_state")
         if first:
-            self._nonfinite = torch.zeros(2, dtype=torch.int32, device=dev)      # include/mmhip.h mmhip_set_step_guard: {counter, void-step flag}
+            self._nonfinite = torch.zeros(2, dtype=torch.int32, device=dev)      # include/mmhip.h mmhip_set_guard: this handle's {counter, void-step flag}
             self._loss_scale = 0.0
-        _lib.check(lib.mmhip_set_step_guard(_lib.ptr(self._nonfinite)), "set_step_guard")
+        _lib.check(lib.mmhip_set_guard(h, _lib.ptr(self._nonfinite)), "set_guard")
         if self._loss_scale > 0:
             _lib.check(lib.mmhip_set_loss_scale(h, self._loss_scale), "set_loss_scale")
         self._ws = None
@@ -247,7 +247,6 @@ class MM_Model(nn.Module):
     def __del__(self):
         try:
             if self._handle is not None:
-                _lib.lib().mmhip_set_step_guard(None)
                 _lib.lib().mmhip_destroy(self._handle)
         except Exception:
             pass
@@ -505,7 +504,6 @@ class MMLate_Model(object):
         if not m.training:
             m.train()                              # walks ~370 submodules (1.3 ms of host time): only on a mode change
         m._clean_grad()                            # an autograd-path backward before this step left its gradient in the flat buffer
-        lib.mmhip_set_step_guard(_lib.ptr(m._nonfinite))     # process-wide registration: (re)claim it for the model that steps
         self._poll_guard()                                   # the counter as it stood a step ago (pinned copy, no host sync)
         try:
             return self._train_step(ids, mask, pixel_values, onehot, class_weight, lr, weight_decay, step, tim_ids, tim_mask, lbl_tim, vision_keys)
@@ -570,13 +568,16 @@ class MMLate_Model(object):
         a = m.arch
         B = B or self.batch_size
         T = T or self.max_length
+        calls, rs, trs = m._calls, np.random.get_state(), torch.get_rng_state()      # (synthetic_batch draws from torch's global generator)
         ids, mask, px, oh = synthetic_batch(a["vocab"], self.num_labels, int(B), int(T), 0, a["txt_kind"], a["pad_id"], False, a["image"], self.device)
-        calls, rs = m._calls, np.random.get_state()
         before = m._flat_train.clone()
         self.train_step(ids, mask, px, oh, None, 0.0, 0.0, 1)
         torch.cuda.synchronize(self.device)
         np.random.set_state(rs)                      # the ITM sampling drew from numpy's global stream
+        torch.set_rng_state(trs)                     # a run's shuffle order must not depend on whether it warm-started (num_workers > 0 does)
         m._calls = calls
+        m._nonfinite.zero_()                         # the throw-away step leaves no trace in the overflow guard either
+        self._nf_seen, self._nf_clean, self._nf_pending = 0, 0, False
         self._opt = None                             # the moments of the throw-away step are dropped (the next step starts from zeros)
         m._word_row_state.zero_()
         if not torch.equal(before, m._flat_train):   # lr = 0: AdamW must have left every parameter untouched
@@ -653,17 +654,20 @@ class MMLate_Model(object):
         for b, e in m.active_ranges(self.use_clip_loss, self.use_tim_loss):
             dense_end = min(e, w0)
             if dense and dense_end > b:
-                _lib.check(lib.mmhip_adamw(at(m._flat_train, b), at(m._flat_grad, b), at(em, b), at(ev, b), dense_end - b, lr, 0.9, 0.999,
-                                           1e-8, weight_decay, step, 1.0 / self.world, 1, _lib.stream_ptr()), "adamw")
+                _lib.check(lib.mmhip_adamw_guarded(at(m._flat_train, b), at(m._flat_grad, b), at(em, b), at(ev, b), dense_end - b, lr, 0.9, 0.999,
+                                                   1e-8, weight_decay, step, 1.0 / self.world, 1, _lib.stream_ptr(), _lib.ptr(m._nonfinite)), "adamw")
             if rows and e > w0:
                 # rows without gradient and without moments only decay: same values as the dense update, 1/4 of its traffic
-                _lib.check(lib.mmhip_adamw_rows(at(m._flat_train, w0), at(m._flat_grad, w0), at(em, w0), at(ev, w0), V, H,
-                                                _lib.ptr(m._word_row_state), lr, 0.9, 0.999, 1e-8, weight_decay, step,
-                                                1.0 / self.world, 1, _lib.stream_ptr()), "adamw_rows")
+                _lib.check(lib.mmhip_adamw_rows_guarded(at(m._flat_train, w0), at(m._flat_grad, w0), at(em, w0), at(ev, w0), V, H,
+                                                        _lib.ptr(m._word_row_state), lr, 0.9, 0.999, 1e-8, weight_decay, step,
+                                                        1.0 / self.world, 1, _lib.stream_ptr(), _lib.ptr(m._nonfinite)), "adamw_rows")
 
     # ---- overflow guard, host side.  The device skips a void step by itself (include/mmhip.h: mmhip_set_step_guard); the host only adapts
     # the f16 loss scale, from a pinned copy of the counter taken at the end of the previous step -- no synchronisation in the step loop.
-    GROWTH_INTERVAL = 200          # clean steps before the f16 loss scale doubles again (torch.cuda.amp.GradScaler's schedule: 2000; runs here are short)
+    # clean steps before the f16 loss scale doubles again.  torch.cuda.amp.GradScaler's default is 2000; the runs of this path are two epochs of a few
+    # hundred steps (run_mm_late.py), hence 200 -- MMHIP_SCALE_GROWTH_INTERVAL (or the attribute) restores GradScaler's schedule.  Unlike GradScaler the
+    # optimizer's step counter (bias correction) also advances on a void step: the reference's loop counts steps, not successful updates.
+    GROWTH_INTERVAL = int(os.environ.get("MMHIP_SCALE_GROWTH_INTERVAL", "200"))
     MAX_LOSS_SCALE = 65536.0
 
     def _share_guard_flag(self, exchange):

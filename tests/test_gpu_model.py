@@ -339,6 +339,7 @@ def test_adamw_guards_against_nonfinite_gradients():
     assert torch.isfinite(p).all() and torch.isfinite(m).all() and torch.isfinite(v).all() and int(cnt.item()) >= 2
     for i in (5, 1000, 4098):
         assert m[i].item() == 0.0 and v[i].item() == 0.0 and abs(p[i].item() - p0[i].item() * (1 - 1e-3 * 0.01)) < 1e-7
+    _lib.check(lib.mmhip_set_nonfinite_counter(None))          # the process-wide registration must not outlive `cnt`
     cfgd = types.SimpleNamespace(batch_size=4, num_labels=3, use_clip_loss=False, beta_itc=0.1, use_tim_loss=False, beta_itm=0.1, max_length=32, dropout=0.0)
     arch = dict(layers_txt=1, layers_img=1, vocab=300, max_pos=130)
     tr = MMLate_Model(cfgd, "bernice", "vit", "attention", arch=arch, seed=3, dtype="f16")
@@ -410,6 +411,28 @@ def test_step_guard_skips_a_void_step_as_a_whole():
     tr.train_step(ids, mask, px, oh, None, 1e-3, 0.01, 4)
     torch.cuda.synchronize()
     assert not torch.equal(mm._flat_train, mid) and torch.isfinite(mm._flat_train).all() and mm._loss_scale == 1024.0
+
+
+def test_guard_is_per_handle():
+    """include/mmhip.h mmhip_set_guard: two models in one process own separate {counter, flag} words -- an overflowing
+    f16 model must not void (or count into) the step of a second model created after it, whichever steps last"""
+    import types
+    from smtc_amd import _lib
+    dev = torch.device("cuda")
+    cfgd = types.SimpleNamespace(batch_size=4, num_labels=3, use_clip_loss=False, beta_itc=0.1, use_tim_loss=False, beta_itm=0.1, max_length=32, dropout=0.0)
+    arch = dict(layers_txt=2, layers_img=1, vocab=300, max_pos=130)
+    a = MMLate_Model(cfgd, "bernice", "vit", "attention", arch=arch, seed=3, dtype="f16")
+    b = MMLate_Model(cfgd, "bernice", "vit", "attention", arch=arch, seed=4, dtype="f16")       # created later: the old process-wide slot was its
+    ids, mask, px, oh = synthetic_batch(a.model.arch["vocab"], 3, 4, 32, 7, a.model.arch["txt_kind"], a.model.arch["pad_id"], True, a.model.arch["image"], dev)
+    a.model._loss_scale = 2.0 ** 40
+    _lib.check(_lib.lib().mmhip_set_loss_scale(a.model._handle, a.model._loss_scale))
+    pa, pb = a.model._flat_train.clone(), b.model._flat_train.clone()
+    a.train_step(ids, mask, px, oh, None, 1e-3, 0.01, 1)                # overflows: void on ITS handle
+    b.train_step(ids, mask, px, oh, None, 1e-3, 0.01, 1)                # a clean step of the other model
+    torch.cuda.synchronize()
+    assert int(a.model._nonfinite[0].item()) > 0 and int(a.model._nonfinite[1].item()) == 1
+    assert int(b.model._nonfinite[0].item()) == 0 and int(b.model._nonfinite[1].item()) == 0
+    assert torch.equal(a.model._flat_train, pa) and not torch.equal(b.model._flat_train, pb)
 
 
 @pytest.mark.parametrize("lr,wd", [(1e-3, 0.01), (1e-5, 2.5e-4)])
