@@ -45,7 +45,10 @@ typedef struct mmhip_config {
     int fusion;                          /* MMHIP_FUSION_*  (--fusion_name, models/run_mm_late.py:23) */
     float p_hidden, p_attn, p_head;      /* text hidden / attention-prob dropout, --dropout */
     int dtype;                           /* MMHIP_BF16 | MMHIP_F16: storage + MFMA operand type of activations; MMHIP_BF16X3: parity mode */
-    int max_posts, max_text_len;         /* capacity: B <= max_posts, T <= max_text_len (ITM doubles the text rows) */
+    int max_posts, max_text_len;         /* capacity: B <= max_posts, T <= max_text_len (ITM doubles the text rows).  LIMIT: max_text_len <= 128 -- the
+                                            text tower's attention backward keeps Q, dO, K of a head and a 64 x S dS tile in LDS and gives each wave one
+                                            32-key tile (S <= 128); the reference tokenises to 128 (models/config.py:60).  Image tokens (forward only):
+                                            <= 608 (CLIP-ViT-L/14 @336: 577), in every dtype since round 4. */
     float loss_scale;                    /* gradient scale inside the 16-bit text tower; 0 = default (1 for bf16, 1024 for f16:
                                             f16 has 5 exponent bits, deep-layer activation gradients ~1e-6 would be subnormal).
                                             train_grad is always in true units. */

@@ -362,6 +362,49 @@ __device__ __forceinline__ void stage_image_x3(char* hi, char* lo, const float* 
         *reinterpret_cast<bf16x8*>(lo + off) = f.lo;
     }
 }
+// the same images from a plane pair (mmhip_kernels.h): the planes are copied as they are
+__device__ __forceinline__ void stage_image_pp(char* hi, char* lo, const bf16_t* src, int ld, int lo_off, int rows_valid, int rows_pad, bool tr_layout, int tid, int nthreads) {
+    for (int idx = tid; idx < rows_pad * 8; idx += nthreads) {
+        const int row = idx >> 3, ch = idx & 7;
+        const int gr = min(row, rows_valid - 1);
+        const bf16_t* p = src + (size_t)gr * ld + ch * 8;
+        const int off = tr_layout ? trimg_off(row, ch) : rowimg_off(row, ch);
+        *reinterpret_cast<bf16x8*>(hi + off) = *reinterpret_cast<const bf16x8*>(p);
+        *reinterpret_cast<bf16x8*>(lo + off) = *reinterpret_cast<const bf16x8*>(p + lo_off);
+    }
+}
+// X = fp32 tensor or plane pair: image staging, 8-element fragments, 4-element values and stores through one interface
+template <bool PAIR> struct X3IO;
+template <> struct X3IO<false> {
+    typedef float elem;
+    static __device__ __forceinline__ void stage(char* hi, char* lo, const elem* src, int ld, int, int rv, int rp, bool tr, int tid, int nt) { stage_image_x3(hi, lo, src, ld, rv, rp, tr, tid, nt); }
+    static __device__ __forceinline__ Frag3 frag(const elem* p, int) { float v[8]; load8(p, v); return split8(v); }
+    static __device__ __forceinline__ f32x4 load4(const elem* p, int) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void store4(elem* p, int, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    static __device__ __forceinline__ void store1(elem* p, int, float v) { *p = v; }
+};
+template <> struct X3IO<true> {
+    typedef bf16_t elem;
+    static __device__ __forceinline__ void stage(char* hi, char* lo, const elem* src, int ld, int lo_off, int rv, int rp, bool tr, int tid, int nt) { stage_image_pp(hi, lo, src, ld, lo_off, rv, rp, tr, tid, nt); }
+    static __device__ __forceinline__ Frag3 frag(const elem* p, int lo_off) {
+        Frag3 f;
+        f.hi = *reinterpret_cast<const bf16x8*>(p);
+        f.lo = *reinterpret_cast<const bf16x8*>(p + lo_off);
+        return f;
+    }
+    static __device__ __forceinline__ f32x4 load4(const elem* p, int lo_off) {
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(p), l = *reinterpret_cast<const bf16x4*>(p + lo_off);
+        return f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+    }
+    static __device__ __forceinline__ void store4(elem* p, int lo_off, f32x4 v) {
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (bf16_t)v[e]; l[e] = (bf16_t)(v[e] - (float)h[e]); }
+        *reinterpret_cast<bf16x4*>(p) = h;
+        *reinterpret_cast<bf16x4*>(p + lo_off) = l;
+    }
+    static __device__ __forceinline__ void store1(elem* p, int lo_off, float v) { const bf16_t h = (bf16_t)v; p[0] = h; p[lo_off] = (bf16_t)(v - (float)h); }
+};
 __device__ __forceinline__ Frag3 lds_pair(const char* hi, const char* lo, int off) {
     Frag3 f;
     f.hi = lds_read8<bf16_t>(hi, off);
@@ -374,8 +417,10 @@ __device__ __forceinline__ Frag3 global_pair(const float* p) {
     return split8(v);
 }
 
-template <int NKT, int NW>
+template <int NKT, int NW, bool PAIR>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(AttnArgs a) {
+    typedef X3IO<PAIR> IO;
+    typedef typename IO::elem E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 32, IMG = SP * 128;
     char* Kh = smem;                         // [SP][64] row images of K (hi, lo), tr images of V (hi, lo)
@@ -386,9 +431,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int head = blockIdx.x, post = blockIdx.y;
     const int S = a.S;
-    const float* base = (const float*)a.qkv + (size_t)post * S * a.ld_qkv + head * HD;
-    stage_image_x3(Kh, Kl, base + a.hidden, a.ld_qkv, S, SP, false, tid, NW * 64);
-    stage_image_x3(Vh, Vl, base + 2 * a.hidden, a.ld_qkv, S, SP, true, tid, NW * 64);
+    const E* base = (const E*)a.qkv + (size_t)post * S * a.ld_qkv + head * HD;
+    IO::stage(Kh, Kl, base + a.hidden, a.ld_qkv, a.lo_qkv, S, SP, false, tid, NW * 64);
+    IO::stage(Vh, Vl, base + 2 * a.hidden, a.ld_qkv, a.lo_qkv, S, SP, true, tid, NW * 64);
     for (int k = tid; k < SP; k += NW * 64) {
         float b = (k < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f) : -INFINITY;
         mb[k] = b * LOG2E;
@@ -401,10 +446,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(AttnArgs a) {
     for (int qt = w; qt < nqt; qt += NW) {
         const int q = qt * 32 + r;
         const int qrow = min(q, S - 1);
-        const float* qp = base + (size_t)qrow * a.ld_qkv + 8 * h2;
+        const E* qp = base + (size_t)qrow * a.ld_qkv + 8 * h2;
         Frag3 qf[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = global_pair(qp + 16 * s);
+        for (int s = 0; s < 4; ++s) qf[s] = IO::frag(qp + 16 * s, a.lo_qkv);
         const uint32_t ebase = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)qrow) * (uint32_t)S;
         float m_run = -INFINITY, l_run = 0.f;
         f32x16 oacc[2] = {f32x16{}, f32x16{}};
@@ -468,7 +513,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(AttnArgs a) {
         if (a.lse && h2 == 0 && q < S) a.lse[((size_t)post * a.heads + head) * S + q] = (m_run + log2f(l_run)) * (1.0f / LOG2E);
         const float inv = 1.0f / l_run;
         if (q < S) {
-            float* op = (float*)a.ctx + ((size_t)post * S + q) * a.ld_ctx + head * HD;
+            E* op = (E*)a.ctx + ((size_t)post * S + q) * a.ld_ctx + head * HD;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -476,14 +521,142 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(AttnArgs a) {
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = oacc[dt][4 * g + e] * inv;
-                    *reinterpret_cast<f32x4*>(op + dt * 32 + 8 * g + 4 * h2) = o;
+                    IO::store4(op + dt * 32 + 8 * g + 4 * h2, a.lo_ctx, o);
                 }
         }
     }
 }
 
-template <int NKT>
+// Parity-mode forward for sequences whose split K / V images do not fit the CU's LDS at once (S > 288: the 577 image tokens of
+// CLIP-ViT-L/14 @336 need 4 x 608 x 128 B = 311 KB).  The keys are walked in CHUNKS of CKT x 32 (288 keys = 147 KB of images): a chunk is
+// staged once and every wave runs all its query tiles over it before the next chunk replaces it; the online soft-max state of a wave's (at
+// most QPW = 3) query tiles -- running maximum, running sum, 32 x 64 output accumulator -- stays in registers across the chunks, so the
+// result is the same online soft-max as attn_fwd_x3_kernel's, merely with two more workgroup barriers per chunk.  S <= QPW * 8 * 32 = 768.
+template <bool PAIR>
+__global__ __launch_bounds__(512) void attn_fwd_x3_long_kernel(AttnArgs a) {
+    typedef X3IO<PAIR> IO;
+    typedef typename IO::elem E;
+    constexpr int NW = 8, CKT = 9, QPW = 3, IMG = CKT * 32 * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kh = smem;
+    char* Kl = smem + IMG;
+    char* Vh = smem + 2 * IMG;
+    char* Vl = smem + 3 * IMG;
+    float* mb = reinterpret_cast<float*>(smem + 4 * IMG);          // [QPW * NW * 32] additive key bias * log2e of ALL keys
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int head = blockIdx.x, post = blockIdx.y;
+    const int S = a.S, nkt = (S + 31) / 32;
+    const E* base = (const E*)a.qkv + (size_t)post * S * a.ld_qkv + head * HD;
+    for (int k = tid; k < nkt * 32; k += NW * 64) {
+        float b = (k < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f) : -INFINITY;
+        mb[k] = b * LOG2E;
+    }
+    const int r = lane & 31, h2 = lane >> 5;
+    const float sc = a.scale * LOG2E;
+    const int nqt = a.q_tiles > 0 ? min(nkt, a.q_tiles) : nkt;
+    const bool dropping = a.drop.thresh16 != 0;
+    float m_run[QPW], l_run[QPW];
+    f32x16 oacc[QPW][2];
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) { m_run[j] = -INFINITY; l_run[j] = 0.f; oacc[j][0] = f32x16{}; oacc[j][1] = f32x16{}; }
+    for (int c0 = 0; c0 < nkt; c0 += CKT) {
+        const int ckt = min(CKT, nkt - c0), krow0 = c0 * 32;
+        __syncthreads();                                   // every wave is done with the previous chunk's images
+        IO::stage(Kh, Kl, base + a.hidden + (size_t)krow0 * a.ld_qkv, a.ld_qkv, a.lo_qkv, S - krow0, ckt * 32, false, tid, NW * 64);
+        IO::stage(Vh, Vl, base + 2 * a.hidden + (size_t)krow0 * a.ld_qkv, a.ld_qkv, a.lo_qkv, S - krow0, ckt * 32, true, tid, NW * 64);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < QPW; ++j) {
+            const int qt = w + j * NW;
+            if (qt >= nqt) continue;
+            const int qrow = min(qt * 32 + r, S - 1);
+            const E* qp = base + (size_t)qrow * a.ld_qkv + 8 * h2;
+            Frag3 qf[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[s] = IO::frag(qp + 16 * s, a.lo_qkv);
+            const uint32_t ebase = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)qrow) * (uint32_t)S;
+#pragma unroll 1
+            for (int kt = 0; kt < ckt; ++kt) {
+                f32x16 acc = f32x16{};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = mma3_32(lds_pair(Kh, Kl, rowimg_off(kt * 32 + r, 2 * s + h2)), qf[s], acc);
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 b = *reinterpret_cast<const f32x4*>(mb + krow0 + kt * 32 + 8 * g + 4 * h2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[4 * g + e] * sc + b[e];
+                        acc[4 * g + e] = v;
+                        tmax = fmaxf(tmax, v);
+                    }
+                }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                const float m_new = fmaxf(m_run[j], tmax);
+                const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = fast_exp2(m_run[j] - m_safe);
+                float psum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = fast_exp2(acc[e] - m_safe);
+                    acc[e] = p;
+                    psum += p;
+                }
+                psum += __shfl_xor(psum, 32);
+                l_run[j] = l_run[j] * alpha + psum;
+                m_run[j] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[j][dt][e] *= alpha;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float pv[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int reg = 8 * s2 + jj;
+                        float p = acc[reg];
+                        if (dropping) {
+                            const int key = krow0 + kt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+                            p = mm_keep(ebase + (uint32_t)key, a.drop) ? p * a.drop.keep_scale : 0.f;
+                        }
+                        pv[jj] = p;
+                    }
+                    const Frag3 pf = split8(pv);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        Frag3 vf;
+                        vf.hi = tr_frag_acc_order<bf16_t>(Vh, kt * 32 + 16 * s2, dt * 32, lane);
+                        vf.lo = tr_frag_acc_order<bf16_t>(Vl, kt * 32 + 16 * s2, dt * 32, lane);
+                        oacc[j][dt] = mma3_32(vf, pf, oacc[j][dt]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+        const int qt = w + j * NW, q = qt * 32 + r;
+        if (qt >= nqt || q >= S) continue;
+        if (a.lse && h2 == 0) a.lse[((size_t)post * a.heads + head) * S + q] = (m_run[j] + log2f(l_run[j])) * (1.0f / LOG2E);
+        const float inv = 1.0f / l_run[j];
+        E* op = (E*)a.ctx + ((size_t)post * S + q) * a.ld_ctx + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = oacc[j][dt][4 * g + e] * inv;
+                IO::store4(op + dt * 32 + 8 * g + 4 * h2, a.lo_ctx, o);
+            }
+    }
+}
+
+template <int NKT, bool PAIR>
 __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
+    typedef X3IO<PAIR> IO;
+    typedef typename IO::elem E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NKT * 32, IMG = SP * 128, DSI = 64 * SP * 2;
     constexpr int SPC = SP / 8;
@@ -501,22 +674,22 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
     const int head = blockIdx.x, post = blockIdx.y;
     const int S = a.S;
     const size_t row0 = (size_t)post * S;
-    const float* qb = (const float*)a.qkv + row0 * a.ld_qkv + head * HD;
-    const float* kb = qb + a.hidden;
-    const float* vb = qb + 2 * a.hidden;
-    const float* dob = (const float*)a.dctx + row0 * a.ld_ctx + head * HD;
-    const float* ob = (const float*)a.ctx + row0 * a.ld_ctx + head * HD;
-    stage_image_x3(Qh, Ql, qb, a.ld_qkv, S, SP, true, tid, 256);
-    stage_image_x3(dOh, dOl, dob, a.ld_ctx, S, SP, true, tid, 256);
-    stage_image_x3(Kh, Kl, kb, a.ld_qkv, S, SP, true, tid, 256);
+    const E* qb = (const E*)a.qkv + row0 * a.ld_qkv + head * HD;
+    const E* kb = qb + a.hidden;
+    const E* vb = qb + 2 * a.hidden;
+    const E* dob = (const E*)a.dctx + row0 * a.ld_ctx + head * HD;
+    const E* ob = (const E*)a.ctx + row0 * a.ld_ctx + head * HD;
+    IO::stage(Qh, Ql, qb, a.ld_qkv, a.lo_qkv, S, SP, true, tid, 256);
+    IO::stage(dOh, dOl, dob, a.ld_ctx, a.lo_ctx, S, SP, true, tid, 256);
+    IO::stage(Kh, Kl, kb, a.ld_qkv, a.lo_qkv, S, SP, true, tid, 256);
     for (int q = tid; q < SP; q += 256) {
         float d = 0.f, l = 0.f;
         if (q < S) {
-            const float* o = ob + (size_t)q * a.ld_ctx;
-            const float* g = dob + (size_t)q * a.ld_ctx;
+            const E* o = ob + (size_t)q * a.ld_ctx;
+            const E* g = dob + (size_t)q * a.ld_ctx;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const f32x4 ov = *reinterpret_cast<const f32x4*>(o + c * 4), gv = *reinterpret_cast<const f32x4*>(g + c * 4);
+                const f32x4 ov = IO::load4(o + c * 4, a.lo_ctx), gv = IO::load4(g + c * 4, a.lo_ctx);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d += ov[e] * gv[e];
             }
@@ -534,8 +707,8 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
     if (has_keys) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            kf[s] = global_pair(kb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2);
-            vf[s] = global_pair(vb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2);
+            kf[s] = IO::frag(kb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2, a.lo_qkv);
+            vf[s] = IO::frag(vb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2, a.lo_qkv);
         }
         mbk = (key < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + key] : 0.f) : -INFINITY;
         mbk *= LOG2E;
@@ -617,19 +790,19 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
                     ktf.lo = tr_frag_natural<bf16_t>(Kl, ks * 16, dt * 32, lane);
                     dq = mma3_32(lds_pair(dSh, dSl, ds_off(qi * 32 + r, 2 * ks + h2, SPC)), ktf, dq);
                 }
-                float* dqp = (float*)a.dqkv + row0 * a.ld_qkv + head * HD + dt * 32 + r;
+                E* dqp = (E*)a.dqkv + row0 * a.ld_qkv + head * HD + dt * 32 + r;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int q = qt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-                    if (q < S) dqp[(size_t)q * a.ld_qkv] = dq[reg];
+                    if (q < S) IO::store1(dqp + (size_t)q * a.ld_qkv, a.lo_qkv, dq[reg]);
                 }
             }
         }
         __syncthreads();
     }
     if (has_keys && key < S) {
-        float* dkp = (float*)a.dqkv + (row0 + key) * a.ld_qkv + a.hidden + head * HD;
-        float* dvp = dkp + a.hidden;
+        E* dkp = (E*)a.dqkv + (row0 + key) * a.ld_qkv + a.hidden + head * HD;
+        E* dvp = dkp + a.hidden;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -637,8 +810,8 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
                 f32x4 o1, o2;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { o1[e] = dk[dt][4 * g + e]; o2[e] = dv[dt][4 * g + e]; }
-                *reinterpret_cast<f32x4*>(dkp + dt * 32 + 8 * g + 4 * h2) = o1;
-                *reinterpret_cast<f32x4*>(dvp + dt * 32 + 8 * g + 4 * h2) = o2;
+                IO::store4(dkp + dt * 32 + 8 * g + 4 * h2, a.lo_qkv, o1);
+                IO::store4(dvp + dt * 32 + 8 * g + 4 * h2, a.lo_qkv, o2);
             }
     }
 }
@@ -668,12 +841,17 @@ static hipError_t launch_fwd_d(const AttnArgs& a, hipStream_t s) {
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-template <int NKT, int NW>
-static void launch_fwd_x3_t(const AttnArgs& a, hipStream_t s) {
+template <int NKT, int NW, bool PAIR>
+static void launch_fwd_x3_tp(const AttnArgs& a, hipStream_t s) {
     const int lds = 4 * NKT * 32 * 128 + NKT * 32 * 4;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)attn_fwd_x3_kernel<NKT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
-    hipLaunchKernelGGL((attn_fwd_x3_kernel<NKT, NW>), dim3(a.heads, a.posts), dim3(NW * 64), lds, s, a);
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn_fwd_x3_kernel<NKT, NW, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+    hipLaunchKernelGGL((attn_fwd_x3_kernel<NKT, NW, PAIR>), dim3(a.heads, a.posts), dim3(NW * 64), lds, s, a);
+}
+template <int NKT, int NW>
+static void launch_fwd_x3_t(const AttnArgs& a, hipStream_t s) {
+    if (a.pair) launch_fwd_x3_tp<NKT, NW, true>(a, s);
+    else launch_fwd_x3_tp<NKT, NW, false>(a, s);
 }
 static bool x3_mfma_attention() {
     static int on = -1;
@@ -683,8 +861,24 @@ static bool x3_mfma_attention() {
 hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s) {
     if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1) return hipErrorInvalidValue;
     if (dtype == DT_F32) {
-        // parity mode: split operands on the matrix cores while two 16-bit images per tensor fit the CU's LDS (S <= 288: 148 KB), else fp32 ALUs
-        if (!x3_mfma_attention() || a.S > 288 || ((uintptr_t)a.qkv & 15) || ((uintptr_t)a.ctx & 15)) return launch_attn_fwd_f32(a, s);
+        // parity mode: split operands on the matrix cores; two 16-bit images per tensor fit the CU's LDS up to S = 288 (148 KB), longer
+        // sequences (up to 768) walk the keys in LDS-sized chunks (attn_fwd_x3_long_kernel); MMHIP_X3_FAST=0: fp32 on the vector ALUs
+        if (!x3_mfma_attention() || ((uintptr_t)a.qkv & 15) || ((uintptr_t)a.ctx & 15) || a.S > 768) {
+            if (a.pair) return hipErrorInvalidValue;          // the fp32 ALU kernels read fp32 tensors only
+            return launch_attn_fwd_f32(a, s);
+        }
+        if (a.S > 288) {
+            const int lds = 4 * 9 * 32 * 128 + 768 * 4;
+            static bool done[2] = {false, false};
+            if (a.pair) {
+                if (!done[1]) { (void)hipFuncSetAttribute((const void*)attn_fwd_x3_long_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done[1] = true; }
+                hipLaunchKernelGGL((attn_fwd_x3_long_kernel<true>), dim3(a.heads, a.posts), dim3(512), lds, s, a);
+            } else {
+                if (!done[0]) { (void)hipFuncSetAttribute((const void*)attn_fwd_x3_long_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done[0] = true; }
+                hipLaunchKernelGGL((attn_fwd_x3_long_kernel<false>), dim3(a.heads, a.posts), dim3(512), lds, s, a);
+            }
+            return hipGetLastError();
+        }
         if (a.S <= 32) launch_fwd_x3_t<1, 1>(a, s);
         else if (a.S <= 64) launch_fwd_x3_t<2, 2>(a, s);
         else if (a.S <= 128) launch_fwd_x3_t<4, 4>(a, s);
@@ -714,18 +908,26 @@ static hipError_t launch_bwd_d(const AttnBwdArgs& a, hipStream_t s) {
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-template <int NKT>
-static void launch_bwd_x3_t(const AttnBwdArgs& a, hipStream_t s) {
+template <int NKT, bool PAIR>
+static void launch_bwd_x3_tp(const AttnBwdArgs& a, hipStream_t s) {
     const int lds = 6 * NKT * 32 * 128 + 2 * 64 * NKT * 32 * 2 + 2 * NKT * 32 * 4;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)attn_bwd_x3_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
-    hipLaunchKernelGGL((attn_bwd_x3_kernel<NKT>), dim3(a.heads, a.posts), dim3(256), lds, s, a);
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn_bwd_x3_kernel<NKT, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+    hipLaunchKernelGGL((attn_bwd_x3_kernel<NKT, PAIR>), dim3(a.heads, a.posts), dim3(256), lds, s, a);
+}
+template <int NKT>
+static void launch_bwd_x3_t(const AttnBwdArgs& a, hipStream_t s) {
+    if (a.pair) launch_bwd_x3_tp<NKT, true>(a, s);
+    else launch_bwd_x3_tp<NKT, false>(a, s);
 }
 hipError_t launch_attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t s) {
     if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1) return hipErrorInvalidValue;
     if (dtype == DT_F32) {
         auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-        if (!x3_mfma_attention() || a.S > 128 || !al(a.qkv) || !al(a.ctx) || !al(a.dctx) || !al(a.dqkv)) return launch_attn_bwd_f32(a, s);
+        if (!x3_mfma_attention() || a.S > 128 || !al(a.qkv) || !al(a.ctx) || !al(a.dctx) || !al(a.dqkv)) {
+            if (a.pair) return hipErrorInvalidValue;
+            return launch_attn_bwd_f32(a, s);
+        }
         if (a.S <= 32) launch_bwd_x3_t<1>(a, s);
         else if (a.S <= 64) launch_bwd_x3_t<2>(a, s);
         else launch_bwd_x3_t<4>(a, s);

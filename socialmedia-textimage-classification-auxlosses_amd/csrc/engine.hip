@@ -23,6 +23,7 @@ struct LayerW16 {   // 16-bit GEMM operand copies (byte offsets into the workspa
 };
 struct TextAct {    // saved activations of one text layer (byte offsets into the workspace)
     size_t qkv, ctx, pre1, a1, u, h, pre2, out, mean1, rstd1, mean2, rstd2, lse;
+    size_t a1p, outp;      // parity mode with plane pairs: the LayerNorm outputs once more as pairs (the fp32 forms stay the residual inputs)
 };
 struct Stream16 { size_t off; };
 
@@ -53,7 +54,13 @@ struct mmhip_engine {
     size_t x3_ws[3] = {0, 0, 0}, x3_bytes[3] = {0, 0, 0};      // parity mode: split-plane scratch of the caller's stream | side stream | image-tower stream
     size_t patch_w16;
     std::vector<TextAct> tact;
-    size_t ids_all, mask_all, pos_ids, maskbias, x0, xhat_emb, rstd_emb;
+    size_t ids_all, mask_all, pos_ids, maskbias, x0, xhat_emb, rstd_emb, x0p = 0;
+    // Parity mode (bf16x3), round 4: every tensor that feeds a matrix product is written by its producer as a PLANE PAIR (mmhip_kernels.h) and the
+    // GEMMs read the planes directly (MMHIP_X3_PAIRS=0 at mmhip_create: round 3's form -- fp32 tensors, split into scratch copies per call).
+    // Pairs: weights' operand copies, qkv, ctx, FC1 output h, the LayerNorm outputs (beside their fp32 forms), the image tower's LN output /
+    // qkv / ctx / h / patches, and in the backward du, dqkv, d ctx and the LayerNorm-backward outputs the GEMMs read.  fp32: the residual
+    // stream (pre1, pre2, x, d pre, dx), the GELU stash u, everything the heads touch.
+    bool px = false;
     size_t v_patches, v_pe, v_x, v_ln, v_qkv, v_ctx, v_h, v_out;                             // ViT ping-pong
     size_t g_partial, g_partial_side, g_det_rows = 0;
     size_t g_lnp[2][2];      // LN-backward partials per (layer parity, LN index): reduced on the side stream with the layer's dW
@@ -318,8 +325,11 @@ void build_workspace(mmhip_engine& e) {
     e.patch_w16 = w.take(Hv * Kpp * Z);
     e.ids_all = w.take(Bt * Tm * 8); e.mask_all = w.take(Bt * Tm * 8); e.pos_ids = w.take(Bt * Tm * 4); e.maskbias = w.take(Bt * Tm * 4);
     e.x0 = w.take(Mt * H * Z); e.xhat_emb = w.take(Mt * H * Z); e.rstd_emb = w.take(Mt * 4);
+    if (e.px) e.x0p = w.take(Mt * H * Z);
     e.tact.resize(c.layers_txt);
     for (auto& a : e.tact) {
+        a.a1p = a.outp = 0;
+        if (e.px) { a.a1p = w.take(Mt * H * Z); a.outp = w.take(Mt * H * Z); }
         a.qkv = w.take(Mt * 3 * H * Z); a.ctx = w.take(Mt * H * Z); a.pre1 = w.take(Mt * H * Z); a.a1 = w.take(Mt * H * Z);
         a.u = w.take(Mt * I * Z); a.h = w.take(Mt * I * Z); a.pre2 = w.take(Mt * H * Z); a.out = w.take(Mt * H * Z);
         a.mean1 = w.take(Mt * 4); a.rstd1 = w.take(Mt * 4); a.mean2 = w.take(Mt * 4); a.rstd2 = w.take(Mt * 4);
@@ -350,7 +360,7 @@ void build_workspace(mmhip_engine& e) {
     e.h_featd = f(Bm * H); e.h_out_cls = f(Bm * C); e.h_out_tim = f(Bm * 2);
     e.splitk_ws = f((size_t)(I / 384 + 1) * 128 * (size_t)(I > 3 * H ? I : 3 * H)); e.has_splitk = true;
     e.splitk_ws_vit = f((size_t)(Iv / 384 + 1) * 128 * (size_t)(Iv > 3 * Hv ? Iv : 3 * Hv));
-    if (c.dtype == MMHIP_BF16X3) {
+    if (c.dtype == MMHIP_BF16X3 && !e.px) {
         // split planes of the operands of one GEMM call at a time per stream (x3.hip): the widest NT problem of a tower, or the four
         // weight-gradient problems of a text layer together
         auto nt = [](size_t M, size_t H, size_t I) {
@@ -403,6 +413,10 @@ struct G {
     G& residual(const void* p, int ld) { a.residual = p; a.ldres = ld; a.flags |= GEMM_RESIDUAL; return *this; }
     G& mul_gelu_grad(const void* p, int ld) { a.mul_in = p; a.ldmul = ld; a.flags |= GEMM_MUL_GELU_GRAD; return *this; }
     G& dropout(const DropCfg& d, int row_mul = 1) { a.drop = d; a.drop_row_mul = row_mul; if (d.thresh16) a.flags |= GEMM_DROPOUT; return *this; }
+    // parity mode with plane pairs: both operands are pairs whose rows hold [hi(W) | lo(W)] -- the leading dimensions given in logical
+    // elements double, the lo planes sit K elements behind; px_out: C as a pair, rows [hi(N) | lo(N)]
+    G& px_in(bool px) { if (px) { a.a_pair = a.b_pair = 1; a.lda *= 2; a.ldb *= 2; a.a_lo = a.b_lo = a.K; } return *this; }
+    G& px_out(bool px) { if (px) { a.flags |= GEMM_OUT_PAIR; a.ldc *= 2; a.c_lo = a.N; } return *this; }
 };
 // forward GEMM of tower `which` (0 text, 1 image) under the CU partition: persistent 256 x 256 tiles on at most cur_part[which] workgroups
 inline void part_gemm(const mmhip_engine& e, G& g, int which) {
@@ -505,7 +519,7 @@ int refresh_layer(mmhip_engine& e, const float* base, const LayerOff& o, const L
                     {base + o.ao_w, e.ws + w.ao, transposed ? e.ws + w.aoT : nullptr, H, H, 0},
                     {base + o.fc1_w, e.ws + w.fc1, transposed ? e.ws + w.fc1T : nullptr, I, H, 0},
                     {base + o.fc2_w, e.ws + w.fc2, transposed ? e.ws + w.fc2T : nullptr, H, I, 0}};
-    CHECK_HIP(launch_cast_group(m, 4, e.dt(), s));
+    CHECK_HIP(launch_cast_group(m, 4, e.px ? DT_PAIR : e.dt(), s));
     return 0;
 }
 
@@ -516,10 +530,15 @@ int vit_forward(mmhip_engine& e, const float* pixels, hipStream_t s) {
     const int Mv = B * P;
     const bool clip = e.clip();
     const float* F = e.frozen;
-    CHECK_HIP(launch_patchify(pixels, e.ws + e.v_patches, B, c.image, c.patch, Kpp, dt, s));
+    const bool px = e.px;
+    auto ln_to = [&](LNArgs& ln, size_t pair_buf, int W) {          // parity mode: a LayerNorm output that only GEMMs read goes out as a plane pair only
+        if (px) { ln.y = nullptr; ln.y_pair = e.ws + pair_buf; ln.ld_pair = 2 * W; ln.lo_pair = W; }
+    };
+    CHECK_HIP(launch_patchify(pixels, e.ws + e.v_patches, B, c.image, c.patch, Kpp, px ? DT_PAIR : dt, s));
     {
         G g(e.ws + e.v_patches, Kpp, e.ws + e.patch_w16, Kpp, e.ws + e.v_pe, H, B * (P - 1), H, Kpp);
         if (!clip) g.bias(F + e.v_patch_b);           // CLIP's patch conv has no bias
+        g.px_in(px);
         part_gemm(e, g, 1);
         if (int r = run_gemm(e, g, s)) return r;
     }
@@ -533,18 +552,21 @@ int vit_forward(mmhip_engine& e, const float* pixels, hipStream_t s) {
         const LayerOff& o = e.vit[l];
         const LayerW16& w = e.vit_w16[l];
         LNArgs ln{x, e.ws + e.v_ln, F + o.ln1_w, F + o.ln1_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+        ln_to(ln, e.v_ln, H);
         CHECK_HIP(launch_layernorm_fwd(ln, dt, s));
-        { G g(e.ws + e.v_ln, H, e.ws + w.qkv, H, e.ws + e.v_qkv, 3 * H, Mv, 3 * H, H); g.bias(F + o.qkv_b); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_ln, H, e.ws + w.qkv, H, e.ws + e.v_qkv, 3 * H, Mv, 3 * H, H); g.bias(F + o.qkv_b).px_in(px).px_out(px); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
         AttnArgs at;
         memset(&at, 0, sizeof(at));
         at.qkv = e.ws + e.v_qkv; at.ctx = e.ws + e.v_ctx; at.posts = B; at.S = P; at.heads = e.heads_v(); at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
+        if (px) { at.pair = 1; at.ld_qkv = 6 * H; at.lo_qkv = 3 * H; at.ld_ctx = 2 * H; at.lo_ctx = H; }
         at.scale = 1.0f / sqrtf((float)(H / e.heads_v()));
         CHECK_HIP(launch_attn_fwd(at, dt, s));
-        { G g(e.ws + e.v_ctx, H, e.ws + w.ao, H, x, H, Mv, H, H); g.bias(F + o.ao_b).residual(x, H); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_ctx, H, e.ws + w.ao, H, x, H, Mv, H, H); g.bias(F + o.ao_b).residual(x, H).px_in(px); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
         LNArgs ln2{x, e.ws + e.v_ln, F + o.ln2_w, F + o.ln2_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+        ln_to(ln2, e.v_ln, H);
         CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
-        { G g(e.ws + e.v_ln, H, e.ws + w.fc1, H, e.ws + e.v_h, I, Mv, I, H); g.bias(F + o.fc1_b); if (clip) g.qgelu(); else g.gelu(); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
-        { G g(e.ws + e.v_h, I, e.ws + w.fc2, I, x, H, Mv, H, I); g.bias(F + o.fc2_b).residual(x, H); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_ln, H, e.ws + w.fc1, H, e.ws + e.v_h, I, Mv, I, H); g.bias(F + o.fc1_b); if (clip) g.qgelu(); else g.gelu(); g.px_in(px).px_out(px); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + e.v_h, I, e.ws + w.fc2, I, x, H, Mv, H, I); g.bias(F + o.fc2_b).residual(x, H).px_in(px); part_gemm(e, g, 1); if (int r = run_gemm(e, g, s)) return r; }
     }
     if (clip) {
         // last_hidden_state = the encoder output as it is; pooler_output = post_layernorm(CLS row)   (CLIPVisionTransformer.forward)
@@ -575,15 +597,18 @@ int text_forward(mmhip_engine& e, hipStream_t s) {
     ea.maskbias = e.wsp<float>(e.maskbias);
     ea.posts = Bt; ea.T = T; ea.H = H; ea.xlmr = c.txt_kind == MMHIP_TXT_XLMR; ea.pad_id = c.pad_id; ea.eps = c.ln_eps_txt;
     ea.drop = make_drop(c.p_hidden, e.seed, STREAM_EMBED, tr);
+    const bool px = e.px;
+    if (px) { ea.x_pair = e.ws + e.x0p; ea.ld_pair = 2 * H; ea.lo_pair = H; }
     CHECK_HIP(launch_embed_fwd(ea, dt, s));
     const char* x = e.ws + e.x0;
+    const char* xg = px ? e.ws + e.x0p : x;          // the layer input as the GEMMs read it (parity mode: its plane pair)
     if (e.cls_only < 0) { const char* v = getenv("MMHIP_CLS_ONLY"); e.cls_only = v ? atoi(v) : 1; }
     e.cls_compact = false;
     for (int l = 0; l < c.layers_txt; ++l) {
         const LayerOff& o = e.txt[l];
         const LayerW16& w = e.txt_w16[l];
         const TextAct& a = e.tact[l];
-        { G g(x, H, e.ws + w.qkv, H, e.ws + a.qkv, 3 * H, Mt, 3 * H, H); g.bias(W + o.qkv_b); part_gemm(e, g, 0); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(xg, H, e.ws + w.qkv, H, e.ws + a.qkv, 3 * H, Mt, 3 * H, H); g.bias(W + o.qkv_b).px_in(px).px_out(px); part_gemm(e, g, 0); if (int r = run_gemm(e, g, s)) return r; }
         // Only the CLS row of the last layer's output is ever consumed (fusion query and pooler, mm_late.py:111,155-158):
         // its attention needs query tile 0 only and everything after it runs on Bt rows (row stride T*H in the full
         // tensors, compact [Bt, .] outputs).  Dropout indices keep the full-tensor numbering (row_mul = T).
@@ -593,25 +618,29 @@ int text_forward(mmhip_engine& e, hipStream_t s) {
         memset(&at, 0, sizeof(at));
         at.qkv = e.ws + a.qkv; at.maskbias = e.wsp<float>(e.maskbias); at.ctx = e.ws + a.ctx; at.lse = e.wsp<float>(a.lse);
         at.posts = Bt; at.S = T; at.heads = c.heads; at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
+        if (px) { at.pair = 1; at.ld_qkv = 6 * H; at.lo_qkv = 3 * H; at.ld_ctx = 2 * H; at.lo_ctx = H; }
         at.scale = 1.0f / sqrtf((float)(H / c.heads));
         at.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
         at.q_tiles = compact ? 1 : 0;
         CHECK_HIP(launch_attn_fwd(at, dt, s));
         { G g(e.ws + a.ctx, rs, e.ws + w.ao, H, e.ws + a.pre1, H, Mr, H, H);
-          g.bias(W + o.ao_b).dropout(make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr), rmul).residual(x, rs);
+          g.bias(W + o.ao_b).dropout(make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr), rmul).residual(x, rs).px_in(px);
           part_gemm(e, g, 0);
           if (int r = run_gemm(e, g, s)) return r; }
         LNArgs ln1{e.ws + a.pre1, e.ws + a.a1, W + o.ln1_w, W + o.ln1_b, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), Mr, H, H, H, c.ln_eps_txt};
+        if (px) { ln1.y_pair = e.ws + a.a1p; ln1.ld_pair = 2 * H; ln1.lo_pair = H; }
         CHECK_HIP(launch_layernorm_fwd(ln1, dt, s));
-        { G g(e.ws + a.a1, H, e.ws + w.fc1, H, e.ws + a.h, I, Mr, I, H); g.bias(W + o.fc1_b).aux(e.ws + a.u, I).gelu(); part_gemm(e, g, 0); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(e.ws + (px ? a.a1p : a.a1), H, e.ws + w.fc1, H, e.ws + a.h, I, Mr, I, H); g.bias(W + o.fc1_b).aux(e.ws + a.u, I).gelu().px_in(px).px_out(px); part_gemm(e, g, 0); if (int r = run_gemm(e, g, s)) return r; }
         { G g(e.ws + a.h, I, e.ws + w.fc2, I, e.ws + a.pre2, H, Mr, H, I);
-          g.bias(W + o.fc2_b).dropout(make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr), rmul).residual(e.ws + a.a1, H);
+          g.bias(W + o.fc2_b).dropout(make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr), rmul).residual(e.ws + a.a1, H).px_in(px);
           part_gemm(e, g, 0);
           if (int r = run_gemm(e, g, s)) return r; }
         LNArgs ln2{e.ws + a.pre2, e.ws + a.out, W + o.ln2_w, W + o.ln2_b, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), Mr, H, H, H, c.ln_eps_txt};
+        if (px) { ln2.y_pair = e.ws + a.outp; ln2.ld_pair = 2 * H; ln2.lo_pair = H; }
         CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
         e.cls_compact = compact;
         x = e.ws + a.out;
+        xg = px ? e.ws + a.outp : x;
     }
     return 0;
 }
@@ -895,7 +924,8 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     const LayerOff& o = e.txt[l];
     const LayerW16& w = e.txt_w16[l];
     const TextAct& a = e.tact[l];
-    const char* x_in = l ? e.ws + e.tact[l - 1].out : e.ws + e.x0;
+    const bool px = e.px;
+    const char* x_in = px ? (l ? e.ws + e.tact[l - 1].outp : e.ws + e.x0p) : (l ? e.ws + e.tact[l - 1].out : e.ws + e.x0);      // as the dWqkv product reads it
     const bool tr = e.train_mode;
     // temporaries that the weight-gradient GEMMs read are double-buffered per layer parity so that the side stream may
     // still be consuming layer l's set while the main stream runs layer l-1 on the other one
@@ -917,8 +947,9 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     // (the second stage of its dgamma / dbeta reduction is not on the dX chain: it runs with the layer's dW on the side stream)
     LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mr, H,
                  e.wsp<float>(e.g_lnp[set][0]), 1.0f / e.gscale(), d_ffn.thresh16 ? ddrop2 : nullptr, nullptr, d_ffn, rmul, 1};
+    if (px) { b2.pair_out = ddrop2; b2.ld_pair = 2 * H; b2.lo_pair = H; }      // parity mode: the GEMMs' operand (dropped or not) as a plane pair in the ddrop buffer
     CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
-    const char* df = d_ffn.thresh16 ? ddrop2 : dpre2;
+    const char* df = (px || d_ffn.thresh16) ? ddrop2 : dpre2;
     // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
     if (e.part_bwd < 0) { const char* v = getenv("MMHIP_PART_BWD"); e.part_bwd = v ? atoi(v) : 0; }
     static int bwd_mask = -1;
@@ -926,28 +957,31 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     auto part_bwd = [&](G& g, int bit) {
         if (e.part_bwd > 0 && (bwd_mask & bit) && side && g.a.M >= 2048 && g.a.N % 256 == 0 && g.a.K % 64 == 0 && (dt == DT_BF16 || dt == DT_F16)) { g.a.tile = 15; g.a.grid = e.part_bwd; }
     };
-    { G g(df, H, e.ws + w.fc2T, H, du, I, Mr, I, H); g.mul_gelu_grad(e.ws + a.u, I); part_bwd(g, 1); if (int r = run_gemm(e, g, s)) return r; }
+    { G g(df, H, e.ws + w.fc2T, H, du, I, Mr, I, H); g.mul_gelu_grad(e.ws + a.u, I).px_in(px).px_out(px); part_bwd(g, 1); if (int r = run_gemm(e, g, s)) return r; }
     // the two long-K activation-gradient GEMMs of the layer (768 wide): one role-specialised 256x96 tile per CU when M gives
     // exactly <= 256 of them -- in isolation 7 % faster than the 192 tiles of 256x128, in the step -0.05 ms (same-box A/B; the
     // same tile in the FORWARD costs +0.3 ms: it leaves no CU to the image tower).  MMHIP_BWD_TILE12=0 turns it off.
     static int bt12 = -1;
     if (bt12 < 0) { const char* v = getenv("MMHIP_BWD_TILE12"); bt12 = v ? atoi(v) : 1; }
     const int nt = (bt12 && Mr >= 4096 && Mr <= 8192 && H % 96 == 0) ? 12 : 0;
-    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mr, H, I); g.residual(dpre2, H); g.a.tile = nt; part_bwd(g, 2); if (int r = run_gemm(e, g, s)) return r; }
+    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mr, H, I); g.residual(dpre2, H).px_in(px); g.a.tile = nt; part_bwd(g, 2); if (int r = run_gemm(e, g, s)) return r; }
     // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
     LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mr, H,
                  e.wsp<float>(e.g_lnp[set][1]), 1.0f / e.gscale(), d_ao.thresh16 ? ddrop1 : nullptr, nullptr, d_ao, rmul, 1};
+    if (px) { b1.pair_out = ddrop1; b1.ld_pair = 2 * H; b1.lo_pair = H; }
     CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
-    const char* dout = d_ao.thresh16 ? ddrop1 : dpre1;
+    const char* dout = (px || d_ao.thresh16) ? ddrop1 : dpre1;
     if (compact) {
-        // d ctx for the CLS rows only, spread into an otherwise-zero full tensor for the attention backward
-        { G g(dout, H, e.ws + w.aoT, H, dx2, H, Mr, H, H); if (int r = run_gemm(e, g, s)) return r; }
+        // d ctx for the CLS rows only, spread into an otherwise-zero full tensor for the attention backward (parity mode: pair rows of 2 H 16-bit
+        // elements are moved as the H 4-byte words they occupy; an all-zero pair is zero)
+        { G g(dout, H, e.ws + w.aoT, H, dx2, H, Mr, H, H); g.px_in(px).px_out(px); if (int r = run_gemm(e, g, s)) return r; }
         CHECK_HIP(hipMemsetAsync(dctx, 0, (size_t)Mt * H * e.esz(), s));
         CHECK_HIP(launch_scatter_rows16(dx2, dctx, Bt, (size_t)T * H, H, 0, dt, s));
         CHECK_HIP(hipMemsetAsync(dqkv, 0, (size_t)Mt * 3 * H * e.esz(), s));      // dQ of the skipped query tiles is zero
     } else {
         G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H);
+        g.px_in(px).px_out(px);
         g.a.tile = (bt12 & 2) ? nt : 0;
         part_bwd(g, 4);
         if (int r = run_gemm(e, g, s)) return r;
@@ -956,6 +990,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     memset(&ab, 0, sizeof(ab));
     ab.qkv = e.ws + a.qkv; ab.maskbias = e.wsp<float>(e.maskbias); ab.ctx = e.ws + a.ctx; ab.dctx = dctx; ab.lse = e.wsp<float>(a.lse);
     ab.dqkv = dqkv; ab.posts = Bt; ab.S = T; ab.heads = c.heads; ab.ld_qkv = 3 * H; ab.ld_ctx = H; ab.hidden = H;
+    if (px) { ab.pair = 1; ab.ld_qkv = 6 * H; ab.lo_qkv = 3 * H; ab.ld_ctx = 2 * H; ab.lo_ctx = H; }
     ab.scale = 1.0f / sqrtf((float)(H / c.heads));
     ab.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
     ab.q_tiles = compact ? 1 : 0;
@@ -970,11 +1005,11 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     }
     if (compact) {
         // dx_in = dqkv . Wqkv, plus d pre1 on the CLS rows (the residual branch of the CLS rows)
-        { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.px_in(px); if (int r = run_gemm(e, g, s)) return r; }
         CHECK_HIP(launch_scatter_rows16(dpre1, dx, Bt, (size_t)T * H, H, 1, dt, s));
     } else {
         G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H);
-        g.residual(dpre1, H);
+        g.residual(dpre1, H).px_in(px);
         g.a.tile = nt;
         part_bwd(g, 8);
         if (int r = run_gemm(e, g, s)) return r;
@@ -987,6 +1022,10 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     pr[1] = GemmTNProblem{du, e.ws + a.a1, Gd + o.fc1_w, Mr, I, H, I, H, H, 0, Gd + o.fc1_b};          // dW1[I,H]   = du^T a1
     pr[2] = GemmTNProblem{dqkv, x_in, Gd + o.qkv_w, Mt, 3 * H, H, 3 * H, H, H, 0, Gd + o.qkv_b};       // dWqkv[3H,H] = dqkv^T x_in
     pr[3] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mr, H, H, H, rs, H, 0, Gd + o.ao_b};        // dWo[H,H]   = dout^T ctx (CLS rows: stride T*H)
+    if (px) {
+        pr[1].B = e.ws + a.a1p;
+        for (auto& q : pr) { q.pair = 1; q.lda *= 2; q.ldb *= 2; q.a_lo = q.Nn; q.b_lo = q.Nc; }
+    }
     {
         const int i = e.side && ps == e.side ? 1 : 0;
         CHECK_HIP(launch_gemm_tn(pr, 4, 0, dt, 0, ps, 1.0f / e.gscale(), e.x3_bytes[i] ? e.ws + e.x3_ws[i] : nullptr, e.x3_bytes[i]));
@@ -1056,7 +1095,7 @@ int mmhip_create(const mmhip_config* cfg, mmhip_handle* out) {
         // attention keeps the K / V of a head in LDS: 608 keys of 64 x 16 bit fill the 160 KB of a CU (336 / 14 -> 577 tokens);
         // the fp32 parity-mode attention holds 4-byte K / V: 288 keys
         const int P = (c.image / c.patch) * (c.image / c.patch) + 1;
-        if (P > (c.dtype == MMHIP_BF16X3 ? 288 : 608)) return MMHIP_E_INVALID;
+        if (P > 608) return MMHIP_E_INVALID;
     }
     if (c.max_text_len > 128 || c.max_text_len < 1 || c.max_posts < 1 || c.max_posts > 1024) return MMHIP_E_INVALID;
     if (c.dtype != MMHIP_BF16 && c.dtype != MMHIP_F16 && c.dtype != MMHIP_BF16X3) return MMHIP_E_INVALID;
@@ -1066,6 +1105,7 @@ int mmhip_create(const mmhip_config* cfg, mmhip_handle* out) {
     mmhip_engine* e = new (std::nothrow) mmhip_engine();
     if (!e) return MMHIP_E_INVALID;
     e->cfg = c;
+    if (c.dtype == MMHIP_BF16X3) { const char* v = getenv("MMHIP_X3_PAIRS"); e->px = v ? atoi(v) != 0 : true; }
     build_layout(*e);
     build_workspace(*e);
     *out = e;
@@ -1108,7 +1148,7 @@ int mmhip_refresh_weights(mmhip_handle h, int which, void* stream) {
         for (int l = 0; l < e.cfg.layers_img; ++l)
             if (int r = refresh_layer(e, e.frozen, e.vit[l], e.vit_w16[l], false, s, e.Hv(), e.Iv())) return r;
         // patch-embedding weight [Hv, 3*p*p], rows zero-padded to the GEMM's k-step (14 x 14 patches: 588 -> 640)
-        CHECK_HIP(launch_cast_pad(e.frozen + e.v_patch_w, e.ws + e.patch_w16, e.Hv(), e.Kp(), e.Kpp(), e.dt(), s));
+        CHECK_HIP(launch_cast_pad(e.frozen + e.v_patch_w, e.ws + e.patch_w16, e.Hv(), e.Kp(), e.Kpp(), e.px ? DT_PAIR : e.dt(), s));
     }
     if (which & 2)
         for (int l = 0; l < e.cfg.layers_txt; ++l)

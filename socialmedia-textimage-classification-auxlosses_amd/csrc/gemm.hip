@@ -357,9 +357,19 @@ void gemm_tn_kernel(GemmTNGroup g) {
         const int row = (lw * C::BI + i) * C::B_RPI + lane / SPR, slot = lane % SPR;
         bsrc[i] = B + (size_t)row * P.ldb + c0 + (slot ^ fsw(row)) * 8;
     }
+    // parity mode, plane pairs (mmhip_kernels.h): the M rows are walked three times -- (A hi, B hi), (A lo, B hi), (A hi, B lo)
+    const int msteps = P.M / 64;
     auto stage = [&](int buf, int mstep) {
         char* base = smem + buf * C::STAGE;
-        const size_t ao = g.accumulate == 2 ? 0 : (size_t)mstep * 64 * P.lda, bo = g.accumulate == 2 ? 0 : (size_t)mstep * 64 * P.ldb;
+        size_t ao, bo;
+        if (P.pair) {
+            const int seg = mstep / msteps, r = mstep - seg * msteps;
+            ao = (size_t)r * 64 * P.lda + (seg == 1 ? (size_t)P.a_lo : 0);
+            bo = (size_t)r * 64 * P.ldb + (seg == 2 ? (size_t)P.b_lo : 0);
+        } else {
+            ao = g.accumulate == 2 ? 0 : (size_t)mstep * 64 * P.lda;
+            bo = g.accumulate == 2 ? 0 : (size_t)mstep * 64 * P.ldb;
+        }
 #pragma unroll
         for (int i = 0; i < C::AI; ++i)
             __builtin_amdgcn_global_load_lds(MM_GLB(asrc[i] + ao), MM_LDS(base + (lw * C::AI + i) * 1024), 16, 0, 0);
@@ -413,8 +423,9 @@ void gemm_tn_kernel(GemmTNGroup g) {
             }
         }
     };
-    const int nsteps = P.M / 64;
-    const int cs_steps = P.colsum_rows > 0 ? P.colsum_rows / 64 : nsteps;      // the column sums may cover the first rows only (parity mode: x3.hip)
+    const int nsteps = P.pair ? 3 * msteps : msteps;
+    // the column sums may cover the first rows only (parity mode: the hi and lo planes of A = the first two of the three passes)
+    const int cs_steps = P.pair ? 2 * msteps : (P.colsum_rows > 0 ? P.colsum_rows / 64 : nsteps);
     if constexpr (NL > 0) {
         // role-specialised ring (see gemm_nt_kernel): loader waves stream, consumer waves multiply, one barrier per step
         if (w >= C::NW) {

@@ -102,6 +102,13 @@ __device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, 
         float* c = (float*)a.C + (size_t)m * a.ldc + n;
         *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else if (std::is_same<T, float>::value && (fl & GEMM_OUT_PAIR)) {
+        // parity mode: C as a plane pair (mmhip_kernels.h) -- the following matrix products read hi and lo as they are: two 16-byte stores
+        // instead of the two of the fp32 row, no split pass later
+        const Frag3 f = split8(v);
+        bf16_t* c = (bf16_t*)a.C + (size_t)m * a.ldc + n;
+        *reinterpret_cast<bf16x8*>(c) = f.hi;
+        *reinterpret_cast<bf16x8*>(c + a.c_lo) = f.lo;
     } else {
         v8 o;
 #pragma unroll
@@ -231,7 +238,10 @@ struct I8 {
 
 // ET = element type of everything the epilogue touches (C, aux, residual, mul_in): T, or float in the parity mode (bf16x3), whose 16-bit
 // operands are the split planes of fp32 tensors (x3.hip) -- the K loop is the same
-template <typename T, int BN, int EPI, typename ET = T>
+// SEG (parity mode, round 4): A and B are plane pairs written by their producers (mmhip_kernels.h); the reduction runs over THREE segments of
+// K / 64 K-tiles each -- (A hi, B hi), (A lo, B hi), (A hi, B lo) -- by moving the operands' base pointers between the planes at the segment
+// ends: one launch, no scratch copies of the operands (round 3 split every fp32 operand into [hi | lo | hi] copies before each call).
+template <typename T, int BN, int EPI, typename ET = T, bool SEG = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int persistent) {
     using C = P8<BN>;
     using P = I8<BN>;
@@ -244,7 +254,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
     const int tilesN = g.p[0].N / BN;
     const int tilesM0 = (g.p[0].M + C::BM - 1) / C::BM, tiles0 = tilesN * tilesM0;
     const int tilesM1 = g.count > 1 ? (g.p[1].M + C::BM - 1) / C::BM : 0, ntiles = tiles0 + tilesN * tilesM1;
-    const int nk = g.p[0].K / C::BK;
+    const int kseg = g.p[0].K / C::BK;               // K-tiles of one plane
+    const int nk = SEG ? 3 * kseg : kseg;
+    // byte steps of the operand pointers at the two segment ends (on top of the ordinary 128 bytes): A hi -> A lo -> A hi, B hi -> B hi -> B lo
+    const int segA1 = SEG ? (g.p[0].a_lo - g.p[0].K) * 2 : 0, segA2 = SEG ? -(g.p[0].a_lo + g.p[0].K) * 2 : 0;
+    const int segB1 = SEG ? -g.p[0].K * 2 : 0, segB2 = SEG ? (g.p[0].b_lo - g.p[0].K) * 2 : 0;
     const int nwg = gridDim.x;
     int first, stride, count;
     if (persistent) {
@@ -313,8 +327,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
             g_inc[p] = live ? 128 : 0;
             rebase(pc_, first + (live ? g_tile[p] : 0) * stride);
         } else {
-            gA[p] += g_inc[p];
-            gB[p] += g_inc[p];
+            if constexpr (SEG) {
+                // g_rem K-tiles of the group's current tile are still to be issued: the next one opens segment 1 / segment 2 (never while the
+                // group runs on past the end of the work list: g_inc = 0 there)
+                const int j1 = g_rem[p] == 2 * kseg ? (g_inc[p] >> 7) : 0, j2 = g_rem[p] == kseg ? (g_inc[p] >> 7) : 0;
+                gA[p] += g_inc[p] + j1 * segA1 + j2 * segA2;
+                gB[p] += g_inc[p] + j1 * segB1 + j2 * segB2;
+            } else {
+                gA[p] += g_inc[p];
+                gB[p] += g_inc[p];
+            }
         }
     };
     typedef std::integral_constant<int, 0> I0;
@@ -526,6 +548,8 @@ hipError_t launch_splitk_finish(const GemmNTArgs& a, int dtype, int slices, hipS
 
 static bool nt8_ok(const GemmNTArgs& a, int bn) {
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (a.a_pair != a.b_pair || (a.a_pair && (a.a_lo % 8 || a.b_lo % 8))) return false;      // plane pairs: both operands, 16-byte aligned planes
+    if ((a.flags & GEMM_OUT_PAIR) && a.c_lo % 8) return false;
     return a.N % bn == 0 && a.K % 64 == 0 && a.K >= 64 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&
            (!(a.flags & GEMM_RESIDUAL) || (a.ldres % 8 == 0 && al(a.residual))) &&
            (!(a.flags & GEMM_AUX_PRE) || (a.ldaux % 8 == 0 && al(a.aux))) &&
@@ -534,11 +558,11 @@ static bool nt8_ok(const GemmNTArgs& a, int bn) {
 }
 
 static int nt8_grid(int ntiles) { return ntiles <= 256 ? ntiles : 256; }      // workgroups of a persistent launch: one per CU
-template <typename T, int BN, int EPI, typename ET = T>
+template <typename T, int BN, int EPI, typename ET = T, bool SEG = false>
 static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
     using C = P8<BN>;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<T, BN, EPI, ET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<T, BN, EPI, ET, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
     int ntiles = 0;
     for (int i = 0; i < g.count; ++i) ntiles += ((g.p[i].M + C::BM - 1) / C::BM) * (g.p[i].N / BN);
     const int cap = g.p[0].grid > 0 ? (g.p[0].grid < ntiles ? g.p[0].grid : ntiles) : 0;
@@ -552,26 +576,31 @@ static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
         const int tn = g.p[0].N / BN, ng = (tn + 7) / 8;
         g2.gw = (tn + ng - 1) / ng;
     }
-    hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI, ET>), dim3(grid), dim3(512), lds, s, g2, persistent && ntiles > grid ? 1 : 0);
+    hipLaunchKernelGGL((gemm_nt8_kernel<T, BN, EPI, ET, SEG>), dim3(grid), dim3(512), lds, s, g2, persistent && ntiles > grid ? 1 : 0);
 }
 // epilogue class that covers a flag set (a pair uses the class that covers both)
 static int nt8_class(int f) {
+    f &= ~GEMM_OUT_PAIR;          // where the result goes does not change the class
     if (f == (GEMM_BIAS | GEMM_GELU) || f == (GEMM_BIAS | GEMM_GELU | GEMM_AUX_PRE) || f == (GEMM_BIAS | GEMM_QGELU)) return EP_GELU;
     if (f == GEMM_MUL_GELU_GRAD || f == (GEMM_MUL_GELU_GRAD | GEMM_RESIDUAL)) return EP_MULG;
     if (!(f & ~(GEMM_BIAS | GEMM_DROPOUT | GEMM_RESIDUAL))) return EP_PLAIN;
     return EP_ANY;
 }
-template <typename T, int BN, typename ET = T>
+template <typename T, int BN, typename ET = T, bool SEG = false>
 static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
     int c = nt8_class(g.p[0].flags);
     if (g.count > 1 && nt8_class(g.p[1].flags) != c) c = EP_ANY;
-    if (c == EP_GELU) launch_nt8_e<T, BN, EP_GELU, ET>(g, persistent, s);
-    else if (c == EP_MULG) launch_nt8_e<T, BN, EP_MULG, ET>(g, persistent, s);
-    else if (c == EP_PLAIN) launch_nt8_e<T, BN, EP_PLAIN, ET>(g, persistent, s);
-    else launch_nt8_e<T, BN, EP_ANY, ET>(g, persistent, s);
+    if (c == EP_GELU) launch_nt8_e<T, BN, EP_GELU, ET, SEG>(g, persistent, s);
+    else if (c == EP_MULG) launch_nt8_e<T, BN, EP_MULG, ET, SEG>(g, persistent, s);
+    else if (c == EP_PLAIN) launch_nt8_e<T, BN, EP_PLAIN, ET, SEG>(g, persistent, s);
+    else launch_nt8_e<T, BN, EP_ANY, ET, SEG>(g, persistent, s);
 }
 static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent, hipStream_t s) {
-    if (dtype == DT_F32) {          // parity mode: bf16 split planes in, fp32 epilogue
+    if (dtype == DT_F32 && g.p[0].a_pair) {          // parity mode, operands as plane pairs: three K segments
+        if (bn == 256) launch_nt8_t<bf16_t, 256, float, true>(g, persistent, s);
+        else if (bn == 192) launch_nt8_t<bf16_t, 192, float, true>(g, persistent, s);
+        else launch_nt8_t<bf16_t, 128, float, true>(g, persistent, s);
+    } else if (dtype == DT_F32) {          // parity mode: bf16 split planes in (x3.hip scratch copies), fp32 epilogue
         if (bn == 256) launch_nt8_t<bf16_t, 256, float>(g, persistent, s);
         else if (bn == 192) launch_nt8_t<bf16_t, 192, float>(g, persistent, s);
         else launch_nt8_t<bf16_t, 128, float>(g, persistent, s);

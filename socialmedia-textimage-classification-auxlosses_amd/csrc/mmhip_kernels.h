@@ -6,7 +6,8 @@
 
 namespace mmhip {
 
-enum { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2 };
+enum { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2,
+       DT_PAIR = 3 };      // destination type of launch_cast_group / launch_cast_pad / launch_patchify only: bf16 plane pairs (parity mode)
 enum { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };
 
 // ---------------------------------------------------------------- GEMM
@@ -20,7 +21,13 @@ enum {
     GEMM_MUL_GELU_GRAD = 64,  // value *= gelu'(mul_in[m][n])
     GEMM_TANH = 128,
     GEMM_QGELU = 256,         // quick-GELU x * sigmoid(1.702 x)   (HF CLIP hidden_act "quick_gelu")
+    GEMM_OUT_PAIR = 512,      // parity mode: C is a plane pair (below) instead of fp32
 };
+// Parity mode (bf16x3), round 4: PLANE PAIRS.  A tensor that feeds a matrix product is stored by its PRODUCER as two bf16 planes,
+// hi = bf16(x) and lo = bf16(x - hi), side by side in one row: element (r, c) has hi at base[r * ld + c] and lo at base[r * ld + lo_off + c]
+// (ld, lo_off in 16-bit elements; the natural layout is ld = 2 W, lo_off = W: the same bytes as the fp32 tensor it replaces).  The matrix
+// cores read the planes directly -- hi.hi + lo.hi + hi.lo as three K segments of ONE launch -- instead of every GEMM call splitting its fp32
+// operands into scratch copies first (round 3: split3_kernel, 6.2 of the 31 ms step).  x = hi + lo carries 16 significant bits.
 struct GemmNTArgs {
     const void* A; const void* B; void* C; void* aux; const float* bias; const void* residual; const void* mul_in;
     int M, N, K, lda, ldb, ldc, ldaux, ldres, ldmul;
@@ -38,6 +45,8 @@ struct GemmNTArgs {
     size_t x3_ws_bytes;
     float* splitk_ws;         // optional fp32 scratch [K/384][M][N]: a GEMM of <= 128 rows with K >= 1536 (the CLS-row GEMMs of the last
                               // text layer) is cut along K into slices that run side by side; a second kernel sums them and applies the epilogue
+    int a_pair, b_pair;       // parity mode: A / B is a plane pair (lda / ldb in 16-bit elements), lo plane a_lo / b_lo elements behind the hi plane
+    int a_lo, b_lo, c_lo;     // c_lo: lo-plane offset of C with GEMM_OUT_PAIR (ldc in 16-bit elements)
 };
 struct GemmNTPair { GemmNTArgs p[2]; int count; int gw; };      // gw: N-tiles per column group of the tile walk (0 = 8)      // gemm8.hip: one or two problems of equal N and K per launch
 static constexpr int GEMM_TN_MAX_GROUP = 8;
@@ -47,6 +56,8 @@ struct GemmTNProblem {
     float* colsum;            // optional [Nn]: (+)= alpha * sum_m A[m][n] -- the bias gradient that goes with dW = dY^T X, taken
                               // from the same operand tiles by one extra MFMA column (B = ones), no extra pass, no atomics
     int colsum_rows;          // > 0: the column sums cover rows 0 .. colsum_rows-1 only (a multiple of 64)
+    int pair;                 // parity mode: A and B are plane pairs (lda / ldb in 16-bit elements, lo planes a_lo / b_lo elements behind): the kernel
+    int a_lo, b_lo;           // walks the M rows three times -- (A hi, B hi), (A lo, B hi), (A hi, B lo) -- and the column sums cover A hi + A lo
 };
 struct GemmTNGroup {
     GemmTNProblem p[GEMM_TN_MAX_GROUP];
@@ -86,6 +97,8 @@ struct AttnArgs {
     float scale;
     DropCfg drop;
     int q_tiles;          // > 0: only the first q_tiles 32-row query tiles are computed / written (last layer: CLS row only)
+    int pair;             // parity mode: qkv and ctx are plane pairs (ld_qkv / ld_ctx in 16-bit elements), lo planes lo_qkv / lo_ctx elements behind
+    int lo_qkv, lo_ctx;
 };
 struct AttnBwdArgs {
     const void* qkv; const float* maskbias; const void* ctx; const void* dctx; const float* lse;
@@ -94,6 +107,8 @@ struct AttnBwdArgs {
     float scale;
     DropCfg drop;
     int q_tiles;          // > 0: d ctx is zero outside the first q_tiles query tiles; dQ of the other tiles is NOT written
+    int pair;             // parity mode: qkv, ctx, dctx, dqkv are plane pairs (qkv and dqkv share ld_qkv / lo_qkv; ctx and dctx ld_ctx / lo_ctx)
+    int lo_qkv, lo_ctx;
 };
 hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s);
 hipError_t launch_attn_fwd_f32(const AttnArgs& a, hipStream_t s);
@@ -104,6 +119,7 @@ hipError_t launch_attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t s);
 struct LNArgs {
     const void* x; void* y; const float* gamma; const float* beta; float* mean; float* rstd;
     int rows, width, ldx, ldy; float eps;
+    void* y_pair; int ld_pair, lo_pair;      // parity mode (optional): y also as a plane pair; y itself may then be null
 };
 struct LNBwdArgs {
     const void* dy; const void* x; const float* gamma; const float* mean; const float* rstd;
@@ -118,6 +134,8 @@ struct LNBwdArgs {
     void* dx_drop; float* colsum_out; DropCfg drop;
     int drop_row_mul;     // dropout index uses row * drop_row_mul (0 = 1)
     int defer_reduce;     // 1: only write the per-block partials; the caller runs launch_layernorm_bwd_reduce later
+    void* pair_out; int ld_pair, lo_pair;      // parity mode (optional): the tensor the following GEMMs read (dx_drop where dropout is on, else dx) as a
+                                               // plane pair; the fp32 dx_drop is then not written
 };
 hipError_t launch_layernorm_bwd_reduce(const LNBwdArgs& a, hipStream_t s);
 hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s);
@@ -133,6 +151,8 @@ struct EmbedArgs {
     float* maskbias;      // [rows] additive key bias (written)
     int posts, T, H, xlmr, pad_id; float eps;
     DropCfg drop;
+    void* x_pair; int ld_pair, lo_pair;      // parity mode (optional): x also as a plane pair
+    const int64_t* type_ids;                 // optional [rows] token type ids (null: every token takes row 0 of the type table)
 };
 struct EmbedBwdArgs {
     const void* dx; const void* xhat; const float* rstd; const float* gamma;
@@ -148,6 +168,8 @@ struct EmbedBwdArgs {
     int max_pos;          // rows of the position table (deterministic mode)
     unsigned* status;     // optional device words {counter, skip flag} (mmhip_set_step_guard): a non-finite element of dx -- the END of the
                           // backward's 16-bit chain, so an overflow anywhere upstream arrives here as inf / NaN -- counts and raises the flag
+    const int64_t* type_ids;   // optional [rows]: with it the token-type gradient goes to row 1 of dtype from the tokens of type 1 only -- the
+                               // early-fusion LXMERT tables are nn.Embedding(padding_idx = 0): type 0 gets no gradient (two-row table)
 };
 bool deterministic();     // MMHIP_DETERMINISTIC=1
 hipError_t launch_embed_fwd(const EmbedArgs& a, int dtype, hipStream_t s);

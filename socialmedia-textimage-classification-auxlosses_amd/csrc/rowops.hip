@@ -2,6 +2,7 @@
 // token assembly, column sums (bias gradients), fp32 -> 16-bit casts (plain and transposed).
 // One wave per row, 8-byte (4 x 16-bit) or 16-byte (4 x fp32) accesses per lane, fp32 arithmetic.
 #include <cstdlib>
+#include <type_traits>
 #include "mmhip_common.h"
 #include "mmhip_kernels.h"
 
@@ -33,6 +34,15 @@ template <typename T> __device__ __forceinline__ void store4(T* p, const float* 
 #pragma unroll
     for (int e = 0; e < 4; ++e) x[e] = from_f<T>(v[e]);
     *reinterpret_cast<typename Vec<T>::v4*>(p) = x;
+}
+
+// parity mode: 4 values into a plane pair (mmhip_kernels.h): hi = bf16(x) at p, lo = bf16(x - hi) `lo` elements behind
+__device__ __forceinline__ void store4_pair(bf16_t* p, int lo, const float* v) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = (bf16_t)v[e]; l[e] = (bf16_t)(v[e] - (float)h[e]); }
+    *reinterpret_cast<bf16x4*>(p) = h;
+    *reinterpret_cast<bf16x4*>(p + lo) = l;
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm forward
@@ -70,7 +80,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
             load4<float>(a.beta + c * 4, b);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[t][e] - mean) * rstd * g[e] + b[e];
-            store4<T>(y + c * 4, o);
+            if (a.y) store4<T>(y + c * 4, o);
+            if (std::is_same<T, float>::value && a.y_pair) store4_pair((bf16_t*)a.y_pair + (size_t)row * a.ld_pair + c * 4, a.lo_pair, o);
         }
     }
     if (lane == 0 && a.mean) { a.mean[row] = mean; a.rstd[row] = rstd; }
@@ -163,8 +174,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
                     o[1] = k1 ? o[1] * a.drop.keep_scale : 0.f;
                     o[2] = k2 ? o[2] * a.drop.keep_scale : 0.f;
                     o[3] = k3 ? o[3] * a.drop.keep_scale : 0.f;
-                    store4<T>((T*)a.dx_drop + (size_t)row * a.width + c * 4, o);
+                    if (!(std::is_same<T, float>::value && a.pair_out)) store4<T>((T*)a.dx_drop + (size_t)row * a.width + c * 4, o);
                 }
+                // parity mode: what the following matrix products read (the dropped gradient where dropout is on) as a plane pair
+                if (std::is_same<T, float>::value && a.pair_out) store4_pair((bf16_t*)a.pair_out + (size_t)row * a.ld_pair + c * 4, a.lo_pair, o);
                 if (a.colsum_out) {      // sums of the values as the bias-gradient consumer sees them (16-bit rounded)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dc[t][e] += to_f<T>(from_f<T>(o[e]));
@@ -258,6 +271,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a) {
     const int pid = a.pos_ids[row];
     const float* wr = a.word + (size_t)id * a.H;
     const float* pr = a.pos + (size_t)pid * a.H;
+    const float* tr = a.type + (a.type_ids ? (size_t)a.type_ids[row] * a.H : 0);
     float v[MAXC][4];
     float s = 0.f;
 #pragma unroll
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a) {
             float x1[4], x2[4], x3[4];
             load4<float>(wr + c * 4, x1);
             load4<float>(pr + c * 4, x2);
-            load4<float>(a.type + c * 4, x3);
+            load4<float>(tr + c * 4, x3);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[t][e] = x1[e] + x3[e] + x2[e]; s += v[t][e]; }
         }
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a) {
                 o[3] = k3 ? o[3] * a.drop.keep_scale : 0.f;
             }
             store4<T>(y + c * 4, o);
+            if (std::is_same<T, float>::value && a.x_pair) store4_pair((bf16_t*)a.x_pair + (size_t)row * a.ld_pair + c * 4, a.lo_pair, o);
         }
     }
     if (lane == 0 && a.rstd) a.rstd[row] = rstd;
@@ -373,6 +388,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
         if (!(fabsf(c1) <= 3.4028234e38f) || !(fabsf(c2) <= 3.4028234e38f)) seen_bad = true;
         const int64_t id = a.ids[row];
         const int pid = a.pos_ids[row];
+        const bool type_on = !a.type_ids || a.type_ids[row] == 1;      // (wave-uniform: one row per wave at a time)
         float* wrow = (id != a.pad_id && !a.det_rows) ? a.dword + (size_t)id * a.H : nullptr;
         const bool pos_on = pid != a.pos_pad_id && !a.det_rows;      // deterministic mode: word and position rows are summed by embed_scatter_det_kernel
         if (pos_on && pid0 < 0) pid0 = pid;
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float o = rstd * (g[t][e] - c1 - xh[t][e] * c2);
-                    dt[t][e] += o;
+                    if (type_on) dt[t][e] += o;
                     if (pos_reg) pacc[t][e] += o;
                     ov[e] = o * al;
                 }
@@ -429,7 +445,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
         } else {
             atomicAdd(a.dgamma + c, sg * al);
             atomicAdd(a.dbeta + c, sb * al);
-            atomicAdd(a.dtype + c, st * al);
+            atomicAdd(a.dtype + (a.type_ids ? a.H : 0) + c, st * al);
         }
     }
     __syncthreads();
@@ -538,6 +554,35 @@ __global__ __launch_bounds__(256) void patchify_any_kernel(const float* __restri
         out[idx] = from_f<T>(v);
     }
 }
+// plane-pair forms (parity mode): out rows [hi(ld) | lo(ld)]
+__global__ __launch_bounds__(256) void patchify_pair_kernel(const float* __restrict__ px, bf16_t* __restrict__ out, int B, int img, int ps, int ld) {
+    const int np = img / ps, K = 3 * ps * ps;
+    const size_t total = (size_t)B * np * np * ld;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int col = idx % ld;
+        const size_t prow = idx / ld;
+        float v = 0.f;
+        if (col < K) {
+            const int c = col / (ps * ps), i = (col / ps) % ps, j = col % ps;
+            const int b = prow / (np * np), py = (prow / np) % np, pxi = prow % np;
+            v = px[(((size_t)b * 3 + c) * img + (py * ps + i)) * img + pxi * ps + j];
+        }
+        const bf16_t h = (bf16_t)v;
+        out[prow * (2 * (size_t)ld) + col] = h;
+        out[prow * (2 * (size_t)ld) + ld + col] = (bf16_t)(v - (float)h);
+    }
+}
+__global__ __launch_bounds__(256) void cast_pad_pair_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols, int ld) {
+    const size_t total = (size_t)rows * ld;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = idx % ld;
+        const size_t r = idx / ld;
+        const float v = c < cols ? src[r * cols + c] : 0.f;
+        const bf16_t h = (bf16_t)v;
+        dst[r * (2 * (size_t)ld) + c] = h;
+        dst[r * (2 * (size_t)ld) + ld + c] = (bf16_t)(v - (float)h);
+    }
+}
 // dst[r][0..ld) = cast(src[r][0..cols)), zero beyond cols
 template <typename T>
 __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols, int ld) {
@@ -623,6 +668,39 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 }
 // grouped weight refresh: for each matrix of the group read every fp32 64x64 tile once, write the 16-bit copy and
 // (optionally) the transposed 16-bit copy -- one launch per layer instead of eight
+// parity mode (round 4): the GEMM operand copies of the weights are PLANE PAIRS (mmhip_kernels.h), rows [hi(cols) | lo(cols)]: dst [rows, 2 cols],
+// dstT [cols, 2 rows] -- written once per optimizer step instead of split before every matrix product
+__global__ __launch_bounds__(256) void cast_dual_pair_kernel(CastGroup g) {
+    __shared__ float tile[64][65];
+    int id = blockIdx.x, pi = 0;
+#pragma unroll
+    for (int i = 1; i < CAST_MAX_GROUP; ++i)
+        if (i < g.count && id >= g.m[i].tile_start) pi = i;
+    const CastMat& M = g.m[pi];
+    id -= M.tile_start;
+    const int tc = (M.cols + 63) / 64;
+    const int r0 = (id / tc) * 64, c0 = (id % tc) * 64;
+    bf16_t* dst = (bf16_t*)M.dst;
+    bf16_t* dstT = (bf16_t*)M.dstT;
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < M.rows && c0 + c < M.cols) {
+            load4<float>(M.src + (size_t)(r0 + r) * M.cols + c0 + c, v);
+            store4_pair(dst + (size_t)(r0 + r) * (2 * M.cols) + c0 + c, M.cols, v);
+        }
+        tile[r][c] = v[0]; tile[r][c + 1] = v[1]; tile[r][c + 2] = v[2]; tile[r][c + 3] = v[3];
+    }
+    if (!dstT) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+        const int c = i >> 4, r = (i & 15) * 4;
+        if (c0 + c < M.cols && r0 + r < M.rows) {
+            float v[4] = {tile[r][c], tile[r + 1][c], tile[r + 2][c], tile[r + 3][c]};
+            store4_pair(dstT + (size_t)(c0 + c) * (2 * M.rows) + r0 + r, M.rows, v);
+        }
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void cast_dual_kernel(CastGroup g) {
     __shared__ float tile[64][65];
@@ -781,7 +859,7 @@ hipError_t launch_embed_bwd(const EmbedBwdArgs& a, int dtype, hipStream_t s) {
     else if (dtype == DT_F16) hipLaunchKernelGGL(embed_bwd_kernel<f16_t>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), 0, s, a);
     if (a.partial) {
-        launch_reduce_partials(a.partial, (int)(grid.x * grid.y), a.H, a.dgamma, s, a.alpha == 0.f ? 1.f : a.alpha, a.dbeta, a.dtype);
+        launch_reduce_partials(a.partial, (int)(grid.x * grid.y), a.H, a.dgamma, s, a.alpha == 0.f ? 1.f : a.alpha, a.dbeta, a.dtype + (a.type_ids ? a.H : 0));
     }
     if (a.det_rows)
         hipLaunchKernelGGL(embed_scatter_det_kernel, dim3(a.posts * a.T + a.max_pos), dim3(64), 0, s, a.ids, a.pos_ids, a.det_rows, a.dword, a.dpos,
@@ -792,6 +870,7 @@ hipError_t launch_cast_pad(const float* src, void* dst, int rows, int cols, int 
     if (rows <= 0 || cols <= 0) return hipSuccess;
     if (ld < cols) return hipErrorInvalidValue;
     const int grid = cap_grid((size_t)rows * ld);
+    if (dtype == DT_PAIR) { hipLaunchKernelGGL(cast_pad_pair_kernel, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, rows, cols, ld); return hipGetLastError(); }
     if (dtype == DT_BF16) hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, rows, cols, ld);
     else if (dtype == DT_F16) hipLaunchKernelGGL(cast_pad_kernel<f16_t>, dim3(grid), dim3(256), 0, s, src, (f16_t*)dst, rows, cols, ld);
     else hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, rows, cols, ld);
@@ -800,6 +879,10 @@ hipError_t launch_cast_pad(const float* src, void* dst, int rows, int cols, int 
 hipError_t launch_patchify(const float* pixels, void* out, int B, int img, int patch, int ld, int dtype, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (img % patch || ld < 3 * patch * patch) return hipErrorInvalidValue;
+    if (dtype == DT_PAIR) {
+        hipLaunchKernelGGL(patchify_pair_kernel, dim3(cap_grid((size_t)B * (img / patch) * (img / patch) * ld)), dim3(256), 0, s, pixels, (bf16_t*)out, B, img, patch, ld);
+        return hipGetLastError();
+    }
     if (patch % 8 || ld != 3 * patch * patch) {
         const int grid = cap_grid((size_t)B * (img / patch) * (img / patch) * ld);
         if (dtype == DT_BF16) hipLaunchKernelGGL(patchify_any_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, pixels, (bf16_t*)out, B, img, patch, ld);
@@ -860,6 +943,7 @@ hipError_t launch_cast_group(const CastMat* mats, int count, int dtype, hipStrea
     if (!tiles) return hipSuccess;
     if (dtype == DT_BF16) hipLaunchKernelGGL(cast_dual_kernel<bf16_t>, dim3(tiles), dim3(256), 0, s, g);
     else if (dtype == DT_F16) hipLaunchKernelGGL(cast_dual_kernel<f16_t>, dim3(tiles), dim3(256), 0, s, g);
+    else if (dtype == DT_PAIR) hipLaunchKernelGGL(cast_dual_pair_kernel, dim3(tiles), dim3(256), 0, s, g);
     else hipLaunchKernelGGL(cast_dual_kernel<float>, dim3(tiles), dim3(256), 0, s, g);
     return hipGetLastError();
 }

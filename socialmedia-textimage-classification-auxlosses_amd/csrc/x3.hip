@@ -18,8 +18,40 @@ __device__ __forceinline__ f32x4 mma3(const Frag3& a, const Frag3& b, f32x4 c) {
     return mfma16(a.hi, b.hi, c);
 }
 
+// operand fragment of 8 consecutive k of one row: an fp32 row split in registers, or the two planes of a plane pair as they are
+// (mmhip_kernels.h: hi at base[row * ld + k], lo `lo` elements behind; ld, lo in 16-bit elements)
+__device__ __forceinline__ Frag3 frag_any(const void* base, size_t row, int ld, int k, int pair, int lo) {
+    if (pair) {
+        const bf16_t* p = (const bf16_t*)base + row * (size_t)ld + k;
+        Frag3 f;
+        f.hi = *reinterpret_cast<const bf16x8*>(p);
+        f.lo = *reinterpret_cast<const bf16x8*>(p + lo);
+        return f;
+    }
+    float v[8];
+    load8((const float*)base + row * (size_t)ld + k, v);
+    return split8(v);
+}
+__device__ __forceinline__ float value_any(const void* base, size_t row, int ld, int k, int pair, int lo) {
+    if (pair) { const bf16_t* p = (const bf16_t*)base + row * (size_t)ld + k; return (float)p[0] + (float)p[lo]; }
+    return ((const float*)base)[row * (size_t)ld + k];
+}
+// C row store of 4 consecutive columns: fp32, or a plane pair (GEMM_OUT_PAIR)
+__device__ __forceinline__ void store4_any(const GemmNTArgs& a, int m, int n, const float* v) {
+    if (a.flags & GEMM_OUT_PAIR) {
+        bf16_t* c = (bf16_t*)a.C + (size_t)m * a.ldc + n;
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (bf16_t)v[e]; l[e] = (bf16_t)(v[e] - (float)h[e]); }
+        *reinterpret_cast<bf16x4*>(c) = h;
+        *reinterpret_cast<bf16x4*>(c + a.c_lo) = l;
+    } else {
+        *reinterpret_cast<f32x4*>((float*)a.C + (size_t)m * a.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ NT
-// C[M,N] = epilogue(A[M,K] . B[N,K]^T), all fp32 in memory.  Block = 4 waves (2 x 2), 128 x 128 tile, wave 64 x 64.
+// C[M,N] = epilogue(A[M,K] . B[N,K]^T), all fp32 in memory (or plane pairs, see frag_any).  Block = 4 waves (2 x 2), 128 x 128 tile, wave 64 x 64.
 // Swapped MFMA operands (D = B_frag . A_frag^T): D row = n offset 4*(lane>>4) + reg, D column = m offset lane&15, so a
 // lane holds 4 consecutive columns of one output row -> 16-byte stores and the same fused epilogue as gemm.hip.
 __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmNTArgs a) {
@@ -27,29 +59,28 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmNTArgs a) {
     const int l15 = lane & 15, kc = lane >> 4;
     const int m0 = blockIdx.y * 128 + wm * 64, n0 = blockIdx.x * 128 + wn * 64;
     if (m0 >= a.M || n0 >= a.N) return;
-    const float* ap[4];
-    const float* bp[4];
+    size_t arow[4], brow[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ap[i] = (const float*)a.A + (size_t)min(m0 + i * 16 + l15, a.M - 1) * a.lda + kc * 8;
-        bp[i] = (const float*)a.B + (size_t)min(n0 + i * 16 + l15, a.N - 1) * a.ldb + kc * 8;
-    }
+    for (int i = 0; i < 4; ++i) { arow[i] = (size_t)min(m0 + i * 16 + l15, a.M - 1); brow[i] = (size_t)min(n0 + i * 16 + l15, a.N - 1); }
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ra[4][8], rb[4][8];
+    Frag3 na[4], nb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { load8(ap[i], ra[i]); load8(bp[i], rb[i]); }
+    for (int i = 0; i < 4; ++i) { na[i] = frag_any(a.A, arow[i], a.lda, kc * 8, a.a_pair, a.a_lo); nb[i] = frag_any(a.B, brow[i], a.ldb, kc * 8, a.b_pair, a.b_lo); }
 #pragma unroll 1
     for (int k0 = 0; k0 < a.K; k0 += 32) {
         Frag3 af[4], bf[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { af[i] = split8(ra[i]); bf[i] = split8(rb[i]); }
+        for (int i = 0; i < 4; ++i) { af[i] = na[i]; bf[i] = nb[i]; }
         if (k0 + 32 < a.K) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { load8(ap[i] + k0 + 32, ra[i]); load8(bp[i] + k0 + 32, rb[i]); }
+            for (int i = 0; i < 4; ++i) {
+                na[i] = frag_any(a.A, arow[i], a.lda, k0 + 32 + kc * 8, a.a_pair, a.a_lo);
+                nb[i] = frag_any(a.B, brow[i], a.ldb, k0 + 32 + kc * 8, a.b_pair, a.b_lo);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -103,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmNTArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += r[e];
             }
-            *reinterpret_cast<f32x4*>((float*)a.C + (size_t)m * a.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+            store4_any(a, m, n, v);
         }
     }
 }
@@ -112,10 +143,8 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmNTArgs a) {
 __global__ __launch_bounds__(256) void slow_nt_f32_kernel(GemmNTArgs a) {
     const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
     if (n >= a.N) return;
-    const float* x = (const float*)a.A + (size_t)m * a.lda;
-    const float* wv = (const float*)a.B + (size_t)n * a.ldb;
     float v = 0.f;
-    for (int k = 0; k < a.K; ++k) v = fmaf(x[k], wv[k], v);
+    for (int k = 0; k < a.K; ++k) v = fmaf(value_any(a.A, m, a.lda, k, a.a_pair, a.a_lo), value_any(a.B, n, a.ldb, k, a.b_pair, a.b_lo), v);
     const int fl = a.flags;
     if (fl & GEMM_BIAS) v += a.bias[n];
     if (fl & GEMM_AUX_PRE) ((float*)a.aux)[(size_t)m * a.ldaux + n] = v;
@@ -125,7 +154,14 @@ __global__ __launch_bounds__(256) void slow_nt_f32_kernel(GemmNTArgs a) {
     if (fl & GEMM_MUL_GELU_GRAD) v *= mm_gelu_grad(((const float*)a.mul_in)[(size_t)m * a.ldmul + n]);
     if ((fl & GEMM_DROPOUT) && a.drop.thresh16) v = mm_keep((uint32_t)m * (uint32_t)(a.drop_row_mul ? a.drop_row_mul : 1) * (uint32_t)a.N + (uint32_t)n, a.drop) ? v * a.drop.keep_scale : 0.f;
     if (fl & GEMM_RESIDUAL) v += ((const float*)a.residual)[(size_t)m * a.ldres + n];
-    ((float*)a.C)[(size_t)m * a.ldc + n] = v;
+    if (fl & GEMM_OUT_PAIR) {
+        bf16_t* c = (bf16_t*)a.C + (size_t)m * a.ldc + n;
+        const bf16_t h = (bf16_t)v;
+        c[0] = h;
+        c[a.c_lo] = (bf16_t)(v - (float)h);
+    } else {
+        ((float*)a.C)[(size_t)m * a.ldc + n] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ split planes
@@ -165,8 +201,10 @@ static bool nt_x3_fast(const GemmNTArgs& a, hipStream_t s) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("MMHIP_X3_FAST"); on = e ? atoi(e) : 1; }
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    if (!on || !a.x3_ws || a.force_slow || a.M <= 128 || a.N % 128 || a.K % 64 || a.lda % 4 || a.ldb % 4 || !al(a.A) || !al(a.B)) return false;
-    if (x3_nt_scratch_bytes(a.M, a.N, a.K) > a.x3_ws_bytes) return false;
+    const bool pairs = a.a_pair && a.b_pair;          // plane pairs written by the producers: no scratch, no copies
+    if (a.a_pair != a.b_pair) return false;
+    if (!on || (!pairs && !a.x3_ws) || a.force_slow || a.M <= 128 || a.N % 128 || a.K % 64 || a.lda % 4 || a.ldb % 4 || !al(a.A) || !al(a.B)) return false;
+    if (!pairs && x3_nt_scratch_bytes(a.M, a.N, a.K) > a.x3_ws_bytes) return false;
     int bn = 0;
     double best = 0;
     const long tm = (a.M + 255) / 256;
@@ -175,6 +213,11 @@ static bool nt_x3_fast(const GemmNTArgs& a, hipStream_t s) {
         const long t = tm * (a.N / cand);
         const double u = (double)t / (double)(((t + 255) / 256) * 256) + (cand == 256 ? 0.08 : (cand == 192 ? 0.04 : 0.0));      // near ties -> wider
         if (u > best) { best = u; bn = cand; }
+    }
+    if (pairs) {
+        GemmNTArgs b = a;
+        b.x3_ws = nullptr; b.splitk_ws = nullptr;
+        return launch_gemm_nt8(b, DT_F32, bn, 1, s);
     }
     GemmNTArgs b = a;
     char* pa = (char*)a.x3_ws;
@@ -191,6 +234,7 @@ hipError_t launch_gemm_nt_x3(const GemmNTArgs& a, hipStream_t s) {
     if (nt_x3_fast(a, s)) return hipGetLastError();
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     const bool fast = !a.force_slow && a.K % 32 == 0 && a.N % 4 == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.ldc % 4 == 0 && al(a.A) && al(a.B) && al(a.C) &&
+                      (!a.a_pair || (a.a_lo % 8 == 0 && a.lda % 8 == 0)) && (!a.b_pair || (a.b_lo % 8 == 0 && a.ldb % 8 == 0)) && (!(a.flags & GEMM_OUT_PAIR) || a.c_lo % 4 == 0) &&
                       (!(a.flags & GEMM_RESIDUAL) || (a.ldres % 4 == 0 && al(a.residual))) && (!(a.flags & GEMM_AUX_PRE) || (a.ldaux % 4 == 0 && al(a.aux))) &&
                       (!(a.flags & GEMM_MUL_GELU_GRAD) || (a.ldmul % 4 == 0 && al(a.mul_in))) && (!(a.flags & GEMM_BIAS) || al(a.bias));
     if (fast) hipLaunchKernelGGL(gemm_nt_x3_kernel, dim3((a.N + 127) / 128, (a.M + 127) / 128), dim3(256), 0, s, a);
@@ -208,8 +252,6 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(GemmTNProblem P, int ac
     const int l15 = lane & 15, kc = lane >> 4;
     const int n0 = blockIdx.y * 128 + wn_ * 64, c0 = blockIdx.x * 128 + wc_ * 64;
     if (n0 >= P.Nn || c0 >= P.Nc) return;
-    const float* A = (const float*)P.A;
-    const float* B = (const float*)P.B;
     int ncol[4], ccol[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ncol[i] = min(n0 + i * 16 + l15, P.Nn - 1); ccol[i] = min(c0 + i * 16 + l15, P.Nc - 1); }
@@ -235,7 +277,7 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(GemmTNProblem P, int ac
                 const int m = mb + 8 * kc + e;
                 const bool in = m < P.M;
                 const int mr = in ? m : P.M - 1;
-                const float y = A[(size_t)mr * P.lda + ncol[i]], x = B[(size_t)mr * P.ldb + ccol[i]];
+                const float y = value_any(P.A, mr, P.lda, ncol[i], P.pair, P.a_lo), x = value_any(P.B, mr, P.ldb, ccol[i], P.pair, P.b_lo);
                 ry[e] = in ? y : 0.f;
                 rx[e] = in ? x : 0.f;
             }
@@ -283,8 +325,15 @@ hipError_t launch_gemm_tn_x3(const GemmTNProblem* probs, int count, int accumula
     int nfast = 0;
     size_t used = 0;
     bool taken[64] = {false};
-    for (int i = 0; i < count && i < 64 && on && ws; ++i) {
+    for (int i = 0; i < count && i < 64 && on; ++i) {
         const GemmTNProblem& P = probs[i];
+        if (P.pair) {          // plane pairs: the grouped kernel walks the planes itself (gemm.hip), no scratch
+            if (P.M <= 0 || P.M % 64 || P.Nn % 256 || P.Nc % 128 || P.lda % 8 || P.ldb % 8 || P.a_lo % 8 || P.b_lo % 8 || !al(P.A) || !al(P.B) || nfast == GEMM_TN_MAX_GROUP) continue;
+            fastp[nfast++] = P;
+            taken[i] = true;
+            continue;
+        }
+        if (!ws) continue;
         if (P.M <= 0 || P.M % 64 || P.Nn % 256 || P.Nc % 128 || P.lda % 4 || P.ldb % 4 || !al(P.A) || !al(P.B) || nfast == GEMM_TN_MAX_GROUP) continue;
         const size_t need = x3_tn_scratch_bytes(P.M, P.Nn, P.Nc);
         if (used + need > ws_bytes) continue;
