@@ -330,6 +330,63 @@ int mmhip_op_cast(int dtype, const float* src, void* dst, uint64_t n, int transp
  * each lane received (tests/test_hw_layouts.py checks the lane maps every kernel here is built on). out: int32[4096] */
 int mmhip_op_probe_layouts(int32_t* out, void* stream);
 
+/* ==== early-fusion engine (BASELINE config 5): the LXMERT step of the reference's models/mm_early.py as ONE native call path (round 4;
+ * csrc/early.hip).  Boundary replaced: class Lxmert -- forward(input_ids, attention_mask, token_type_ids, features, normalized_boxes,
+ * tim_inputs) -> (linear_output, max_embeddings_t, max_embeddings_v, out_tim), models/mm_early.py:121-163, get_logits_per_text :165-172 --
+ * and the step body of MMEarly_Model.train :332-407 (loss mix :366-379, loss.backward(), optimizer.step()).  Below it: HF LxmertModel
+ * (transformers 4.25.1: embeddings with padding_idx = 0 on all three tables, visual-feature encoder, 9 language + 5 relational + 5
+ * cross-modality layers whose ONE cross-attention module serves both directions) on hand-written HIP kernels, two internal streams
+ * (language = the caller's, vision = internal).  Same conventions as the late-fusion handle: caller-owned flat fp32 parameter / gradient
+ * buffers laid out as mmhip_early_param_info_at describes (names = the reference module's state_dict keys: `model.*`, `linear_fusion.*`,
+ * `linear.*`, `linear_tim.*`, `logit_scale`), caller-owned workspace, caller's stream, error codes. */
+typedef struct mmhip_early_config {
+    int hidden, heads, inter;            /* 768, 12, 3072 (heads * 64 == hidden) */
+    int l_layers, r_layers, x_layers;    /* 9, 5, 5 */
+    int vocab, max_pos, type_vocab;      /* 30522, 512, 2 */
+    int feat_dim, pos_dim;               /* 2048 ROI feature width, 4 box coordinates (multiples of 4) */
+    int num_labels;
+    int max_posts, max_text_len, max_boxes;   /* capacity: B <= max_posts, T <= max_text_len <= 128, boxes <= max_boxes <= 128 (the ITM pass doubles the posts) */
+    int dtype;                           /* MMHIP_BF16 | MMHIP_F16 | MMHIP_BF16X3 */
+    float p_hidden, p_attn, p_head;      /* LXMERT hidden / attention dropout (0.1), the head's --dropout */
+    float ln_eps;                        /* 1e-12 */
+} mmhip_early_config;
+typedef struct mmhip_early* mmhip_early_handle;
+int mmhip_early_create(const mmhip_early_config* cfg, mmhip_early_handle* out);
+void mmhip_early_destroy(mmhip_early_handle h);
+int mmhip_early_param_count(mmhip_early_handle h);
+int mmhip_early_param_info_at(mmhip_early_handle h, int index, mmhip_param_info* out);      /* buffer = 1 for every entry; group: MMHIP_G_NEVER = the pooler */
+uint64_t mmhip_early_numel(mmhip_early_handle h);
+uint64_t mmhip_early_workspace_bytes(mmhip_early_handle h);
+/* params / grads: flat fp32 device buffers (256-byte aligned; grads may be NULL for inference); the call clears the boxes' key bias on `stream` */
+int mmhip_early_bind(mmhip_early_handle h, float* params, float* grads, void* workspace, uint64_t workspace_bytes, void* stream);
+/* 16-bit (parity mode: fp32) operand copies of the weights + transposed copies; call after the parameters changed */
+int mmhip_early_refresh_weights(mmhip_early_handle h, void* stream);
+/* Lxmert.forward.  ids / mask / token_type_ids (may be NULL = zeros): int64 [B, T]; feats fp32 [B, Nb, feat_dim]; boxes fp32 [B, Nb, pos_dim];
+ * tim_*: the swapped texts of the ITM pass (NULL = no ITM) -- both passes run as ONE encoder pass of 2B posts.  Outputs (may be NULL) fp32:
+ * out [B, num_labels], emb_t [B, H] (masked max over tokens, detached), emb_v [B, H] (max over boxes), out_tim [B, 2]. */
+int mmhip_early_forward(mmhip_early_handle h, const int64_t* ids, const int64_t* mask, const int64_t* token_type_ids, const float* feats, const float* boxes,
+                        const int64_t* tim_ids, const int64_t* tim_mask, const int64_t* tim_token_type_ids, int B, int T, int Nb, int train, uint64_t seed,
+                        float* out, float* emb_t, float* emb_v, float* out_tim, void* stream);
+/* loss mix models/mm_early.py:366-379 on the last forward's outputs; loss[4] = total, cls, itc, itm; logits_per_text (may be NULL) [B, B].
+ * Leaves the output gradients in the handle and ADDS d logit_scale to the gradient buffer. */
+int mmhip_early_loss(mmhip_early_handle h, const int64_t* onehot, const float* class_w, const int64_t* lbl_tim, float w_cls, float w_itc, float w_itm, float* loss,
+                     float* logits_per_text, void* stream);
+/* loss.backward(): NULL pointers = the gradients mmhip_early_loss left; else explicit fp32 d_out [B, C], d_emb_v [B, H] | NULL, d_out_tim [B, 2] | NULL.
+ * Entry condition: the gradient buffer is zero over the ranges that receive gradients (the step's AdamW re-establishes it). */
+int mmhip_early_backward(mmhip_early_handle h, const float* d_out, const float* d_emb_v, const float* d_out_tim, void* stream);
+/* backward stages for a data-parallel caller: 0 heads, then the cross-modality layers last -> first, then the language / relational layers by
+ * depth, then the inputs (visual-feature encoder + embeddings); [begin, end) of the flat buffers whose gradients are final after `stage` */
+int mmhip_early_num_stages(mmhip_early_handle h);
+int mmhip_early_stage_grad_range(mmhip_early_handle h, int stage, uint64_t* begin, uint64_t* end);
+/* one whole training step (forward, loss mix, backward, AdamW over the ranges that receive gradients for this flag set, operand refresh).
+ * itm_src: device int64 [B], row b of the ITM pass = row itm_src[b] of this batch (MMEarly_Model.prepare_itm_inputs' draw); on_stage: the
+ * exchange hook of mmhip_train_step_dp (may be NULL): on_stage(user, st) once stage st's gradient range is final in `stream` order,
+ * on_stage(user, MMHIP_CB_WAIT_DENSE) before the optimizer; grad_scale = 1 / world. */
+int mmhip_early_train_step(mmhip_early_handle h, const int64_t* ids, const int64_t* mask, const int64_t* token_type_ids, const float* feats, const float* boxes,
+                           const int64_t* itm_src, const int64_t* lbl_tim, const int64_t* onehot, const float* class_w, int B, int T, int Nb, uint64_t seed,
+                           int use_itc, int use_itm, float w_cls, float w_itc, float w_itm, float* adam_m, float* adam_v, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, int step, float grad_scale, float* loss, void* stream, mmhip_exchange_cb on_stage, void* user);
+
 const char* mmhip_version(void);
 #ifdef __cplusplus
 }

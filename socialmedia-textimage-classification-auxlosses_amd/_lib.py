@@ -24,6 +24,13 @@ class Config(C.Structure):
                 ("heads_img", C.c_int), ("inter_img", C.c_int)]
 
 
+class EarlyConfig(C.Structure):      # include/mmhip.h: mmhip_early_config
+    _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("inter", C.c_int), ("l_layers", C.c_int), ("r_layers", C.c_int), ("x_layers", C.c_int),
+                ("vocab", C.c_int), ("max_pos", C.c_int), ("type_vocab", C.c_int), ("feat_dim", C.c_int), ("pos_dim", C.c_int), ("num_labels", C.c_int),
+                ("max_posts", C.c_int), ("max_text_len", C.c_int), ("max_boxes", C.c_int), ("dtype", C.c_int), ("p_hidden", C.c_float), ("p_attn", C.c_float),
+                ("p_head", C.c_float), ("ln_eps", C.c_float)]
+
+
 class ParamInfo(C.Structure):
     _fields_ = [("name", C.c_char * 192), ("ndim", C.c_int), ("dims", C.c_int64 * 4), ("buffer", C.c_int), ("group", C.c_int),
                 ("offset", C.c_uint64), ("numel", C.c_uint64)]
@@ -103,6 +110,20 @@ _SIGS = {
     "mmhip_op_colsum": (I, [I, P, I, I, I, P, P]),
     "mmhip_op_cast": (I, [I, P, P, U64, I, I, P]),
     "mmhip_op_probe_layouts": (I, [P, P]),
+    "mmhip_early_create": (I, [C.POINTER(EarlyConfig), C.POINTER(P)]),
+    "mmhip_early_destroy": (None, [P]),
+    "mmhip_early_param_count": (I, [P]),
+    "mmhip_early_param_info_at": (I, [P, I, C.POINTER(ParamInfo)]),
+    "mmhip_early_numel": (U64, [P]),
+    "mmhip_early_workspace_bytes": (U64, [P]),
+    "mmhip_early_bind": (I, [P, P, P, P, U64, P]),
+    "mmhip_early_refresh_weights": (I, [P, P]),
+    "mmhip_early_forward": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, U64, P, P, P, P, P]),
+    "mmhip_early_loss": (I, [P, P, P, P, F, F, F, P, P, P]),
+    "mmhip_early_backward": (I, [P, P, P, P, P]),
+    "mmhip_early_num_stages": (I, [P]),
+    "mmhip_early_stage_grad_range": (I, [P, I, C.POINTER(U64), C.POINTER(U64)]),
+    "mmhip_early_train_step": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P, P]),
     "mmhip_version": (C.c_char_p, []),
 }
 EXPORTS = tuple(_SIGS)

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmhip.so")
-SOURCES = ["gemm.hip", "gemm8.hip", "x3.hip", "attention.hip", "rowops.hip", "heads.hip", "engine.hip", "capi_ops.hip", "image.hip"]
+SOURCES = ["gemm.hip", "gemm8.hip", "x3.hip", "attention.hip", "rowops.hip", "heads.hip", "engine.hip", "early.hip", "capi_ops.hip", "image.hip"]
 HEADERS = ["mmhip_common.h", "mmhip_kernels.h", os.path.join("..", "..", "include", "mmhip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fgpu-rdc=0"]
 

@@ -152,6 +152,14 @@ __global__ __launch_bounds__(256) void gather_rows_i64_kernel(const int64_t* __r
     out[idx] = in[(size_t)src[b] * T + t];
 }
 
+// key biases at the packed cross-attention length S = max(T, boxes): live keys copy their bias, keys past the stream's own length get -inf
+__global__ __launch_bounds__(256) void pad_bias_kernel(const float* __restrict__ in, float* __restrict__ out, int posts, int L, int S) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= posts * S) return;
+    const int b = idx / S, k = idx % S;
+    out[idx] = k < L ? (in ? in[(size_t)b * L + k] : 0.f) : -INFINITY;
+}
+
 inline int cap(size_t work) { size_t g = (work + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 
 DropCfg drop_cfg(float p, uint64_t seed, uint32_t stream, bool on) {
@@ -523,12 +531,14 @@ int encoder_forward(mmhip_early& e, const float* feats, const float* boxes, hipS
         ea.posts = Bt; ea.T = T; ea.H = H; ea.xlmr = 0; ea.pad_id = 0; ea.eps = c.ln_eps;
         ea.drop = drop_cfg(c.p_hidden, e.seed, 1, e.train);
         CHECK_HIP(launch_embed_fwd(ea, dt, s));
-        if (T < S) {          // key bias of the text padded to the packed cross-attention length (keys past T masked)
-            CHECK_HIP(hipMemsetAsync(e.ws + e.lbias_x, 0xFF, (size_t)Bt * S * 4, s));      // 0xFFFFFFFF = a NaN pattern: overwritten below where live, -inf needed
-            // -inf everywhere first (memset cannot write it: fill through the avg kernel is overkill) -> small strided copies
-            std::vector<float> ninf((size_t)S, -INFINITY);
-            (void)ninf;
+        if (T < S) {          // key bias of the text at the packed cross-attention length (keys past T masked)
+            hipLaunchKernelGGL(pad_bias_kernel, dim3((Bt * S + 255) / 256), dim3(256), 0, s, e.wsp<float>(e.lbias), e.wsp<float>(e.lbias_x), Bt, T, S);
+            CHECK_HIP(hipGetLastError());
         }
+    }
+    if (Nb < S) {
+        hipLaunchKernelGGL(pad_bias_kernel, dim3((Bt * S + 255) / 256), dim3(256), 0, sv, (const float*)nullptr, e.wsp<float>(e.vbias_x), Bt, Nb, S);
+        CHECK_HIP(hipGetLastError());
     }
     // ---- vision stream: visual-feature encoder  visn = dropout((LN(visn_fc(feats)) + LN(box_fc(boxes))) / 2)   (HF LxmertVisualFeatureEncoder)
     {
@@ -848,26 +858,18 @@ int mmhip_early_stage_grad_range(mmhip_early_handle h, int stage, uint64_t* begi
     return 0;
 }
 
-namespace {
-// key biases at the packed cross-attention length: live keys copy their bias, keys past the stream's own length get -inf
-__global__ __launch_bounds__(256) void pad_bias_kernel(const float* __restrict__ in, float* __restrict__ out, int posts, int L, int S) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= posts * S) return;
-    const int b = idx / S, k = idx % S;
-    out[idx] = k < L ? (in ? in[(size_t)b * L + k] : 0.f) : -INFINITY;
-}
-}  // namespace
-
-int mmhip_early_forward(mmhip_early_handle h, const int64_t* ids, const int64_t* mask, const int64_t* token_type_ids, const float* feats, const float* boxes,
-                        const int64_t* tim_ids, const int64_t* tim_mask, const int64_t* tim_token_type_ids, int B, int T, int Nb, int train, uint64_t seed,
-                        float* out, float* emb_t, float* emb_v, float* out_tim, void* stream) {
+// tim_*: the swapped texts of the ITM pass (reference :146-161) as explicit tensors, OR itm_src [B] (device int64): row b of the ITM pass is
+// row itm_src[b] of this batch (what the reference's sampling produces: MMEarly_Model.prepare_itm_inputs) -- gathered on the device
+static int forward_impl(mmhip_early_handle h, const int64_t* ids, const int64_t* mask, const int64_t* token_type_ids, const float* feats, const float* boxes,
+                        const int64_t* tim_ids, const int64_t* tim_mask, const int64_t* tim_token_type_ids, const int64_t* itm_src, int B, int T, int Nb, int train,
+                        uint64_t seed, float* out, float* emb_t, float* emb_v, float* out_tim, void* stream) {
     if (!h || !h->ws) return MMHIP_E_STATE;
     if (!ids || !mask || !feats || !boxes || B < 1 || T < 1 || Nb < 1) return MMHIP_E_INVALID;
-    if ((tim_ids == nullptr) != (tim_mask == nullptr)) return MMHIP_E_INVALID;
+    if ((tim_ids == nullptr) != (tim_mask == nullptr) || (tim_ids && itm_src)) return MMHIP_E_INVALID;
     mmhip_early& e = *h;
     if (B > e.cfg.max_posts || T > e.cfg.max_text_len || Nb > e.cfg.max_boxes) return MMHIP_E_CAPACITY;
     hipStream_t s = (hipStream_t)stream;
-    e.B = B; e.T = T; e.Nb = Nb; e.itm = tim_ids != nullptr; e.Bt = e.itm ? 2 * B : B; e.train = train != 0; e.seed = seed;
+    e.B = B; e.T = T; e.Nb = Nb; e.itm = tim_ids != nullptr || itm_src != nullptr; e.Bt = e.itm ? 2 * B : B; e.train = train != 0; e.seed = seed;
     e.fwd_done = false; e.itc_done = false; e.bd_out = e.bd_embv = e.bd_tim = nullptr;
     CHECK_RC(side_init(e));
     const size_t nb = (size_t)B * T * 8;
@@ -875,16 +877,143 @@ int mmhip_early_forward(mmhip_early_handle h, const int64_t* ids, const int64_t*
     CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all, mask, nb, hipMemcpyDeviceToDevice, s));
     if (token_type_ids) CHECK_HIP(hipMemcpyAsync(e.ws + e.tt_all, token_type_ids, nb, hipMemcpyDeviceToDevice, s));
     else CHECK_HIP(hipMemsetAsync(e.ws + e.tt_all, 0, nb, s));
-    if (e.itm) {
+    if (tim_ids) {
         CHECK_HIP(hipMemcpyAsync(e.ws + e.ids_all + nb, tim_ids, nb, hipMemcpyDeviceToDevice, s));
         CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all + nb, tim_mask, nb, hipMemcpyDeviceToDevice, s));
         if (tim_token_type_ids) CHECK_HIP(hipMemcpyAsync(e.ws + e.tt_all + nb, tim_token_type_ids, nb, hipMemcpyDeviceToDevice, s));
         else CHECK_HIP(hipMemsetAsync(e.ws + e.tt_all + nb, 0, nb, s));
+    } else if (itm_src) {
+        const int grid = (B * T + 255) / 256;
+        for (size_t off : {e.ids_all, e.mask_all, e.tt_all})
+            hipLaunchKernelGGL(gather_rows_i64_kernel, dim3(grid), dim3(256), 0, s, e.wsp<int64_t>(off), itm_src, e.wsp<int64_t>(off) + (size_t)B * T, B, T);
+        CHECK_HIP(hipGetLastError());
     }
     CHECK_RC(encoder_forward(e, feats, boxes, s));
     CHECK_RC(heads_forward(e, out, emb_t, emb_v, out_tim, s));
     e.fwd_done = true;
     return 0;
+}
+int mmhip_early_forward(mmhip_early_handle h, const int64_t* ids, const int64_t* mask, const int64_t* token_type_ids, const float* feats, const float* boxes,
+                        const int64_t* tim_ids, const int64_t* tim_mask, const int64_t* tim_token_type_ids, int B, int T, int Nb, int train, uint64_t seed,
+                        float* out, float* emb_t, float* emb_v, float* out_tim, void* stream) {
+    return forward_impl(h, ids, mask, token_type_ids, feats, boxes, tim_ids, tim_mask, tim_token_type_ids, nullptr, B, T, Nb, train, seed, out, emb_t, emb_v, out_tim,
+                        stream);
+}
+
+// loss mix of the reference's step (models/mm_early.py:366-379): (1 - b_itc - b_itm) CE(out, one-hot labels as probabilities, class weights)
+// + b_itc clip_loss(logits_per_text) + b_itm CE(out_tim, lbl_tim), logits_per_text = normalise(emb_t) normalise(emb_v)^T exp(logit_scale) (:165-172).
+// Leaves the output gradients in the handle for mmhip_early_backward(NULL ...) and ADDS d logit_scale to the gradient buffer.
+int mmhip_early_loss(mmhip_early_handle h, const int64_t* onehot, const float* class_w, const int64_t* lbl_tim, float w_cls, float w_itc, float w_itm, float* loss,
+                     float* logits_per_text, void* stream) {
+    if (!h || !h->fwd_done) return MMHIP_E_STATE;
+    if (!onehot) return MMHIP_E_INVALID;
+    mmhip_early& e = *h;
+    if (w_itm != 0.f && (!e.itm || !lbl_tim)) return MMHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = e.B, H = e.cfg.hidden;
+    if (w_itc != 0.f || logits_per_text) {
+        ItcArgs it{e.wsp<float>(e.h_embt), e.wsp<float>(e.h_embv), e.P + e.logit_scale, e.wsp<float>(e.h_txt_n), e.wsp<float>(e.h_img_n), e.wsp<float>(e.h_txt_inv),
+                   e.wsp<float>(e.h_img_inv), e.wsp<float>(e.h_logits), B, H};
+        CHECK_HIP(launch_itc_fwd(it, s));
+        e.itc_done = true;
+        if (logits_per_text) CHECK_HIP(hipMemcpyAsync(logits_per_text, e.ws + e.h_logits, (size_t)B * B * 4, hipMemcpyDeviceToDevice, s));
+    }
+    LossArgs a;
+    memset(&a, 0, sizeof(a));
+    a.out_cls = e.wsp<float>(e.h_out); a.onehot = onehot; a.class_w = class_w;
+    a.logits_per_text = w_itc != 0.f ? e.wsp<float>(e.h_logits) : nullptr;
+    a.out_tim = w_itm != 0.f ? e.wsp<float>(e.h_tim) : nullptr; a.lbl_tim = lbl_tim;
+    a.w_cls = w_cls; a.w_itc = w_itc; a.w_itm = w_itm;
+    a.loss = e.wsp<float>(e.h_loss);
+    a.d_out_cls = e.wsp<float>(e.h_dout);
+    a.d_logits = w_itc != 0.f ? e.wsp<float>(e.h_dlogits) : nullptr;
+    a.d_out_tim = w_itm != 0.f ? e.wsp<float>(e.h_dtim) : nullptr;
+    a.B = B; a.C = e.cfg.num_labels;
+    CHECK_HIP(launch_loss(a, s));
+    if (loss) CHECK_HIP(hipMemcpyAsync(loss, a.loss, 16, hipMemcpyDeviceToDevice, s));
+    e.bd_out = a.d_out_cls; e.bd_tim = a.d_out_tim; e.bd_embv = nullptr;
+    if (w_itc != 0.f) {
+        if (!e.G) return MMHIP_E_STATE;
+        // the text embedding is detached (reference :139): only the image side and logit_scale receive the ITC gradient
+        ItcBwdArgs ib{a.d_logits, e.wsp<float>(e.h_logits), e.wsp<float>(e.h_txt_n), e.wsp<float>(e.h_img_n), e.wsp<float>(e.h_txt_inv), e.wsp<float>(e.h_img_inv),
+                      e.P + e.logit_scale, e.wsp<float>(e.h_dembt), e.wsp<float>(e.h_dembv), e.G + e.logit_scale, B, H};
+        CHECK_HIP(launch_itc_bwd(ib, s));
+        e.bd_embv = e.wsp<float>(e.h_dembv);
+    }
+    return 0;
+}
+
+// loss.backward() (reference :381): gradients of every parameter on the path, ADDED into / stored to the bound gradient buffer.  CONTRACT as
+// mmhip_backward's: the gradient buffer is zero on entry over the ranges that receive gradients (LayerNorm weights, embedding rows, heads and
+// the shared cross-attention module accumulate; the other weight gradients are plain stores).  NULL pointers: the gradients mmhip_early_loss
+// left in the handle; else explicit fp32 output gradients d_out [B, C], d_emb_v [B, H] (may be NULL), d_out_tim [B, 2] (may be NULL).
+static int backward_impl(mmhip_early& e, const float* d_out, const float* d_emb_v, const float* d_out_tim, hipStream_t s, mmhip_exchange_cb cb, void* user) {
+    if (!e.fwd_done || !e.G) return MMHIP_E_STATE;
+    if (d_out) { e.bd_out = d_out; e.bd_embv = d_emb_v; e.bd_tim = d_out_tim; }
+    else if (!e.bd_out) return MMHIP_E_STATE;
+    const char* dl = nullptr;
+    const char* dv = nullptr;
+    const int n = num_stages(e);
+    hipStream_t sv = vstream(e, s);
+    for (int st = 0; st < n; ++st) {
+        CHECK_RC(backward_stage(e, st, &dl, &dv, s));
+        if (cb && st >= 1) {
+            // stage st-1's gradients are final once its work on BOTH streams is ordered into the caller's stream
+            CHECK_RC(order(e, e.ev_v2, sv, s));
+            CHECK_RC(cb(user, st - 1));
+        }
+    }
+    if (cb) { CHECK_RC(cb(user, n - 1)); CHECK_RC(cb(user, MMHIP_CB_WAIT_DENSE)); }
+    return 0;
+}
+int mmhip_early_backward(mmhip_early_handle h, const float* d_out, const float* d_emb_v, const float* d_out_tim, void* stream) {
+    if (!h) return MMHIP_E_STATE;
+    return backward_impl(*h, d_out, d_emb_v, d_out_tim, (hipStream_t)stream, nullptr, nullptr);
+}
+
+// One training step of MMEarly_Model.train (reference models/mm_early.py:332-407: forward, loss mix, backward, optimizer.step) in ONE call:
+// forward (train mode; the ITM pass batched with the main pass as 2B posts) + loss + backward + AdamW over the parameter ranges that receive a
+// gradient for this flag set (torch skips `grad is None`: never the pooler; logit_scale only with ITC, linear_tim only with ITM) + operand refresh.
+// on_stage (may be NULL): the data-parallel exchange hook of mmhip_train_step_dp -- stage st's gradient range (mmhip_early_stage_grad_range) is
+// final in `stream` order when on_stage(user, st) is called; MMHIP_CB_WAIT_DENSE before the optimizer.
+int mmhip_early_train_step(mmhip_early_handle h, const int64_t* ids, const int64_t* mask, const int64_t* token_type_ids, const float* feats, const float* boxes,
+                           const int64_t* itm_src, const int64_t* lbl_tim, const int64_t* onehot, const float* class_w, int B, int T, int Nb, uint64_t seed,
+                           int use_itc, int use_itm, float w_cls, float w_itc, float w_itm, float* adam_m, float* adam_v, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, int step, float grad_scale, float* loss, void* stream, mmhip_exchange_cb on_stage, void* user) {
+    if (!h || !h->ws || !h->G) return MMHIP_E_STATE;
+    if (!adam_m || !adam_v || !onehot || step < 1) return MMHIP_E_INVALID;
+    if (use_itm && (!itm_src || !lbl_tim)) return MMHIP_E_INVALID;
+    mmhip_early& e = *h;
+    hipStream_t s = (hipStream_t)stream;
+    CHECK_RC(forward_impl(h, ids, mask, token_type_ids, feats, boxes, nullptr, nullptr, nullptr, use_itm ? itm_src : nullptr, B, T, Nb, 1, seed, nullptr, nullptr, nullptr,
+                          nullptr, stream));
+    CHECK_RC(mmhip_early_loss(h, onehot, class_w, use_itm ? lbl_tim : nullptr, w_cls, use_itc ? w_itc : 0.f, use_itm ? w_itm : 0.f, loss, nullptr, stream));
+    CHECK_RC(backward_impl(e, nullptr, nullptr, nullptr, s, on_stage, user));
+    // AdamW over the merged ranges of the active groups, in address order
+    bool act[6] = {false, use_itc != 0, use_itm != 0, false, true, false};
+    uint64_t rb = 0, re = 0;
+    bool open = false;
+    AdamWArgs a;
+    memset(&a, 0, sizeof(a));
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)beta1, step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+    a.zero_grad = 1; a.grad_scale = grad_scale;
+    auto flush = [&]() -> int {
+        if (!open || re <= rb) return 0;
+        a.p = e.P + rb; a.g = e.G + rb; a.m = adam_m + rb; a.v = adam_v + rb; a.n = re - rb;
+        CHECK_HIP(launch_adamw(a, s));
+        return 0;
+    };
+    for (const auto& p : e.params) {
+        if (!act[p.group]) continue;
+        const uint64_t b = p.offset, en = p.offset + ((p.numel + 3) & ~(uint64_t)3);
+        if (open && b == re) { re = en; continue; }
+        CHECK_RC(flush());
+        rb = b; re = en; open = true;
+    }
+    CHECK_RC(flush());
+    return refresh(e, s);
 }
 
 }  // extern "C"
