@@ -210,6 +210,11 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
  *                       word-table exchange (it travelled meanwhile); the row-lazy AdamW of the table follows.
  * A non-zero return aborts the step with that code.  grad_scale = 1 / world.  Everything else as mmhip_train_step. */
 enum { MMHIP_CB_WAIT_DENSE = -1, MMHIP_CB_FINISH_ROWS = -2 };
+/* on_stage(user, MMHIP_CB_WAIT_DENSE) may return MMHIP_CB_HANDLED instead of 0: the caller has run the optimizer over the DENSE parameter
+ * ranges itself (sharded: reduce-scatter of the gradients, AdamW on the rank's own shard with moments only it keeps, all-gather of the updated
+ * parameters -- smtc_amd/dist.py ShardedBuckets); the library then skips its dense AdamW launches and goes on with the 16-bit weight refresh
+ * and the word-table rows (adam_m / adam_v are then only dereferenced over the word table's range). */
+enum { MMHIP_CB_HANDLED = 1 };
 typedef int (*mmhip_exchange_cb)(void* user, int stage);
 int mmhip_train_step_dp(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
                         const int64_t* tim_mask, const int64_t* lbl_tim, const int64_t* onehot, const float* class_w, int B, int T,

@@ -51,6 +51,7 @@ class MMHipError(RuntimeError):
 
 EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)      # include/mmhip.h: mmhip_exchange_cb
 CB_WAIT_DENSE, CB_FINISH_ROWS = -1, -2
+CB_HANDLED = 1               # include/mmhip.h MMHIP_CB_HANDLED: the caller ran the dense optimizer itself
 _lib = None
 P, I, F, U64, U32, I64P = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p
 

@@ -160,6 +160,33 @@ __global__ __launch_bounds__(256) void pad_bias_kernel(const float* __restrict__
     out[idx] = k < L ? (in ? in[(size_t)b * L + k] : 0.f) : -INFINITY;
 }
 
+// dW[n][c] += sum_m dY[m][n] X[m][c] for a handful of columns c (box_fc: 4 box coordinates) -- the generic fallback of gemm_tn walked all M rows in
+// 4 threads per output row (410 us per step); here a block owns 64 n x 256 rows, thread = (n, c), coalesced over n, one atomic per output and block.
+// colsum[n] += sum_m dY[m][n] from the threads of c == 0.  The targets are zero on entry (the step's AdamW clears the gradient buffer).
+template <typename T>
+__global__ __launch_bounds__(256) void tn_few_cols_kernel(const T* __restrict__ dy, int ldy, const T* __restrict__ x, int ldx, float* __restrict__ C, float* __restrict__ colsum,
+                                                          int M, int Nn, int Nc) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), c = threadIdx.x >> 6;
+    if (n >= Nn || c >= Nc) return;
+    const int m0 = blockIdx.y * 256, m1 = min(M, m0 + 256);
+    float acc = 0.f, cs = 0.f;
+    for (int m = m0; m < m1; ++m) {
+        const float d = to_f<T>(dy[(size_t)m * ldy + n]);
+        acc += d * to_f<T>(x[(size_t)m * ldx + c]);
+        cs += d;
+    }
+    atomicAdd(C + (size_t)n * Nc + c, acc);
+    if (colsum && c == 0) atomicAdd(colsum + n, cs);
+}
+hipError_t launch_tn_few_cols(const void* dy, int ldy, const void* x, int ldx, float* C, float* colsum, int M, int Nn, int Nc, int dtype, hipStream_t s) {
+    if (Nc > 4 || M <= 0) return hipErrorInvalidValue;
+    const dim3 grid((Nn + 63) / 64, (M + 255) / 256);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(tn_few_cols_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, C, colsum, M, Nn, Nc);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(tn_few_cols_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)dy, ldy, (const f16_t*)x, ldx, C, colsum, M, Nn, Nc);
+    else hipLaunchKernelGGL(tn_few_cols_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, ldy, (const float*)x, ldx, C, colsum, M, Nn, Nc);
+    return hipGetLastError();
+}
+
 inline int cap(size_t work) { size_t g = (work + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 
 DropCfg drop_cfg(float p, uint64_t seed, uint32_t stream, bool on) {
@@ -199,8 +226,9 @@ struct mmhip_early {
     int B = 0, Bt = 0, T = 0, Nb = 0; bool itm = false, train = false, fwd_done = false, itc_done = false;
     uint64_t seed = 0;
     const float *bd_out = nullptr, *bd_embv = nullptr, *bd_tim = nullptr;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_l = nullptr, ev_v = nullptr, ev_l2 = nullptr, ev_v2 = nullptr;
+    hipStream_t side = nullptr;          // vision stream
+    hipStream_t wside = nullptr;         // weight-gradient stream: a layer's grouped dW launches run beside the activation-gradient chains of the layers below
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_l = nullptr, ev_v = nullptr, ev_l2 = nullptr, ev_v2 = nullptr, ev_lw = nullptr, ev_vw = nullptr, ev_w = nullptr;
     int overlap = -1;
 
     template <typename U> U* wsp(size_t off) const { return reinterpret_cast<U*>(ws + off); }
@@ -397,12 +425,14 @@ int side_init(mmhip_early& e) {
     if (e.overlap < 0) { const char* v = getenv("MMHIP_EARLY_STREAMS"); e.overlap = v ? atoi(v) : 1; }
     if (e.side) return 0;
     CHECK_HIP(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
-    hipEvent_t* evs[6] = {&e.ev_fork, &e.ev_join, &e.ev_l, &e.ev_v, &e.ev_l2, &e.ev_v2};
+    CHECK_HIP(hipStreamCreateWithFlags(&e.wside, hipStreamNonBlocking));
+    hipEvent_t* evs[9] = {&e.ev_fork, &e.ev_join, &e.ev_l, &e.ev_v, &e.ev_l2, &e.ev_v2, &e.ev_lw, &e.ev_vw, &e.ev_w};
     for (auto ev : evs) CHECK_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     return 0;
 }
 // the vision stream of this call: the internal one, or the caller's when MMHIP_EARLY_STREAMS=0
 inline hipStream_t vstream(const mmhip_early& e, hipStream_t s) { return e.overlap > 0 ? e.side : s; }
+inline hipStream_t wstream(const mmhip_early& e, hipStream_t s) { return e.overlap > 0 ? e.wside : s; }
 inline int order(const mmhip_early& e, hipEvent_t ev, hipStream_t from, hipStream_t to) {      // `to` continues after everything enqueued on `from` so far
     if (from == to) return 0;
     CHECK_HIP(hipEventRecord(ev, from));
@@ -686,12 +716,37 @@ int num_stages(const mmhip_early& e) {
     return 1 + (int)e.xl.size() + depth + 1;
 }
 
+// AdamW + operand refresh of one layer stage on the weight-gradient stream, right behind the stage's grouped dW launches: an HBM-bound update beside the
+// MFMA-bound activation-gradient chains of the stages below instead of 1.4 + 0.45 ms at the end of the step (LXMERT: 213 M parameters, 6.8 GB of
+// optimizer traffic).  Single rank only: under data parallelism the optimizer waits for the exchange.
+struct StageOpt { AdamWArgs a; float* m; float* v; };
+int stage_refresh(mmhip_early& e, int stage, hipStream_t s) {
+    const int H = e.cfg.hidden, I = e.cfg.inter, X = (int)e.xl.size();
+    std::vector<CastMat> mats;
+    auto add = [&](size_t off, const Copy& k, int rows, int cols) { mats.push_back(CastMat{e.P + off, e.ws + k.w, k.wT ? e.ws + k.wT : nullptr, rows, cols, 0}); };
+    auto att = [&](const AttOff& o, const AttW& a) { add(o.qkv_w, a.qkv, 3 * H, H); add(o.o_w, a.o, H, H); };
+    auto ffn = [&](const FfnOff& o, const FfnW& f) { add(o.w1, f.w1, I, H); add(o.w2, f.w2, H, I); };
+    if (stage <= X) {
+        XLayer& x = e.xl[X - stage];
+        att(x.cross, x.cw); att(x.lself, x.lw); att(x.vself, x.vw); ffn(x.lffn, x.lfw); ffn(x.vffn, x.vfw);
+    } else {
+        const int d = stage - X - 1, li = (int)e.lang.size() - 1 - d, ri = (int)e.rel.size() - 1 - d;
+        if (li >= 0) { att(e.lang[li].att, e.lang[li].aw); ffn(e.lang[li].ffn, e.lang[li].fw); }
+        if (ri >= 0) { att(e.rel[ri].att, e.rel[ri].aw); ffn(e.rel[ri].ffn, e.rel[ri].fw); }
+    }
+    for (size_t i = 0; i < mats.size(); i += CAST_MAX_GROUP) {
+        const int n = (int)(mats.size() - i < (size_t)CAST_MAX_GROUP ? mats.size() - i : (size_t)CAST_MAX_GROUP);
+        CHECK_HIP(launch_cast_group(mats.data() + i, n, e.dt(), s));
+    }
+    return 0;
+}
+
 // stage: 0 heads | 1 .. X cross-modality layers last -> first | X+1 .. X+D language / relational layers by depth below the cross layers | X+D+1 inputs
 int backward_stage(mmhip_early& e, int stage, const char** dlang_io, const char** dvisn_io, hipStream_t s) {
     const mmhip_early_config& c = e.cfg;
     const int H = c.hidden, Bt = e.Bt, T = e.T, Nb = e.Nb, ML = Bt * T, MV = Bt * Nb, S = e.S(), dt = e.dt();
     const int X = (int)e.xl.size(), D = (int)(e.lang.size() > e.rel.size() ? e.lang.size() : e.rel.size());
-    hipStream_t sv = vstream(e, s);
+    hipStream_t sv = vstream(e, s), sw = wstream(e, s);
     const float* lbias = e.wsp<float>(e.lbias);
     const float* vbias = e.wsp<float>(e.vbias);
     const float* lbias_x = T == S ? lbias : e.wsp<float>(e.lbias_x);
@@ -727,9 +782,12 @@ int backward_stage(mmhip_early& e, int stage, const char** dlang_io, const char*
         *dvisn_io = e.ws + x.cv.dxq;
         // weight gradients: each stream's own blocks as plain stores; the ONE cross-attention module both directions used accumulates both
         // contributions, on the language stream (it has waited for the vision stream's cross block above)
-        CHECK_RC(tl.flush(dt, 0, s));
-        CHECK_RC(tv.flush(dt, 0, sv));
-        CHECK_RC(tshared.flush(dt, 1, s));
+        // ... all of it on the weight-gradient stream, behind both chains of this layer
+        CHECK_RC(order(e, e.ev_lw, s, sw));
+        CHECK_RC(order(e, e.ev_vw, sv, sw));
+        CHECK_RC(tl.flush(dt, 0, sw));
+        CHECK_RC(tv.flush(dt, 0, sw));
+        CHECK_RC(tshared.flush(dt, 1, sw));
         return 0;
     }
     if (stage <= X + D) {
@@ -741,7 +799,8 @@ int backward_stage(mmhip_early& e, int stage, const char** dlang_io, const char*
             const char* xin = li ? e.ws + e.lang[li - 1].fa.y : e.ws + e.x0;
             CHECK_RC(ffn_bwd(e, l.ffn, l.fw, l.fa, *dlang_io, e.ws + l.sa.y, ML, b0 + 1, tn, s));
             CHECK_RC(self_bwd(e, l.att, l.aw, l.sa, e.ws + l.fa.dx, xin, lbias, Bt, T, b0, tn, s));
-            CHECK_RC(tn.flush(dt, 0, s));
+            CHECK_RC(order(e, e.ev_lw, s, sw));
+            CHECK_RC(tn.flush(dt, 0, sw));
             *dlang_io = e.ws + l.sa.dx;
         }
         if (ri >= 0) {
@@ -751,7 +810,8 @@ int backward_stage(mmhip_early& e, int stage, const char** dlang_io, const char*
             const char* xin = ri ? e.ws + e.rel[ri - 1].fa.y : e.ws + e.v0;
             CHECK_RC(ffn_bwd(e, l.ffn, l.fw, l.fa, *dvisn_io, e.ws + l.sa.y, MV, b0 + 1, tn, sv));
             CHECK_RC(self_bwd(e, l.att, l.aw, l.sa, e.ws + l.fa.dx, xin, vbias, Bt, Nb, b0, tn, sv));
-            CHECK_RC(tn.flush(dt, 0, sv));
+            CHECK_RC(order(e, e.ev_vw, sv, sw));
+            CHECK_RC(tn.flush(dt, 0, sw));
             *dvisn_io = e.ws + l.sa.dx;
         }
         return 0;
@@ -783,10 +843,12 @@ int backward_stage(mmhip_early& e, int stage, const char** dlang_io, const char*
         CHECK_HIP(launch_layernorm_bwd(b2, dt, sv));
         TNQueue tn;
         tn.add(e.ws + e.dvf_pre, H, e.ws + e.feats16, c.feat_dim, e.G + e.visn_fc_w, MV, H, c.feat_dim, e.G + e.visn_fc_b);
-        tn.add(e.ws + e.dbx_pre, H, e.ws + e.boxes16, c.pos_dim, e.G + e.box_fc_w, MV, H, c.pos_dim, e.G + e.box_fc_b);
+        if (c.pos_dim <= 4) CHECK_HIP(launch_tn_few_cols(e.ws + e.dbx_pre, H, e.ws + e.boxes16, c.pos_dim, e.G + e.box_fc_w, e.G + e.box_fc_b, MV, H, c.pos_dim, dt, sv));
+        else tn.add(e.ws + e.dbx_pre, H, e.ws + e.boxes16, c.pos_dim, e.G + e.box_fc_w, MV, H, c.pos_dim, e.G + e.box_fc_b);
         CHECK_RC(tn.flush(dt, 0, sv));
     }
     CHECK_RC(order(e, e.ev_join, sv, s));
+    CHECK_RC(order(e, e.ev_w, sw, s));          // every weight gradient is final in the caller's stream order
     return 0;
 }
 
@@ -815,9 +877,10 @@ void mmhip_early_destroy(mmhip_early_handle h) {
     if (!h) return;
     if (h->side) {
         (void)hipStreamSynchronize(h->side);
-        for (hipEvent_t ev : {h->ev_fork, h->ev_join, h->ev_l, h->ev_v, h->ev_l2, h->ev_v2})
+        for (hipEvent_t ev : {h->ev_fork, h->ev_join, h->ev_l, h->ev_v, h->ev_l2, h->ev_v2, h->ev_lw, h->ev_vw, h->ev_w})
             if (ev) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(h->side);
+        if (h->wside) { (void)hipStreamSynchronize(h->wside); (void)hipStreamDestroy(h->wside); }
     }
     delete h;
 }
@@ -947,7 +1010,8 @@ int mmhip_early_loss(mmhip_early_handle h, const int64_t* onehot, const float* c
 // mmhip_backward's: the gradient buffer is zero on entry over the ranges that receive gradients (LayerNorm weights, embedding rows, heads and
 // the shared cross-attention module accumulate; the other weight gradients are plain stores).  NULL pointers: the gradients mmhip_early_loss
 // left in the handle; else explicit fp32 output gradients d_out [B, C], d_emb_v [B, H] (may be NULL), d_out_tim [B, 2] (may be NULL).
-static int backward_impl(mmhip_early& e, const float* d_out, const float* d_emb_v, const float* d_out_tim, hipStream_t s, mmhip_exchange_cb cb, void* user) {
+static int backward_impl(mmhip_early& e, const float* d_out, const float* d_emb_v, const float* d_out_tim, hipStream_t s, mmhip_exchange_cb cb, void* user,
+                         const StageOpt* opt = nullptr) {
     if (!e.fwd_done || !e.G) return MMHIP_E_STATE;
     if (d_out) { e.bd_out = d_out; e.bd_embv = d_emb_v; e.bd_tim = d_out_tim; }
     else if (!e.bd_out) return MMHIP_E_STATE;
@@ -957,9 +1021,19 @@ static int backward_impl(mmhip_early& e, const float* d_out, const float* d_emb_
     hipStream_t sv = vstream(e, s);
     for (int st = 0; st < n; ++st) {
         CHECK_RC(backward_stage(e, st, &dl, &dv, s));
+        if (opt && st >= 1 && st < n - 1) {
+            uint64_t b = 0, en = 0;
+            CHECK_RC(mmhip_early_stage_grad_range(&e, st, &b, &en));
+            AdamWArgs a = opt->a;
+            a.p = e.P + b; a.g = e.G + b; a.m = opt->m + b; a.v = opt->v + b; a.n = en - b;
+            hipStream_t sw = wstream(e, s);
+            CHECK_HIP(launch_adamw(a, sw));
+            CHECK_RC(stage_refresh(e, st, sw));
+        }
         if (cb && st >= 1) {
-            // stage st-1's gradients are final once its work on BOTH streams is ordered into the caller's stream
+            // stage st-1's gradients are final once its work on the vision and the weight-gradient stream is ordered into the caller's stream
             CHECK_RC(order(e, e.ev_v2, sv, s));
+            CHECK_RC(order(e, e.ev_l2, wstream(e, s), s));
             CHECK_RC(cb(user, st - 1));
         }
     }
@@ -988,17 +1062,24 @@ int mmhip_early_train_step(mmhip_early_handle h, const int64_t* ids, const int64
     CHECK_RC(forward_impl(h, ids, mask, token_type_ids, feats, boxes, nullptr, nullptr, nullptr, use_itm ? itm_src : nullptr, B, T, Nb, 1, seed, nullptr, nullptr, nullptr,
                           nullptr, stream));
     CHECK_RC(mmhip_early_loss(h, onehot, class_w, use_itm ? lbl_tim : nullptr, w_cls, use_itc ? w_itc : 0.f, use_itm ? w_itm : 0.f, loss, nullptr, stream));
-    CHECK_RC(backward_impl(e, nullptr, nullptr, nullptr, s, on_stage, user));
-    // AdamW over the merged ranges of the active groups, in address order
-    bool act[6] = {false, use_itc != 0, use_itm != 0, false, true, false};
-    uint64_t rb = 0, re = 0;
-    bool open = false;
     AdamWArgs a;
     memset(&a, 0, sizeof(a));
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
     a.bc1 = (float)(1.0 - pow((double)beta1, step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
     a.zero_grad = 1; a.grad_scale = grad_scale;
+    const char* early_env = getenv("MMHIP_EARLY_ADAMW");
+    const bool layer_opt = !on_stage && e.overlap != 0 && (early_env ? atoi(early_env) != 0 : true);
+    StageOpt so{a, adam_m, adam_v};
+    CHECK_RC(side_init(e));
+    CHECK_RC(backward_impl(e, nullptr, nullptr, nullptr, s, on_stage, user, layer_opt && e.overlap > 0 ? &so : nullptr));
+    const bool stepped = layer_opt && e.overlap > 0;
+    uint64_t lb = 0, le = 0;          // the layer stages' ranges are contiguous: [first x layer's begin, vin_begin)
+    if (stepped) { lb = e.heads_end; le = e.vin_begin; }
+    // AdamW over the merged ranges of the active groups, in address order (the layer stages already stepped on the weight-gradient stream)
+    bool act[6] = {false, use_itc != 0, use_itm != 0, false, true, false};
+    uint64_t rb = 0, re = 0;
+    bool open = false;
     auto flush = [&]() -> int {
         if (!open || re <= rb) return 0;
         a.p = e.P + rb; a.g = e.G + rb; a.m = adam_m + rb; a.v = adam_v + rb; a.n = re - rb;
@@ -1006,13 +1087,18 @@ int mmhip_early_train_step(mmhip_early_handle h, const int64_t* ids, const int64
         return 0;
     };
     for (const auto& p : e.params) {
-        if (!act[p.group]) continue;
+        if (!act[p.group] || (stepped && p.offset >= lb && p.offset < le)) continue;
         const uint64_t b = p.offset, en = p.offset + ((p.numel + 3) & ~(uint64_t)3);
         if (open && b == re) { re = en; continue; }
         CHECK_RC(flush());
         rb = b; re = en; open = true;
     }
     CHECK_RC(flush());
+    if (stepped) {          // only the visual-feature encoder's matrices are left to refresh
+        CastMat m2[2] = {{e.P + e.visn_fc_w, e.ws + e.c_visn_fc.w, nullptr, e.cfg.hidden, e.cfg.feat_dim, 0}, {e.P + e.box_fc_w, e.ws + e.c_box_fc.w, nullptr, e.cfg.hidden, e.cfg.pos_dim, 0}};
+        CHECK_HIP(launch_cast_group(m2, 2, e.dt(), s));
+        return 0;
+    }
     return refresh(e, s);
 }
 

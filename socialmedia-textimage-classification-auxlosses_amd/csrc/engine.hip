@@ -1470,7 +1470,7 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
     // about stage st-1 once stage st is enqueued and st-1's weight gradients are ordered in the caller's stream -- its collective
     // travels while the stages below compute
     const bool layer_opt = early && use_side(e) && !cb;
-    bool opt_pending = false;
+    bool opt_pending = false, dense_by_caller = false;
     for (int st = 0; st < L + 2; ++st) {
         if (int r = mmhip_backward_stage(h, st, stream)) return r;
         if (cb && st >= 1) {
@@ -1493,7 +1493,11 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
     if (opt_pending) CHECK_HIP(hipStreamWaitEvent(s, e.ev_opt, 0));
     if (cb) {
         if (int r = cb(user, L + 1)) return r;                    // embedding stage: dense part + the row-sparse word-table exchange start
-        if (int r = cb(user, MMHIP_CB_WAIT_DENSE)) return r;      // the dense all-reduces are ordered before what follows in `stream`
+        // the dense exchanges are ordered before what follows in `stream`; MMHIP_CB_HANDLED: the caller also ran the dense optimizer itself
+        // (reduce-scatter -> AdamW on its shard -> all-gather of the parameters: dist.ShardedBuckets) -- the dense AdamW launches below are skipped
+        const int r = cb(user, MMHIP_CB_WAIT_DENSE);
+        if (r == MMHIP_CB_HANDLED) dense_by_caller = true;
+        else if (r) return r;
     }
     if (int r = e.span(4, s)) return r;
     // merged [begin, end) ranges of the active gradient groups, in address order (text layers already stepped: skipped)
@@ -1505,7 +1509,7 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
     auto flush = [&]() -> int {
         if (!open || re <= rb) return 0;
         const uint64_t dense_end = re < w0 ? re : w0;
-        if (dense_end > rb)
+        if (dense_end > rb && !dense_by_caller)
             if (int r = adamw_impl(e.train + rb, e.grad + rb, adam_m + rb, adam_v + rb, dense_end - rb, lr, beta1, beta2, eps, weight_decay, step,
                                    grad_scale, 1, stream, gc, gf)) return r;
         if (re > w0) rows_due = true;          // the word table goes last: under data parallelism its rows are still travelling

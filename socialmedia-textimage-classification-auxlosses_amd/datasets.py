@@ -229,9 +229,16 @@ def loaders_from_data_key(cfg, args, trainer):
         kw.update(persistent_workers=True, prefetch_factor=4, worker_init_fn=worker_init)
     inner = None
     if gpu:
-        from .image_processing import GpuImageProcessor, RawImageCollate
+        from .image_processing import GpuImageProcessor, RawImageCollate, RingCollate, SharedImageRing
         trainer.image_processor = GpuImageProcessor(size=size, device=trainer.device)
         inner = RawImageCollate(trainer.image_processor)
+        if kw["num_workers"] > 0 and os.environ.get("MMHIP_IMAGE_RING", "1") != "0":
+            # decoded images reach the training process through a pinned shared-memory ring instead of the DataLoader's result queue
+            # (image_processing.SharedImageRing); a batch that does not fit its slot falls back to the queue
+            slot_mb = float(os.environ.get("MMHIP_RING_SLOT_MB", str(1.5 * cfg.batch_size)))
+            slots = min(kw["num_workers"] * 4 + 6, max(4, int(4096 / slot_mb)))
+            trainer.image_ring = SharedImageRing(slots, int(slot_mb * (1 << 20)))
+            inner = RingCollate(trainer.image_processor, trainer.image_ring)
         kw["collate_fn"] = inner
     if batch_tok:
         kw["collate_fn"] = BatchTokenizeCollate(tok, cfg.max_length, inner)

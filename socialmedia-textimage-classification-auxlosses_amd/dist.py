@@ -159,6 +159,83 @@ class StageBuckets:
         self.begin = self.end = None
 
 
+def _reduce_scatter_inplace(flat, b, s, W):
+    """sum over ranks of flat[b : b + W s]; afterwards rank r's shard flat[b + r s : b + (r + 1) s] holds the sum of that shard (the other
+    shards are scratch).  RCCL: one in-place reduce-scatter (recvbuff = sendbuff + rank * count); gloo (CPU tests) has no reduce-scatter: an
+    all-reduce of the slice gives every rank every shard's sum, of which only the own one is used."""
+    if td.get_backend() == "nccl":
+        r = rank()
+        return td.reduce_scatter_tensor(flat[b + r * s: b + (r + 1) * s], flat[b: b + W * s], op=td.ReduceOp.SUM, async_op=True)
+    return td.all_reduce(flat[b: b + W * s], op=td.ReduceOp.SUM, async_op=True)
+
+
+def _all_gather_inplace(flat, b, s, W):
+    """every rank's shard flat[b + r s : b + (r + 1) s] into all ranks' flat[b : b + W s]"""
+    r = rank()
+    if td.get_backend() == "nccl":
+        return td.all_gather_into_tensor(flat[b: b + W * s], flat[b + r * s: b + (r + 1) * s], async_op=True)
+    return td.all_gather([flat[b + i * s: b + (i + 1) * s] for i in range(W)], flat[b + r * s: b + (r + 1) * s].clone(), async_op=True)
+
+
+class ShardedBuckets(StageBuckets):
+    """Gradient exchange + optimizer of the dense ranges as reduce-scatter -> AdamW on the rank's own shard -> all-gather (ZeRO stage 1), selectable
+    beside the bucketed all-reduce (MMHIP_DP_OPT=shard).  A bucket [b, e) is cut into W equal shards of s elements (s a multiple of 4); the < 4 W
+    elements left at its end take a plain all-reduce and a replicated update.  Rank r receives the summed gradient of shard r only and updates
+    only those parameters, with moments it alone keeps: 1/W of the optimizer state, of the AdamW traffic (2.9 GB per step and GPU for the
+    replicated update of Bernice's dense part) and of its launches' time; the ring moves the same bytes as an all-reduce (reduce-scatter + all-gather
+    ARE its two halves).  Replicas stay bit-identical: every parameter has exactly one writer, the others receive its bytes."""
+
+    def __init__(self, flat_grad):
+        super().__init__(flat_grad)
+        self.plan = []            # (b, s, e, reduce-scatter Work, tail all-reduce Work)
+
+    def flush(self):
+        if self.begin is not None and self.end > self.begin:
+            b, e, W = self.begin, self.end, world_size()
+            s = ((e - b) // (4 * W)) * 4
+            rs = _reduce_scatter_inplace(self.flat, b, s, W) if s > 0 else None
+            ar = allreduce_range(self.flat, b + W * s, e) if e > b + W * s else None
+            self.plan.append((b, s, e, rs, ar))
+            self.bytes += (e - b) * 4
+        self.begin = self.end = None
+
+    def own_ranges(self):
+        """[(begin, end, replicated)] of the gradient elements this rank holds the SUM of after the waits: its shard of every bucket, and the tails"""
+        r, W, out = rank(), world_size(), []
+        for b, s, e, rs, ar in self.plan:
+            if rs is not None:
+                rs.wait()
+            if ar is not None:
+                ar.wait()
+            if s > 0:
+                out.append((b + r * s, b + (r + 1) * s, False))
+            if e > b + W * s:
+                out.append((b + W * s, e, True))
+        return out
+
+    def gather_params(self, flat_param):
+        W = world_size()
+        works = [_all_gather_inplace(flat_param, b, s, W) for b, s, e, _, _ in self.plan if s > 0]
+        for w in works:
+            w.wait()
+
+
+class ShardMoments:
+    """AdamW moments of the ranges a rank owns under ShardedBuckets, stored compactly (the bucket plan is the same every step: keyed by range)"""
+
+    def __init__(self, device):
+        self.device, self.buf = device, {}
+
+    def get(self, b, e):
+        k = (b, e)
+        if k not in self.buf:
+            self.buf[k] = (torch.zeros(e - b, dtype=torch.float32, device=self.device), torch.zeros(e - b, dtype=torch.float32, device=self.device))
+        return self.buf[k]
+
+    def numel(self):
+        return sum(m.numel() for m, _ in self.buf.values())
+
+
 def exchange_stage(model, stage, n_stage, use_itc, use_itm, finishers=None, buckets=None):
     """called right after backward stage `stage` was enqueued; returns async Work handles to wait on before AdamW.  With a
     `finishers` list the word-table exchange of the last stage is only started here: the caller runs the appended callable

@@ -46,9 +46,10 @@ class GpuImageProcessor:
         return self._lut
 
     # ---- host half: pack the decoded images and build the resampling plan (no GPU call)
-    def pack(self, images, pin=True):
+    def pack(self, images, pin=True, alloc=None):
         """-> (packed uint8 [total + 16], plan int32 [words], n).  Host work only (no kernel launch): usable as / inside a
-        DataLoader collate_fn; pass pin=False inside worker processes."""
+        DataLoader collate_fn; pass pin=False inside worker processes.  alloc(nbytes) -> uint8 tensor | None: where to pack instead of a
+        fresh tensor (a slot of the shared pinned ring, SharedImageRing)."""
         lib = _lib.lib()
         arrs = [_as_rgb_u8(im) for im in images]
         n, S = len(arrs), self.size["height"]
@@ -58,7 +59,9 @@ class GpuImageProcessor:
         offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64) if n else np.zeros(0, dtype=np.uint64)
         total = int(sizes.sum())
         # +16: the row-staging kernel reads whole 16-byte chunks; pinned directly when a GPU is present (one host copy)
-        packed = torch.empty(total + 16, dtype=torch.uint8, pin_memory=pin and torch.cuda.is_available())
+        packed = alloc(total + 16) if alloc is not None else None
+        if packed is None:
+            packed = torch.empty(total + 16, dtype=torch.uint8, pin_memory=pin and torch.cuda.is_available())
         pk = packed.numpy()
         for a, o in zip(arrs, offs):
             pk[int(o): int(o) + a.size] = a.reshape(-1)
@@ -116,6 +119,77 @@ class RawImageCollate:
         return batch
 
 
+class SharedImageRing:
+    """Decoded images travel from the DataLoader workers to the training process WITHOUT passing through the DataLoader's result queue: a
+    ring of fixed-size slots in shared memory, page-locked in the training process (hipHostRegister), written by the workers' collate
+    (RingCollate) and read by the asynchronous host-to-device copy as it stands.  Before, a 33 MB batch (64 decoded 480 x 360 posts) was a torch
+    tensor handed over through a shared-memory file per batch (created, mapped, passed as a descriptor, unmapped), then copied into a pinned
+    staging buffer by the training thread; the loader fed 0.66 of the step (profiles/r03_loader_bench.txt) with neither side out of cores.
+    Slots are handed out through a queue of free slot numbers (back-pressure: a worker waits for a slot) and returned by the prefetcher once
+    the copy out of them has completed.  Create it BEFORE the DataLoader forks its workers; decoded bytes are exactly what PIL produced
+    (no draft-mode decode): bit-exactness of the image leg is untouched."""
+
+    def __init__(self, slots, slot_bytes, register=True):
+        import multiprocessing
+        self.slots, self.slot_bytes = int(slots), (int(slot_bytes) + 4095) // 4096 * 4096
+        self.buf = torch.empty(self.slots * self.slot_bytes, dtype=torch.uint8).share_memory_()
+        self.free = multiprocessing.Queue()
+        for i in range(self.slots):
+            self.free.put(i)
+        self.pinned = False
+        if register and torch.cuda.is_available():
+            rc = torch.cuda.cudart().cudaHostRegister(self.buf.data_ptr(), self.buf.numel(), 0)
+            self.pinned = int(rc) == 0
+        self.fallbacks = 0
+
+    def view(self, slot, nbytes):
+        o = slot * self.slot_bytes
+        return self.buf[o: o + nbytes]
+
+    def take(self, nbytes, timeout=20.0):
+        """(slot, uint8 view) or (None, None) when the batch does not fit a slot or no slot came free in time (the caller packs a plain tensor)"""
+        if nbytes > self.slot_bytes:
+            return None, None
+        try:
+            slot = self.free.get(timeout=timeout)
+        except Exception:
+            return None, None
+        return slot, self.view(slot, nbytes)
+
+    def release(self, slot):
+        self.free.put(int(slot))
+
+    def close(self):
+        if self.pinned:
+            torch.cuda.cudart().cudaHostUnregister(self.buf.data_ptr())
+            self.pinned = False
+
+
+class RingCollate:
+    """RawImageCollate writing the packed images into a SharedImageRing slot: the batch that crosses the DataLoader queue carries the slot
+    number, the byte count and the (small) resampling plan instead of the image bytes"""
+
+    def __init__(self, processor, ring):
+        self.proc, self.ring = processor, ring
+
+    def __call__(self, items):
+        from torch.utils.data import default_collate, get_worker_info
+        got = {}
+
+        def alloc(nbytes):
+            slot, view = self.ring.take(nbytes)
+            got["slot"], got["bytes"] = slot, nbytes
+            return view
+        packed, plan, n = self.proc.pack([it["image"] for it in items], pin=get_worker_info() is None, alloc=alloc)
+        batch = default_collate([{k: v for k, v in it.items() if k != "image"} for it in items])
+        if got.get("slot") is not None:
+            batch["image_slot"], batch["image_bytes"] = int(got["slot"]), int(got["bytes"])
+        else:
+            batch["image_packed"] = packed
+        batch["image_plan"], batch["image_count"] = plan, n
+        return batch
+
+
 class DevicePrefetcher:
     """Keeps `depth` batches in flight to the GPU: pinned staging + non-blocking copies on a side stream, so the training
     stream never waits on a pageable host-to-device copy (a 38 MB pixel batch otherwise serialises with the step).
@@ -124,8 +198,9 @@ class DevicePrefetcher:
     _streams = {}        # one copy stream per device for every prefetcher: the caching allocator pools blocks per stream, and a
                          # fresh stream per epoch strands the previous one's cached blocks (reserved memory grew 0.1-0.3 GiB per instance)
 
-    def __init__(self, loader, device, processor=None, depth=2, trim_padding=True):
+    def __init__(self, loader, device, processor=None, depth=2, trim_padding=True, ring=None):
         self.loader, self.device, self.proc, self.depth = loader, torch.device(device), processor, max(1, depth)
+        self.ring, self._held = ring, []          # ring slots whose host-to-device copy is still in flight: (slot, event)
         key = (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
         if key not in DevicePrefetcher._streams:
             DevicePrefetcher._streams[key] = torch.cuda.Stream(device=self.device)
@@ -157,13 +232,20 @@ class DevicePrefetcher:
         out = {}
         if self.trim_padding:
             batch = self.trim(batch)
+        self._reclaim()
+        slot = None
         with torch.cuda.stream(self.stream):
-            if "image_packed" in batch:
+            if "image_slot" in batch:
+                if self.proc is None or self.ring is None:
+                    raise ValueError("ring batches need a GpuImageProcessor and the SharedImageRing they were written to")
+                slot = int(batch["image_slot"])
+                out["pixel_values"] = self.proc.run(self.ring.view(slot, int(batch["image_bytes"])), batch["image_plan"], int(batch["image_count"]))
+            elif "image_packed" in batch:
                 if self.proc is None:
                     raise ValueError("raw-image batches need a GpuImageProcessor")
                 out["pixel_values"] = self.proc.run(batch["image_packed"], batch["image_plan"], int(batch["image_count"]))
             for k, v in batch.items():
-                if k in ("image_packed", "image_plan", "image_count"):
+                if k in ("image_packed", "image_plan", "image_count", "image_slot", "image_bytes"):
                     continue
                 if torch.is_tensor(v) and k != "data_id":
                     h = v if v.is_pinned() else v.pin_memory()
@@ -173,7 +255,21 @@ class DevicePrefetcher:
                     out[k] = v
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        if slot is not None:
+            self._held.append((slot, ev))
         return out, ev
+
+    def _reclaim(self, wait=False):
+        """ring slots whose copy has completed go back to the workers"""
+        keep = []
+        for slot, ev in self._held:
+            if wait:
+                ev.synchronize()
+            if wait or ev.query():
+                self.ring.release(slot)
+            else:
+                keep.append((slot, ev))
+        self._held = keep
 
     def __iter__(self):
         it = iter(self.loader)
@@ -194,3 +290,5 @@ class DevicePrefetcher:
                 queue.append(self._stage(next(it)))
             except StopIteration:
                 pass
+        if self.ring is not None:
+            self._reclaim(wait=True)

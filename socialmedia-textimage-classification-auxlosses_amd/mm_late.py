@@ -454,6 +454,8 @@ class MMLate_Model(object):
         self.device = self.model.device_
         self._opt = None
         self.world = mmdist.world_size()
+        # MMHIP_DP_OPT=shard: reduce-scatter -> sharded AdamW -> all-gather for the dense ranges instead of all-reduce + replicated AdamW (dist.ShardedBuckets)
+        self.sharded_optimizer = os.environ.get("MMHIP_DP_OPT", "allreduce") == "shard"
         self.image_processor = None          # GpuImageProcessor when the loaders yield raw images (datasets.py)
 
     # ---- checkpoints (reference :343-345, :529-531): plain state_dict with the reference's keys
@@ -579,6 +581,7 @@ class MMLate_Model(object):
         m._nonfinite.zero_()                         # the throw-away step leaves no trace in the overflow guard either
         self._nf_seen, self._nf_clean, self._nf_pending = 0, 0, False
         self._opt = None                             # the moments of the throw-away step are dropped (the next step starts from zeros)
+        self._opt_rows = None
         m._word_row_state.zero_()
         if not torch.equal(before, m._flat_train):   # lr = 0: AdamW must have left every parameter untouched
             m._flat_train.copy_(before)
@@ -601,7 +604,8 @@ class MMLate_Model(object):
         if pixels.dim() != 4 or pixels.shape[0] != B or tuple(pixels.shape[1:]) != (3, m.arch["image"], m.arch["image"]):
             raise ValueError(f"pixel_values must be [{B},3,{m.arch['image']},{m.arch['image']}], got {tuple(pixels.shape)}")
         m._ensure(B, T)
-        em, ev = self._moments()
+        sharded = exchange and self.sharded_optimizer
+        em, ev = self._row_moments() if sharded else self._moments()
         m._calls += 1
         seed = (m._seed_base * 0x9E3779B97F4A7C15 + m._calls) & 0xFFFFFFFFFFFFFFFF
         w_cls, w_itc, w_itm = self.loss_weights()
@@ -610,13 +614,14 @@ class MMLate_Model(object):
             tim_mask = tim_mask.to(dev, torch.int64).contiguous()
         m._last = dict(B=B, T=T, itm=tim_ids is not None, seed=seed, ids=ids)
         args = (m._handle, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(pixels), _lib.ptr(tim_ids), _lib.ptr(tim_mask), _lib.ptr(lbl_tim), _lib.ptr(onehot),
-                _lib.ptr(cw), B, T, seed, int(bool(self.use_clip_loss)), int(bool(self.use_tim_loss)), w_cls, w_itc, w_itm, _lib.ptr(em), _lib.ptr(ev),
+                _lib.ptr(cw), B, T, seed, int(bool(self.use_clip_loss)), int(bool(self.use_tim_loss)), w_cls, w_itc, w_itm, em if sharded else _lib.ptr(em),
+                ev if sharded else _lib.ptr(ev),
                 lr, 0.9, 0.999, 1e-8, weight_decay, step, 1.0 / self.world, _lib.ptr(loss), _lib.ptr(ncorr), _lib.stream_ptr())
         if not exchange:
             _lib.check(_lib.lib().mmhip_train_step(*args), "train_step")
         else:
             works, finishers, failure = [], [], []
-            buckets = mmdist.StageBuckets(m._flat_grad)
+            buckets = mmdist.ShardedBuckets(m._flat_grad) if sharded else mmdist.StageBuckets(m._flat_grad)
             n_stage = len(m._stage_ranges)
 
             def on_stage(_user, st):
@@ -628,6 +633,9 @@ class MMLate_Model(object):
                         for w in works + buckets.works:
                             w.wait()
                         self._share_guard_flag(True)
+                        if sharded:
+                            self._sharded_dense_update(buckets, lr, weight_decay, step)
+                            return _lib.CB_HANDLED
                     elif st == _lib.CB_FINISH_ROWS:
                         for f in finishers:
                             f()
@@ -644,6 +652,38 @@ class MMLate_Model(object):
         m._flat_train._version                                        # (read only; the refresh inside the call keeps the 16-bit copies current)
         m._weights_version = (m._flat_train._version, m._flat_frozen._version)
         return loss, ncorr
+
+    # ---- sharded optimizer of the dense ranges under data parallelism (MMHIP_DP_OPT=shard; dist.ShardedBuckets): reduce-scatter -> AdamW on the
+    # rank's own shard (moments only it keeps) -> all-gather of the updated parameters.  The word table keeps its row-sparse exchange and the
+    # replicated row-lazy update.
+    def _row_moments(self):
+        """moments of the word table only, handed to the engine as base pointers such that (base + word offset) is the buffer: with the dense
+        optimizer run by the caller the engine dereferences adam_m / adam_v over the word table's range only (include/mmhip.h MMHIP_CB_HANDLED)"""
+        m = self.model
+        if getattr(self, "_opt_rows", None) is None:
+            V, H = m._word_info["shape"]
+            self._opt_rows = (torch.zeros(V * H, dtype=torch.float32, device=self.device), torch.zeros(V * H, dtype=torch.float32, device=self.device))
+            self._opt_shards = mmdist.ShardMoments(self.device)
+            m._word_row_state.bitwise_and_(1)
+        w0 = m._word_info["offset"]
+        return tuple(C.c_void_p(t.data_ptr() - w0 * 4) for t in self._opt_rows)
+
+    def _sharded_dense_update(self, buckets, lr, weight_decay, step):
+        m, lib = self.model, _lib.lib()
+        at = lambda t, el: C.c_void_p(t.data_ptr() + el * 4)
+        w0 = m._word_info["offset"]
+        active = [(b, min(e, w0)) for b, e in m.active_ranges(self.use_clip_loss, self.use_tim_loss) if b < w0]
+        for ob, oe, _replicated in buckets.own_ranges():
+            mo, vo = self._opt_shards.get(ob, oe)
+            for ab, ae in active:                       # AdamW touches only parameters that received a gradient (torch skips `grad is None`)
+                b, e = max(ob, ab), min(oe, ae)
+                if e > b:
+                    _lib.check(lib.mmhip_adamw_guarded(at(m._flat_train, b), at(m._flat_grad, b), at(mo, b - ob), at(vo, b - ob), e - b, lr, 0.9, 0.999, 1e-8,
+                                                       weight_decay, step, 1.0 / self.world, 1, _lib.stream_ptr(), _lib.ptr(m._nonfinite)), "adamw shard")
+        # the shards of the other ranks hold this rank's unsummed gradient: clear the buckets whole (the entry condition of the next backward)
+        for b, s_, e, _, _ in buckets.plan:
+            m._flat_grad[b:e].zero_()
+        buckets.gather_params(m._flat_train)
 
     def _adamw(self, lr, weight_decay, step, dense=True, rows=True):
         m, lib = self.model, _lib.lib()
@@ -737,7 +777,7 @@ class MMLate_Model(object):
         if self.device.type != "cuda":
             return dataloader
         from .image_processing import DevicePrefetcher
-        return DevicePrefetcher(dataloader, self.device, self.image_processor)
+        return DevicePrefetcher(dataloader, self.device, self.image_processor, ring=getattr(self, "image_ring", None))
 
     def train(self, dataloader, val_dataloader, epochs, loss_fn=None, lr=1e-5, weight_decay=0.00025, tim_loss_fn=None,
               iadds_loss_fn=None, te_dataloader=None, model_path=None, val_filename=None, te_filename=None, class_weight=None,

@@ -100,3 +100,63 @@ def test_exchange_equals_dense_allreduce(world):
         assert p.exitcode == 0
     for _, e1, e2 in res:
         assert e1 < 1e-5 and e2 < 1e-6
+
+
+def _shard_worker(rank, world, port, q):
+    """dist.ShardedBuckets on CPU tensors: reduce-scatter -> update of the own shard -> all-gather must leave every replica with the parameters
+    the all-reduce + replicated update gives (same update rule, here p -= 0.1 * mean gradient), bit-identical across ranks, every element of a
+    bucket owned by exactly one rank (or by all: the tail), the non-owned gradient cleared by the caller"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    mmdist.init_from_env(backend="gloo")
+    n = 203
+    g = torch.Generator().manual_seed(5 + rank)
+    grad = torch.randn(n, generator=g)
+    param = torch.arange(n, dtype=torch.float32) / 7.0            # identical on every rank
+    ref_g = grad.clone()
+    td.all_reduce(ref_g)
+    ref_p = param - 0.1 * ref_g / world
+    old = mmdist.BUCKET_BYTES
+    mmdist.BUCKET_BYTES = 200                    # 50 floats per bucket
+    bk = mmdist.ShardedBuckets(grad)
+    stages = ((0, 28), (28, 64), (64, 64), (64, 131), (131, 203))
+    for b_, e_ in stages:
+        bk.add(b_, e_, flush=(e_ == n))
+    mmdist.BUCKET_BYTES = old
+    owned = torch.zeros(n, dtype=torch.int32)
+    mom = mmdist.ShardMoments("cpu")
+    for ob, oe, replicated in bk.own_ranges():
+        param[ob:oe] -= 0.1 * grad[ob:oe] / world
+        owned[ob:oe] += 1
+        m_, v_ = mom.get(ob, oe)
+        assert m_.numel() == oe - ob
+    bk.gather_params(param)
+    td.all_reduce(owned)
+    gathered = [torch.empty_like(param) for _ in range(world)]
+    td.all_gather(gathered, param)
+    same = all(torch.equal(gathered[0], g_) for g_ in gathered[1:])
+    expect = torch.zeros(n, dtype=torch.int32)        # every element updated by exactly one rank -- or, the few tail elements, once on every rank
+    for b_, s_, e_, _, _ in bk.plan:
+        expect[b_: b_ + world * s_] = 1
+        expect[b_ + world * s_: e_] = world
+    covered = bool(torch.equal(owned, expect)) and int((expect == world).sum()) < 4 * world * len(bk.plan)
+    err = float((param - ref_p).abs().max())
+    frac = mom.numel() / n                            # a rank keeps moments for about 1 / world of the elements
+    q.put((rank, err, same, covered, frac, len(bk.plan), bk.bytes))
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimizer_exchange_equals_allreduce(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + 11 * world) % 2000
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, err, same, covered, frac, nplan, nbytes in res:
+        assert err < 1e-5 and same and covered and nbytes == 203 * 4 and nplan >= 2
+        assert frac < 1.0 / world + 0.25, frac

@@ -91,11 +91,14 @@ torch.distributed.destroy_process_group()
 '''
 
 
-def test_two_rank_step_equals_averaged_single_process(tmp_path):
+@pytest.mark.parametrize("opt", ["allreduce", "shard"])
+def test_two_rank_step_equals_averaged_single_process(tmp_path, opt):
+    """opt = shard: reduce-scatter -> AdamW on the rank's own shard -> all-gather of the parameters (dist.ShardedBuckets, MMHIP_DP_OPT=shard)
+    instead of all-reduce + replicated AdamW -- the same parameters after the step, replicas bit-identical"""
     script = tmp_path / "dp.py"
     script.write_text(DP_SCRIPT)
     r = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-             str(29600 + os.getpid() % 300), str(script)], env={"ROOT": ROOT, "OUT": str(tmp_path)})
+             str(29600 + os.getpid() % 300 + (17 if opt == "shard" else 0)), str(script)], env={"ROOT": ROOT, "OUT": str(tmp_path), "MMHIP_DP_OPT": opt})
     line = [l for l in r.stdout.splitlines() if l.startswith("DP_ERR")][0].split()
     assert line[3] == "True", line                      # replicas stay bit-identical
     assert float(line[1]) < 2e-6, line                  # == one process on the averaged gradients (fp32 sum order only)

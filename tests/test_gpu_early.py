@@ -202,7 +202,13 @@ def test_native_step_equals_the_autograd_path():
                                               _lib.stream_ptr()))
         torch.cuda.synchronize()
         assert abs(la - loss.item()) < 1e-5 * abs(loss.item()), (itc, itm, la, loss.item())
-        d = (a.model._flat - m._flat).abs().max().item()
+        # a key bias shifts every score of a row alike: its true gradient is zero and what the kernels leave there is round-off of either sign,
+        # which AdamW's first step (update = lr * g / (|g| + eps)) turns into +- lr -- those elements are left out
+        keep = torch.ones_like(m._flat, dtype=torch.bool)
+        for inf in m._infos:
+            if inf["name"].endswith("key.bias"):
+                keep[inf["offset"]: inf["offset"] + inf["numel"]] = False
+        d = ((a.model._flat - m._flat).abs() * keep).max().item()
         print("native vs autograd", itc, itm, la, loss.item(), d)
         assert d < 2e-5, (itc, itm, d)          # AdamW's first step moves every touched parameter by ~lr: a sign flip of a ~1e-9 gradient would show as 2e-3
 
@@ -320,7 +326,11 @@ if rank == 0:
         _lib.check(_lib.lib().mmhip_adamw(at(m._flat, b), at(m._flat_grad, b), at(mom[0], b), at(mom[1], b), e - b, 1e-3, 0.9, 0.999, 1e-8, 0.00025, 1, 1.0, 1, _lib.stream_ptr()))
     torch.cuda.synchronize()
     p0, p1 = torch.load(os.environ["OUT"] + "/p0.pt"), torch.load(os.environ["OUT"] + "/p1.pt")
-    print("DP_EARLY", (p0 - m._flat.cpu()).abs().max().item(), torch.equal(p0, p1))
+    keep = torch.ones(p0.numel(), dtype=torch.bool)          # key biases: true gradient zero, round-off of either sign -> +- lr after AdamW's first step
+    for inf in m._infos:
+        if inf["name"].endswith("key.bias"):
+            keep[inf["offset"]: inf["offset"] + inf["numel"]] = False
+    print("DP_EARLY", ((p0 - m._flat.cpu()).abs() * keep).max().item(), torch.equal(p0, p1))
 torch.distributed.destroy_process_group()
 '''
 

@@ -7,7 +7,8 @@ for round in 1 2; do
 import json, sys
 d = json.loads(sys.argv[3])
 sp = d.get("spans_ms") or {}
-print(sys.argv[1], "|", sys.argv[2], "|", d["ms_per_step"], d["fwd_bwd_ms"], d["roofline"]["frac"], d["roofline"]["frac_serial"], "| spans", " ".join("%.2f" % v for v in sp.values()), flush=True)
+r = d.get("roofline") or {}
+print(sys.argv[1], "|", sys.argv[2], "|", d["ms_per_step"], d.get("fwd_bwd_ms"), r.get("frac"), r.get("frac_serial"), "| spans", " ".join("%.2f" % v for v in sp.values()), flush=True)
 PY
   done
 done

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--image_px", default="480x360")
     ap.add_argument("--item_tokenize", action="store_true")
+    ap.add_argument("--no_ring", action="store_true", help="A/B: decoded images through the DataLoader's result queue (round 3) instead of the pinned shared-memory ring")
     ap.add_argument("--resident_last", action="store_true", help="A/B: only MMLate_Model.warm_start() runs before the workers fork; the resident step is not timed")
     args = ap.parse_args()
     import pandas as pd
@@ -94,6 +95,11 @@ def main():
         res_ps = K * args.batch / (time.time() - t)
     ds = MM_Dataset(df.tweet_id.values, df.text.values, labels, tok, 128, fmt, 224, raw_images=True, batch_tokenize=not args.item_tokenize)
     inner = RawImageCollate(proc)
+    ring = None
+    if args.workers and not args.no_ring:
+        from smtc_amd.image_processing import RingCollate, SharedImageRing
+        ring = SharedImageRing(args.workers * 4 + 6, int(1.1 * args.batch * (w * h * 3 + 16)))
+        inner = RingCollate(proc, ring)
     collate = inner if args.item_tokenize else BatchTokenizeCollate(tok, 128, inner)
     kw = dict(num_workers=args.workers, collate_fn=collate, drop_last=True)
     if args.workers:
@@ -104,6 +110,8 @@ def main():
         n = 0
         for b in loader:
             n += b["input_ids"].shape[0]
+            if "image_slot" in b:
+                ring.release(int(b["image_slot"]))
         return n
 
     epoch_loader_only()                                   # start the workers, warm the page cache
@@ -112,7 +120,7 @@ def main():
     def epoch_train():
         nonlocal step
         n = 0
-        for b in DevicePrefetcher(loader, dev, proc, depth=3, trim_padding=False):
+        for b in DevicePrefetcher(loader, dev, proc, depth=3, trim_padding=False, ring=ring):
             ids, mask, px = trainer._unpack(b)
             step += 1
             trainer.train_step(ids, mask, px, b["labels"], None, lr, wd, step)
@@ -147,7 +155,8 @@ def main():
 
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     print(json.dumps({"posts": args.posts, "image_px": args.image_px, "workers": args.workers, "host_cores": cores, "batch": args.batch, "layers": args.layers,
-                      "tokenise": "per item" if args.item_tokenize else "per batch (collate)",
+                      "tokenise": "per item" if args.item_tokenize else "per batch (collate)", "image_handoff": "pinned shared-memory ring" if ring is not None else "DataLoader queue",
+                      "ring_pinned": bool(ring is not None and ring.pinned),
                       "loader_only_posts_per_s": round(loader_ps, 1), "loader_to_train_step_posts_per_s": round(e2e_ps, 1),
                       "resident_batch_train_step_posts_per_s": round(res_ps, 1), "end_to_end_over_resident": round(e2e_ps / res_ps, 3) if res_ps == res_ps else None,
                       "cpu_during_training": cpu,
