@@ -100,9 +100,9 @@ def cpu_baseline(seconds_budget=25.0):
 
 
 def bench_early(args):
-    """BASELINE config 5 (LXMERT early fusion, mm_early.py): first version -- the HIP operators chained by torch autograd, one GPU.
-    Step = forward (+ the second full encoder pass of ITM with --aux) + loss + backward + AdamW.  FLOPs per post: every Linear of the
-    9 language / 5 relational / 5 cross-modality layers on T = 128 tokens and 36 boxes, x3 for forward + backward."""
+    """BASELINE config 5 (LXMERT early fusion, mm_early.py): the native early-fusion engine (csrc/early.hip, round 4) -- one C call per step.
+    Step = forward (with --aux the ITM pass batched with the main pass: 2B posts) + loss mix + backward + AdamW + operand refresh.  FLOPs per
+    post: every Linear of the 9 language / 5 relational / 5 cross-modality layers on T = 128 tokens and 36 boxes, x3 for forward + backward."""
     import types
     import numpy as np
     import torch
@@ -146,6 +146,14 @@ def bench_early(args):
         tmax = torch.tensor([el], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         el = float(tmax.item())
+    # host time to enqueue one step from an idle queue
+    sync()
+    th = time.perf_counter()
+    for _ in range(2):
+        step += 1
+        tr.train_step(ids, mask, tt, feats, boxes, onehot, None, 1e-5, 0.00025, step)
+    host_ms = (time.perf_counter() - th) / 2 * 1e3
+    sync()
     layer = 2.0 * (4 * H * H + 2 * H * I)                       # Linear FLOPs per token of a BERT-shaped layer
     xlayer = 2.0 * (8 * H * H + 2 * H * I)                      # cross-modality layer: cross + self attention blocks, feed-forward
     fwd = (9 * layer + 5 * xlayer) * T + (5 * layer + 5 * xlayer) * NB + 2.0 * NB * (2048 + 4) * H
@@ -177,14 +185,14 @@ def bench_early(args):
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "BASELINE config 5: LXMERT early fusion (mm_early.py), 36 x 2048 ROI features, bs=32/GPU" + (", ITC + ITM" if args.aux else ""),
-                      "implementation": "HIP block operators (self-/cross-attention block, feed-forward block, grouped weight gradients, AdamW) under torch autograd, vision stream on a second HIP stream, ITM pass batched with the main pass",
+                      "implementation": "native engine (csrc/early.hip: one C call per step; language / vision / weight-gradient streams; per-layer AdamW beside the backward; ITM pass batched with the main pass)",
                       "gf_per_post": round(gf_post, 1), "posts_per_gpu": B, "text_tokens": T, "boxes": NB, "parallelism": f"dp{world}", "weights": "random-init at true shapes"},
-           "final_loss": round(float(loss), 5),
-           "roofline": {"bound": "mfma", "kernel": "whole step (no per-kernel timing on this path)", "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / PEAK_TFLOPS, 4), "traffic": None},
+           "final_loss": round(float(loss), 5), "host_enqueue_ms_per_step": round(host_ms, 3),
+           "roofline": {"bound": "mfma", "kernel": "whole step: algorithmic Linear FLOPs / step time (per-kernel durations: profiles/r04_cfg5_kernel_stats.csv, rocprofv3 of this command)",
+                        "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS, 4), "traffic": None},
            "cpu_baseline": cpu}
     if world > 1:
-        out["multi_gpu"] = "one all-reduce of the flat gradient per step (unmeasured on hardware: the development box has one GPU)"
+        out["multi_gpu"] = "staged exchange: the engine calls back per backward stage, ranges leave as bucketed all-reduces beside the stages below (unmeasured on hardware: the development box has one GPU)"
         torch.distributed.barrier()
     if rank == 0:
         print(json.dumps(out))

@@ -363,7 +363,8 @@ void gemm_tn_kernel(GemmTNGroup g) {
         char* base = smem + buf * C::STAGE;
         size_t ao, bo;
         if (P.pair) {
-            const int seg = mstep / msteps, r = mstep - seg * msteps;
+            // the three products of one 64-row slice follow each other (second uses of a slice served from L2), g.pair_serial = the round-3 order
+            const int seg = g.pair_serial ? mstep / msteps : mstep % 3, r = g.pair_serial ? mstep - seg * msteps : mstep / 3;
             ao = (size_t)r * 64 * P.lda + (seg == 1 ? (size_t)P.a_lo : 0);
             bo = (size_t)r * 64 * P.ldb + (seg == 2 ? (size_t)P.b_lo : 0);
         } else {
@@ -425,7 +426,8 @@ void gemm_tn_kernel(GemmTNGroup g) {
     };
     const int nsteps = P.pair ? 3 * msteps : msteps;
     // the column sums may cover the first rows only (parity mode: the hi and lo planes of A = the first two of the three passes)
-    const int cs_steps = P.pair ? 2 * msteps : (P.colsum_rows > 0 ? P.colsum_rows / 64 : nsteps);
+    const int cs_steps = P.pair ? nsteps : (P.colsum_rows > 0 ? P.colsum_rows / 64 : nsteps);
+    const bool pair_ilv = P.pair && !g.pair_serial;          // (pairs: the column sums take A hi and A lo = the first two of every three steps)
     if constexpr (NL > 0) {
         // role-specialised ring (see gemm_nt_kernel): loader waves stream, consumer waves multiply, one barrier per step
         if (w >= C::NW) {
@@ -448,7 +450,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
         for (int t = 0; t < nsteps; ++t) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            cs_now = with_colsum && t < cs_steps;
+            cs_now = with_colsum && t < cs_steps && (!P.pair || (pair_ilv ? t % 3 != 2 : t < 2 * msteps));
             compute(buf);
             buf = (buf + 1 == NS) ? 0 : buf + 1;
         }
@@ -458,7 +460,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
         for (int t = 0; t < nsteps; ++t) {
             const int cur = t & 1;
             if (t + 1 < nsteps) stage(cur ^ 1, t + 1);
-            cs_now = with_colsum && t < cs_steps;
+            cs_now = with_colsum && t < cs_steps && (!P.pair || (pair_ilv ? t % 3 != 2 : t < 2 * msteps));
             compute(cur);
             __syncthreads();
         }
@@ -474,7 +476,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (t + NS - 1 < nsteps) stage(sbuf, t + NS - 1);
-            cs_now = with_colsum && t < cs_steps;
+            cs_now = with_colsum && t < cs_steps && (!P.pair || (pair_ilv ? t % 3 != 2 : t < 2 * msteps));
             compute(buf);
             buf = (buf + 1 == NS) ? 0 : buf + 1;
             sbuf = (sbuf + 1 == NS) ? 0 : sbuf + 1;
@@ -763,6 +765,11 @@ hipError_t launch_gemm_tn(const GemmTNProblem* probs, int count, int accumulate,
     GemmTNGroup g;
     g.count = 0;
     g.accumulate = accumulate;
+    {
+        static int ilv = -1;
+        if (ilv < 0) { const char* e = getenv("MMHIP_X3_INTERLEAVE"); ilv = e ? atoi(e) : 1; }
+        g.pair_serial = !ilv;
+    }
     g.alpha = alpha;
     int tiles = 0;
     auto flush = [&]() {

@@ -241,7 +241,8 @@ struct I8 {
 // SEG (parity mode, round 4): A and B are plane pairs written by their producers (mmhip_kernels.h); the reduction runs over THREE segments of
 // K / 64 K-tiles each -- (A hi, B hi), (A lo, B hi), (A hi, B lo) -- by moving the operands' base pointers between the planes at the segment
 // ends: one launch, no scratch copies of the operands (round 3 split every fp32 operand into [hi | lo | hi] copies before each call).
-template <typename T, int BN, int EPI, typename ET = T, bool SEG = false>
+// SEG = 2: the same three products interleaved per 64-deep k slice (below); 1: three serial segments; 0: plain operands.
+template <typename T, int BN, int EPI, typename ET = T, int SEG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int persistent) {
     using C = P8<BN>;
     using P = I8<BN>;
@@ -257,8 +258,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
     const int kseg = g.p[0].K / C::BK;               // K-tiles of one plane
     const int nk = SEG ? 3 * kseg : kseg;
     // byte steps of the operand pointers at the two segment ends (on top of the ordinary 128 bytes): A hi -> A lo -> A hi, B hi -> B hi -> B lo
-    const int segA1 = SEG ? (g.p[0].a_lo - g.p[0].K) * 2 : 0, segA2 = SEG ? -(g.p[0].a_lo + g.p[0].K) * 2 : 0;
-    const int segB1 = SEG ? -g.p[0].K * 2 : 0, segB2 = SEG ? (g.p[0].b_lo - g.p[0].K) * 2 : 0;
+    const int segA1 = SEG == 1 ? (g.p[0].a_lo - g.p[0].K) * 2 : 0, segA2 = SEG == 1 ? -(g.p[0].a_lo + g.p[0].K) * 2 : 0;
+    const int segB1 = SEG == 1 ? -g.p[0].K * 2 : 0, segB2 = SEG == 1 ? (g.p[0].b_lo - g.p[0].K) * 2 : 0;
+    // interleaved order (g.seg_interleave): the three products of ONE 64-deep k slice follow each other -- (A hi, B hi), (A lo, B hi), (A hi, B lo), then
+    // the next slice -- so the second use of a B hi / A hi slice comes one / two K-tiles after the first and is served from the XCD's L2
+    // instead of, K / 64 tiles later, from beyond it (the K loop runs at the rate its operands arrive: DESIGN.md 7c)
+    const int aLo2 = SEG == 2 ? g.p[0].a_lo * 2 : 0, bLo2 = SEG == 2 ? g.p[0].b_lo * 2 : 0;          // byte steps after the products 0, 1, 2 of a slice: A +lo, -lo, +128; B 0, +lo, 128 - lo
     const int nwg = gridDim.x;
     int first, stride, count;
     if (persistent) {
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
     const char* gA[NPH];
     const char* gB[NPH];
     unsigned voff[NPH][GPP];
-    int g_rem[NPH], g_tile[NPH], g_inc[NPH];
+    int g_rem[NPH], g_tile[NPH], g_inc[NPH], g_ph[NPH];
     auto rebase = [&](auto pc_, int id) {
         constexpr int p = decltype(pc_)::value;
         int m0, n0;
@@ -322,14 +327,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
         constexpr int p = decltype(pc_)::value;
         if (--g_rem[p] == 0) {
             g_rem[p] = nk;
+            g_ph[p] = 0;
             g_tile[p] += 1;
             const bool live = g_tile[p] < count;
             g_inc[p] = live ? 128 : 0;
             rebase(pc_, first + (live ? g_tile[p] : 0) * stride);
         } else {
-            if constexpr (SEG) {
-                // g_rem K-tiles of the group's current tile are still to be issued: the next one opens segment 1 / segment 2 (never while the
-                // group runs on past the end of the work list: g_inc = 0 there)
+            if constexpr (SEG == 2) {
+                // g_ph = the product (0, 1, 2) just issued within its k slice (never moving while the group runs on past the end of the work
+                // list: g_inc = 0 there)
+                const int lv = g_inc[p] >> 7, ph = g_ph[p];
+                gA[p] += lv * (ph == 0 ? aLo2 : (ph == 1 ? -aLo2 : 128));
+                gB[p] += lv * (ph == 0 ? 0 : (ph == 1 ? bLo2 : 128 - bLo2));
+                g_ph[p] = ph == 2 ? 0 : ph + 1;
+            } else if constexpr (SEG == 1) {
+                // g_rem K-tiles of the group's current tile are still to be issued: the next one opens segment 1 / segment 2
                 const int j1 = g_rem[p] == 2 * kseg ? (g_inc[p] >> 7) : 0, j2 = g_rem[p] == kseg ? (g_inc[p] >> 7) : 0;
                 gA[p] += g_inc[p] + j1 * segA1 + j2 * segA2;
                 gB[p] += g_inc[p] + j1 * segB1 + j2 * segB2;
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
         }
     }
     // ---- prologue: K-tiles 0 .. NBUF-1, i.e. what the phases of K-tiles -NBUF .. -1 would have issued
-    for_phases([&](auto pc_) { constexpr int p = decltype(pc_)::value; g_rem[p] = nk; g_tile[p] = 0; g_inc[p] = 128; rebase(pc_, first); });
+    for_phases([&](auto pc_) { constexpr int p = decltype(pc_)::value; g_rem[p] = nk; g_tile[p] = 0; g_inc[p] = 128; g_ph[p] = 0; rebase(pc_, first); });
 #pragma unroll
     for (int b = 0; b < NBUF; ++b) for_phases([&](auto pc_) { issue(pc_, smem + b * C::KT); advance(pc_); });
     wait_vm<(NBUF - 1) * P::PIECES>();          // K-tile 0 has landed
@@ -558,7 +570,7 @@ static bool nt8_ok(const GemmNTArgs& a, int bn) {
 }
 
 static int nt8_grid(int ntiles) { return ntiles <= 256 ? ntiles : 256; }      // workgroups of a persistent launch: one per CU
-template <typename T, int BN, int EPI, typename ET = T, bool SEG = false>
+template <typename T, int BN, int EPI, typename ET = T, int SEG = 0>
 static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
     using C = P8<BN>;
     static bool done = false;
@@ -586,7 +598,7 @@ static int nt8_class(int f) {
     if (!(f & ~(GEMM_BIAS | GEMM_DROPOUT | GEMM_RESIDUAL))) return EP_PLAIN;
     return EP_ANY;
 }
-template <typename T, int BN, typename ET = T, bool SEG = false>
+template <typename T, int BN, typename ET = T, int SEG = 0>
 static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
     int c = nt8_class(g.p[0].flags);
     if (g.count > 1 && nt8_class(g.p[1].flags) != c) c = EP_ANY;
@@ -596,10 +608,16 @@ static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
     else launch_nt8_e<T, BN, EP_ANY, ET, SEG>(g, persistent, s);
 }
 static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent, hipStream_t s) {
-    if (dtype == DT_F32 && g.p[0].a_pair) {          // parity mode, operands as plane pairs: three K segments
-        if (bn == 256) launch_nt8_t<bf16_t, 256, float, true>(g, persistent, s);
-        else if (bn == 192) launch_nt8_t<bf16_t, 192, float, true>(g, persistent, s);
-        else launch_nt8_t<bf16_t, 128, float, true>(g, persistent, s);
+    static int ilv = -1;
+    if (ilv < 0) { const char* e = getenv("MMHIP_X3_INTERLEAVE"); ilv = e ? atoi(e) : 1; }
+    if (dtype == DT_F32 && g.p[0].a_pair && ilv) {          // parity mode, operands as plane pairs: the three products interleaved per k slice
+        if (bn == 256) launch_nt8_t<bf16_t, 256, float, 2>(g, persistent, s);
+        else if (bn == 192) launch_nt8_t<bf16_t, 192, float, 2>(g, persistent, s);
+        else launch_nt8_t<bf16_t, 128, float, 2>(g, persistent, s);
+    } else if (dtype == DT_F32 && g.p[0].a_pair) {          // ... as three serial K segments (MMHIP_X3_INTERLEAVE=0)
+        if (bn == 256) launch_nt8_t<bf16_t, 256, float, 1>(g, persistent, s);
+        else if (bn == 192) launch_nt8_t<bf16_t, 192, float, 1>(g, persistent, s);
+        else launch_nt8_t<bf16_t, 128, float, 1>(g, persistent, s);
     } else if (dtype == DT_F32) {          // parity mode: bf16 split planes in (x3.hip scratch copies), fp32 epilogue
         if (bn == 256) launch_nt8_t<bf16_t, 256, float>(g, persistent, s);
         else if (bn == 192) launch_nt8_t<bf16_t, 192, float>(g, persistent, s);

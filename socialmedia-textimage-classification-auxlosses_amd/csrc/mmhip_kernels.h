@@ -63,6 +63,8 @@ struct GemmTNGroup {
     GemmTNProblem p[GEMM_TN_MAX_GROUP];
     int count, accumulate;
     float alpha;              // C (+)= alpha * A^T B   (un-does the f16 gradient scale)
+    int pair_serial;          // plane pairs: 1 = three passes over all M rows one after the other (round-4 first form); 0 = the three products of a
+                              // 64-row slice follow each other
 };
 struct SmallGemmArgs {
     const void* A; const float* W; const float* bias; float* out;

@@ -298,6 +298,7 @@ class MMEarly_Model(object):
         self.model = Lxmert(model_kw.pop("model_dir", None), self.num_labels, self.max_length, dropout=config.dropout, **model_kw)
         self.device = self.model.device_
         self._opt = None
+        self.adam_eps = 1e-8                  # torch.optim.AdamW's default, as the reference uses it
 
     def prepare_itm_inputs(self, ids, mask, token_type_ids=None):
         """reference :300-330 (same draws as mm_late.prepare_itm_inputs, plus the token type ids of the swapped rows)"""
@@ -352,7 +353,7 @@ class MMEarly_Model(object):
         loss = torch.empty(4, device=dev)
         args = (m._handle, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(tt), _lib.ptr(feats), _lib.ptr(bx), _lib.ptr(src), _lib.ptr(lbl), _lib.ptr(onehot), _lib.ptr(cw),
                 B, T, Nb, m._next_seed(), int(self.use_clip_loss), int(self.use_tim_loss), w_cls, w_itc, w_itm, _lib.ptr(self._opt[0]), _lib.ptr(self._opt[1]),
-                lr, 0.9, 0.999, 1e-8, weight_decay, step, 1.0 / world, _lib.ptr(loss), _lib.stream_ptr())
+                lr, 0.9, 0.999, self.adam_eps, weight_decay, step, 1.0 / world, _lib.ptr(loss), _lib.stream_ptr())
         if world > 1 or mmdist.force_exchange():
             buckets = mmdist.StageBuckets(m._flat_grad)
             failure = []

@@ -173,18 +173,23 @@ def test_cross_attention_with_text_longer_than_boxes_matches_the_oracle():
 def test_native_step_equals_the_autograd_path():
     """mmhip_early_train_step (one native call: forward, fused loss mix incl. the ITC similarity, backward, AdamW, refresh) against the
     reference-style path -- Lxmert.forward, MMEarly_Model.loss in torch, loss.backward(), AdamW over grad_ranges -- on the same weights, batch
-    and ITM draw (dropout off): parameters after the step agree to fp32 round-off, for the three loss mixes"""
+    and ITM draw (dropout off), for the three loss mixes.  AdamW's first step is update = lr g / (|g| + eps): with the default eps = 1e-8 an
+    attention-query gradient of 1e-8 turns fp32 round-off of the loss gradient into +- lr, so the comparison runs with eps = 1e-2 (update
+    proportional to the gradient): the parameter DELTAS of the two paths must agree to 1e-4 of the largest delta."""
     from smtc_amd import _lib
     c = L.LxmertConfig(l_layers=2, r_layers=1, x_layers=1, vocab=400, max_pos=64, num_labels=3)
     arch = dict(l_layers=2, r_layers=1, x_layers=1, vocab=400, max_pos=64, p_hidden=0.0, p_attn=0.0)
     ids, mask, tt, feats, boxes, onehot = L.synthetic_batch(c, 6, 24, 5)
     w = torch.tensor([0.7, 1.6, 0.9])
+    EPS = 1e-2
     for itc, itm in ((False, False), (True, False), (True, True)):
         cfg = types.SimpleNamespace(batch_size=6, num_labels=3, use_clip_loss=itc, beta_itc=0.1, use_tim_loss=itm, beta_itm=0.1, max_length=24, dropout=0.0)
         a, b = MMEarly_Model(cfg, "lxmert", arch=arch, seed=3, dtype="bf16x3"), MMEarly_Model(cfg, "lxmert", arch=arch, seed=3, dtype="bf16x3")
         assert torch.equal(a.model._flat, b.model._flat)
+        p0 = a.model._flat.clone()
+        a.adam_eps = EPS
         np.random.seed(77)
-        la = float(a.train_step(ids, mask, tt, feats, boxes, onehot, w, 1e-3, 0.00025, 1))
+        la = float(a.train_step(ids, mask, tt, feats, boxes, onehot, w, 1e-3, 0.0, 1))
         np.random.seed(77)
         m = b.model
         m.train(); m.zero_grad()
@@ -198,19 +203,16 @@ def test_native_step_equals_the_autograd_path():
         mom = (torch.zeros_like(m._flat), torch.zeros_like(m._flat))
         at = lambda t, el: t.data_ptr() + el * 4
         for rb, re in m.grad_ranges(itc, itm):
-            _lib.check(_lib.lib().mmhip_adamw(at(m._flat, rb), at(m._flat_grad, rb), at(mom[0], rb), at(mom[1], rb), re - rb, 1e-3, 0.9, 0.999, 1e-8, 0.00025, 1, 1.0, 1,
+            _lib.check(_lib.lib().mmhip_adamw(at(m._flat, rb), at(m._flat_grad, rb), at(mom[0], rb), at(mom[1], rb), re - rb, 1e-3, 0.9, 0.999, EPS, 0.0, 1, 1.0, 1,
                                               _lib.stream_ptr()))
         torch.cuda.synchronize()
         assert abs(la - loss.item()) < 1e-5 * abs(loss.item()), (itc, itm, la, loss.item())
-        # a key bias shifts every score of a row alike: its true gradient is zero and what the kernels leave there is round-off of either sign,
-        # which AdamW's first step (update = lr * g / (|g| + eps)) turns into +- lr -- those elements are left out
-        keep = torch.ones_like(m._flat, dtype=torch.bool)
-        for inf in m._infos:
-            if inf["name"].endswith("key.bias"):
-                keep[inf["offset"]: inf["offset"] + inf["numel"]] = False
-        d = ((a.model._flat - m._flat).abs() * keep).max().item()
-        print("native vs autograd", itc, itm, la, loss.item(), d)
-        assert d < 2e-5, (itc, itm, d)          # AdamW's first step moves every touched parameter by ~lr: a sign flip of a ~1e-9 gradient would show as 2e-3
+        da, db = a.model._flat - p0, m._flat - p0
+        scale = db.abs().max().item()
+        d = (da - db).abs().max().item()
+        print("native vs autograd", itc, itm, la, loss.item(), d, scale)
+        assert scale > 1e-6 and d < 1e-4 * scale + 2.5e-7, (itc, itm, d, scale)      # (+ two ulps of a parameter of magnitude 1: LayerNorm weights)
+        assert torch.equal(da == 0, db == 0)              # the same parameters were stepped (pooler, unused heads: untouched on both paths)
 
 
 def test_full_size_step_properties():
@@ -302,6 +304,8 @@ arch = dict(l_layers=1, r_layers=1, x_layers=1, vocab=300, max_pos=64, p_hidden=
 c = L.LxmertConfig(l_layers=1, r_layers=1, x_layers=1, vocab=300, max_pos=64, num_labels=3)
 ids, mask, tt, feats, boxes, onehot = L.synthetic_batch(c, 8, 20, 5)
 tr = MMEarly_Model(cfg, "lxmert", arch=arch, seed=5, dtype="bf16x3")
+tr.adam_eps = 1e-2          # update ~ gradient: with the default 1e-8 an attention-query gradient of 1e-8 turns fp32 round-off into +- lr
+p_init = tr.model._flat.cpu().clone()
 sl = slice(rank * 4, rank * 4 + 4)
 tr.train_step(ids[sl], mask[sl], tt[sl], feats[sl], boxes[sl], onehot[sl], None, 1e-3, 0.00025, 1)
 torch.save(tr.model._flat.cpu(), os.environ["OUT"] + f"/p{rank}.pt")
@@ -323,14 +327,11 @@ if rank == 0:
     mom = (torch.zeros_like(m._flat), torch.zeros_like(m._flat))
     at = lambda t, el: C.c_void_p(t.data_ptr() + el * 4)
     for b, e in m.grad_ranges(True, False):
-        _lib.check(_lib.lib().mmhip_adamw(at(m._flat, b), at(m._flat_grad, b), at(mom[0], b), at(mom[1], b), e - b, 1e-3, 0.9, 0.999, 1e-8, 0.00025, 1, 1.0, 1, _lib.stream_ptr()))
+        _lib.check(_lib.lib().mmhip_adamw(at(m._flat, b), at(m._flat_grad, b), at(mom[0], b), at(mom[1], b), e - b, 1e-3, 0.9, 0.999, 1e-2, 0.00025, 1, 1.0, 1, _lib.stream_ptr()))
     torch.cuda.synchronize()
     p0, p1 = torch.load(os.environ["OUT"] + "/p0.pt"), torch.load(os.environ["OUT"] + "/p1.pt")
-    keep = torch.ones(p0.numel(), dtype=torch.bool)          # key biases: true gradient zero, round-off of either sign -> +- lr after AdamW's first step
-    for inf in m._infos:
-        if inf["name"].endswith("key.bias"):
-            keep[inf["offset"]: inf["offset"] + inf["numel"]] = False
-    print("DP_EARLY", ((p0 - m._flat.cpu()).abs() * keep).max().item(), torch.equal(p0, p1))
+    scale = (m._flat.cpu() - p_init).abs().max().item()
+    print("DP_EARLY", max(0.0, (p0 - m._flat.cpu()).abs().max().item() - 2.5e-7) / scale, torch.equal(p0, p1))      # (- two ulps of a parameter of magnitude 1)
 torch.distributed.destroy_process_group()
 '''
 
@@ -347,4 +348,4 @@ def test_two_rank_step_equals_averaged_single_process(tmp_path):
                        env=dict(os.environ, PYTHONPATH=root, ROOT=root, OUT=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("DP_EARLY")][0].split()
-    assert float(line[1]) < 2e-6 and line[2] == "True", line
+    assert float(line[1]) < 1e-4 and line[2] == "True", line          # parameter deltas agree to 1e-4 of the largest delta; replicas bit-identical

@@ -20,7 +20,9 @@ def main():
     q_k = "Queue_Id" if "Queue_Id" in keys else None
     ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[name_k], r[q_k] if q_k else "0") for r in rows))
     # steps are delimited by the word-table AdamW kernel (one per step, the last optimizer kernel on the main queue)
-    marks = [i for i, e in enumerate(ev) if "adamw_rows_kernel" in e[2]]
+    # (TIMELINE_MARK: another once-per-step kernel, e.g. maxpool_bwd for the early-fusion engine whose step has no word-row AdamW)
+    mark = os.environ.get("TIMELINE_MARK", "adamw_rows_kernel")
+    marks = [i for i, e in enumerate(ev) if mark in e[2]]
     which = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     a, b = marks[-which - 1], marks[-which]
     seg = ev[a + 1: b + 1]
