@@ -968,7 +968,8 @@ def test_eval_loop_matches_reference_golden(dtype, tag, itc, itm):
     rel = abs(res["loss"] - ref_loss) / ref_loss
     top2 = np.sort(z["out_cls"], axis=1)
     margin = top2[:, -1] - top2[:, -2]
-    sure = margin > 4 * TOL_OUT[dtype]["out_cls"] * np.abs(z["out_cls"]).max()
+    # (the logit error of THIS two-layer fixture, about twice what it measures -- not the thirteen-golden band of TOL_OUT, which full-depth cases set)
+    sure = margin > 4 * {"bf16": 1.6e-2, "f16": 3.2e-3, "bf16x3": 1e-3}[dtype] * np.abs(z["out_cls"]).max()
     print(tag, dtype, "loss rel err", rel, "sure", int(sure.sum()), "of", len(sure))
     assert rel < {"bf16x3": 1e-4, "bf16": 5e-3, "f16": 1e-3}[dtype], (res["loss"], ref_loss)
     assert sure.sum() >= (len(sure) - 2 if dtype == "bf16x3" else 1)
