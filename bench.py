@@ -114,6 +114,7 @@ def bench_early(args):
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    torch.set_num_threads(int(os.environ.get("MMHIP_HOST_THREADS", "4")))      # see main(): idle intra-op threads must not throttle the enqueuing thread
     B, T, NB, H, I, C = args.batch, 128, 36, 768, 3072, 3
     cfg = types.SimpleNamespace(batch_size=B, num_labels=C, use_clip_loss=args.aux, beta_itc=0.1, use_tim_loss=args.aux, beta_itm=0.1, max_length=T, dropout=0.05)
     tr = MMEarly_Model(cfg, "lxmert", dtype=args.dtype, seed=0)
@@ -240,6 +241,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}")
     torch.cuda.set_device(dev)
+    # as run_mm_late.py does: torch's default intra-op pool is one thread per HOST core (256 on a GPU box that grants about 16); the
+    # idle threads of CPU-side tensor work (weight init, the parity checker's parameter recipe) spin and throttle the thread that
+    # enqueues the step -- measured: the strict-dtype loop below 27.0 vs 24.5 ms after the parity pass
+    torch.set_num_threads(int(os.environ.get("MMHIP_HOST_THREADS", "4")))
 
     B, T, C = args.batch, 128, (3 if args.aux else 2)
     cfg = types.SimpleNamespace(batch_size=B, num_labels=C, use_clip_loss=args.aux, beta_itc=0.1 if args.aux else None,
@@ -440,11 +445,16 @@ def main():
             sync()
             ks = max(3, min(args.steps, 10))
             ta = time.perf_counter()
+            marks = []
             for _ in range(ks):
                 sn += 1
                 t2.train_step(ids, mask, pixels, onehot, None, lr, wd, sn)
+                if os.environ.get("BENCH_AT_TRACE"):
+                    sync(); marks.append(time.perf_counter())
             sync()
             ms2 = (time.perf_counter() - ta) / ks * 1e3
+            if marks:
+                print("at_tolerance per-step ms:", " ".join("%.2f" % ((b - a) * 1e3) for a, b in zip([ta] + marks[:-1], marks)), file=sys.stderr, flush=True)
             del t2
             torch.cuda.empty_cache()
             p2 = measure_parity(STRICT_DTYPE)["measured"] if not args.no_parity else None

@@ -2,9 +2,11 @@
 # final evidence of a round, on the GPU box: bench lines, kernel statistics (side streams on / off), PMC passes, diagnostics.
 # Everything goes to gpurun_out/final/; copy what is to be judged into profiles/.
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O; rm -rf $O/*
+# usage: collect_profiles.sh a | b     (two gpurun calls: a = PMC passes, bench lines, kernel statistics; b = same-box A/Bs, loader, parity printout)
+R=$GRAFT_REPO_ROOT; PART=${1:-a}; O=$R/gpurun_out/final_$PART; mkdir -p $O; rm -rf $O/*
 cd /tmp && export TMPDIR=/tmp
 step() { echo "== $*" >&2; }
+if [ "$PART" = a ]; then
 step pmc traffic
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_f -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-at-tolerance --no-parity > /dev/null 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_w -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-at-tolerance --no-parity > /dev/null 2>&1 || exit 1
@@ -36,10 +38,13 @@ python3 $R/tools/hbm_table.py $O/kernel_stats_serial.csv > $O/hbm_kernels.md
 step pmc mfma
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_m -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-at-tolerance --no-parity > /dev/null 2>&1 || exit 1
 python3 $R/tools/pmc_mfma.py /tmp/pmc_m > $O/mfma_busy.txt
+fi
+if [ "$PART" = b ]; then
 step diagnostics
 cd $R
-{ tools/ab_env.sh "BASE=1" "MMHIP_EARLY_ADAMW=0" "MMHIP_OVERLAP=0" "MMHIP_DETERMINISTIC=1"; BENCH_ARGS="--dtype bf16x3 --steps 6 --warmup 3 --no-parity --no-at-tolerance" tools/ab_env.sh "MMHIP_X3_PAIRS=1" "MMHIP_X3_PAIRS=1 MMHIP_X3_INTERLEAVE=0" "MMHIP_X3_PAIRS=0"; BENCH_ARGS="--config 5 --steps 12 --warmup 4" tools/ab_env.sh "BASE=1" "MMHIP_EARLY_ADAMW=0" "MMHIP_EARLY_STREAMS=0"; } > $O/step_ab.txt 2>/dev/null
+{ BENCH_ARGS="--no-at-tolerance --no-parity" tools/ab_env.sh "BASE=1" "MMHIP_EARLY_ADAMW=0" "MMHIP_OVERLAP=0" "MMHIP_DETERMINISTIC=1"; BENCH_ARGS="--dtype bf16x3 --steps 6 --warmup 3 --no-parity --no-at-tolerance" tools/ab_env.sh "MMHIP_X3_PAIRS=1" "MMHIP_X3_PAIRS=1 MMHIP_X3_INTERLEAVE=0" "MMHIP_X3_PAIRS=0"; BENCH_ARGS="--config 5 --steps 12 --warmup 4" tools/ab_env.sh "BASE=1" "MMHIP_EARLY_ADAMW=0" "MMHIP_EARLY_STREAMS=0"; } > $O/step_ab.txt 2>/dev/null
 python3 tools/loader_bench.py > $O/loader_bench.txt 2>/dev/null
 python3 tools/loader_bench.py --no_ring >> $O/loader_bench.txt 2>/dev/null
 python3 -m pytest tests/test_gpu_model.py -q -s -k "train_losses_and_grads or dropout_train_step or forward_matches or config4 or eval_loop" 2>&1 | grep -v "^$" > $O/parity.txt
+fi
 echo done >&2
