@@ -424,8 +424,8 @@ void build_workspace(mmhip_early& e) {
 int side_init(mmhip_early& e) {
     if (e.overlap < 0) { const char* v = getenv("MMHIP_EARLY_STREAMS"); e.overlap = v ? atoi(v) : 1; }
     if (e.side) return 0;
-    CHECK_HIP(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
-    CHECK_HIP(hipStreamCreateWithFlags(&e.wside, hipStreamNonBlocking));
+    CHECK_HIP(pool_stream(POOL_VIT, &e.side));          // process-wide streams (mmhip_common.h: pool_stream): vision chain ...
+    CHECK_HIP(pool_stream(POOL_SIDE, &e.wside));        // ... and weight gradients + AdamW, as in the late-fusion engine
     hipEvent_t* evs[9] = {&e.ev_fork, &e.ev_join, &e.ev_l, &e.ev_v, &e.ev_l2, &e.ev_v2, &e.ev_lw, &e.ev_vw, &e.ev_w};
     for (auto ev : evs) CHECK_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     return 0;
@@ -879,8 +879,7 @@ void mmhip_early_destroy(mmhip_early_handle h) {
         (void)hipStreamSynchronize(h->side);
         for (hipEvent_t ev : {h->ev_fork, h->ev_join, h->ev_l, h->ev_v, h->ev_l2, h->ev_v2, h->ev_lw, h->ev_vw, h->ev_w})
             if (ev) (void)hipEventDestroy(ev);
-        (void)hipStreamDestroy(h->side);
-        if (h->wside) { (void)hipStreamSynchronize(h->wside); (void)hipStreamDestroy(h->wside); }
+        if (h->wside) (void)hipStreamSynchronize(h->wside);                       // pooled streams: drained, not destroyed
     }
     delete h;
 }

@@ -493,20 +493,14 @@ SmallGemmArgs small(const void* A, int lda, const float* W, int ldw, const float
 int side_init(mmhip_engine& e) {
     if (e.overlap < 0) { const char* v = getenv("MMHIP_OVERLAP"); e.overlap = v ? atoi(v) : 1; }
     if (!e.overlap || e.side) return 0;
-    {
-        // MMHIP_SIDE_PRIO: HIP priority of the backward's side stream (lower = higher; default: equal to the caller's).
-        const char* v = getenv("MMHIP_SIDE_PRIO");
-        if (v) CHECK_HIP(hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, atoi(v)));
-        else CHECK_HIP(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
-        // The forward's two towers race for the CUs: whichever chain is longer should not be the one that waits.  The image
-        // tower gets the high-priority stream when it is the longer chain (plain batch: 34.9 vs 22.3 GF per post), the
-        // normal one when the text pass is doubled by the ITM posts.  Measured same-box: -0.17 ms/step on config 2; the
-        // same high priority on config 3 costs +0.38 ms.  MMHIP_VIT_PRIO=0/1 forces the choice.
-        int least = 0, greatest = 0;
-        CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        CHECK_HIP(hipStreamCreateWithFlags(&e.side_vit[0], hipStreamNonBlocking));
-        CHECK_HIP(hipStreamCreateWithPriority(&e.side_vit[1], hipStreamNonBlocking, greatest));
-    }
+    // The side streams are borrowed from the process-wide pool (mmhip_common.h: pool_stream -- why they are not created per engine).
+    // The forward's two towers race for the CUs: whichever chain is longer should not be the one that waits.  The image
+    // tower gets the high-priority stream when it is the longer chain (plain batch: 34.9 vs 22.3 GF per post), the
+    // normal one when the text pass is doubled by the ITM posts.  Measured same-box: -0.17 ms/step on config 2; the
+    // same high priority on config 3 costs +0.38 ms.  MMHIP_VIT_PRIO=0/1 forces the choice.
+    CHECK_HIP(pool_stream(POOL_SIDE, &e.side));
+    CHECK_HIP(pool_stream(POOL_VIT, &e.side_vit[0]));
+    CHECK_HIP(pool_stream(POOL_VIT_HI, &e.side_vit[1]));
     hipEvent_t* evs[9] = {&e.ev_fork, &e.ev_vit, &e.ev_ready[0], &e.ev_ready[1], &e.ev_tn[0], &e.ev_tn[1], &e.ev_layer[0], &e.ev_layer[1], &e.ev_opt};
     for (auto ev : evs) CHECK_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     return 0;
@@ -1117,8 +1111,7 @@ void mmhip_destroy(mmhip_handle h) {
         (void)hipStreamSynchronize(h->side);
         for (hipEvent_t ev : {h->ev_fork, h->ev_vit, h->ev_ready[0], h->ev_ready[1], h->ev_tn[0], h->ev_tn[1], h->ev_layer[0], h->ev_layer[1], h->ev_opt})
             if (ev) (void)hipEventDestroy(ev);
-        (void)hipStreamDestroy(h->side);
-        for (auto sv : h->side_vit) if (sv) (void)hipStreamDestroy(sv);
+        for (auto sv : h->side_vit) if (sv) (void)hipStreamSynchronize(sv);      // pooled streams: drained, not destroyed
         for (auto ev : h->span_ev) if (ev) (void)hipEventDestroy(ev);
     }
     for (auto& ev : h->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <mutex>
 
 namespace mmhip {
 
@@ -145,6 +148,42 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
+}
+
+
+// ---- process-wide side streams, one set per device.  ROCm maps HIP streams onto a small pool of hardware queues (4 unless
+// GPU_MAX_HW_QUEUES says otherwise) as they are created.  An engine created after other engines have come and gone -- a training model
+// after the thirteen parity models of bench.py -- got streams that shared a hardware queue with the caller's stream or with one another,
+// and silently lost the overlap the streams exist for (measured, same box: strict-dtype step 29.4 ms instead of 24.5; 25.0 with
+// GPU_MAX_HW_QUEUES=8).  So the engines borrow streams that are created once per process and device, in a fixed order, and never
+// destroyed: every engine of the process sees the mapping the first one saw.  Two engines driven at the same time share them, which
+// orders their side work but keeps every dependency (events) intact.
+enum { POOL_SIDE = 0, POOL_VIT = 1, POOL_VIT_HI = 2, POOL_STREAMS = 3 };
+inline hipError_t pool_stream(int which, hipStream_t* out) {
+    static std::mutex mu;
+    static hipStream_t pool[16][POOL_STREAMS] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    hipError_t r = hipGetDevice(&dev);
+    if (r != hipSuccess) return r;
+    if (dev < 0 || dev >= 16 || which < 0 || which >= POOL_STREAMS) return hipErrorInvalidValue;
+    if (!pool[dev][0]) {
+        // MMHIP_SIDE_PRIO: HIP priority of the backward's side stream (lower = higher; default: equal to the caller's)
+        const char* v = getenv("MMHIP_SIDE_PRIO");
+        int least = 0, greatest = 0;
+        if ((r = hipDeviceGetStreamPriorityRange(&least, &greatest)) != hipSuccess) return r;
+        hipStream_t s[POOL_STREAMS] = {};
+        r = v ? hipStreamCreateWithPriority(&s[POOL_SIDE], hipStreamNonBlocking, atoi(v)) : hipStreamCreateWithFlags(&s[POOL_SIDE], hipStreamNonBlocking);
+        if (r == hipSuccess) r = hipStreamCreateWithFlags(&s[POOL_VIT], hipStreamNonBlocking);
+        if (r == hipSuccess) r = hipStreamCreateWithPriority(&s[POOL_VIT_HI], hipStreamNonBlocking, greatest);
+        if (r != hipSuccess) {
+            for (auto q : s) if (q) (void)hipStreamDestroy(q);
+            return r;
+        }
+        for (int i = 0; i < POOL_STREAMS; ++i) pool[dev][i] = s[i];
+    }
+    *out = pool[dev][which];
+    return hipSuccess;
 }
 
 }  // namespace mmhip
