@@ -657,7 +657,7 @@ static int tile_map_lookup(const GemmNTArgs& a) {
     return 0;
 }
 // tile choice: explicit (a.tile / MMHIP_NT_TILE / MMHIP_TILE_MAP) or measured rules.  Tiles: 1 = 128x128 (two blocks per CU), 6 = 128x192,
-// 9 = role-specialised 256x128, 10 = 128x96, 12 = role-specialised 256x96 (gemm.hip); 13-18 = the deep-pipelined kernel of gemm8.hip
+// 9 = role-specialised 256x128, 10 = 128x96, 12 = role-specialised 256x96, 20 / 21 = 128x128 on a 4- / 3-deep ring (gemm.hip); 13-18 = the deep-pipelined kernel of gemm8.hip
 // (13 / 15 = 256x256 one-shot / persistent, 14 / 16 = 256x128, 17 / 18 = 256x192)
 static int choose_nt_tile(const GemmNTArgs& a) {
     { const int m = tile_map_lookup(a); if (m) return m; }
@@ -668,7 +668,8 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if ((t == 17 || t == 18 || t == 6) && a.N % 192) t = 0;
     if ((t == 14 || t == 16 || t == 1 || t == 9) && a.N % 128) t = 0;
     if ((t == 10 || t == 12) && a.N % 96) t = 0;
-    if (t == 1 || t == 6 || t == 9 || t == 10 || t == 12 || (t >= 13 && t <= 18)) return t;
+    if ((t == 20 || t == 21) && a.N % 128) t = 0;
+    if (t == 1 || t == 6 || t == 9 || t == 10 || t == 12 || (t >= 13 && t <= 18) || t == 20 || t == 21) return t;
     // Rules measured inside the training step (same-box A/B of bench.py, profiles/r02_step_ab*.txt, r03_*): the image-tower-sized GEMMs
     // (M >= 12000 rows) take the deep-pipelined persistent tile that fills the rounds of 256 workgroups best; the 8192-row text GEMMs
     // outside the forward's CU partition (i.e. the backward's) keep 128 x 128 at two blocks per CU, and the long-K 768-wide ones the
@@ -693,6 +694,12 @@ static int choose_nt_tile(const GemmNTArgs& a) {
             if (u128 >= 0.70) return 16;
         }
     }
+    // long K on a grid that leaves one block per CU at most (config 5's 4096- and 1152-row GEMMs): nothing else on the CU hides the
+    // 2-stage variant's load latency; the 3-deep ring does (microbench profiles/r04_early_gemm.txt: 4096x768x3072 40.1 -> 35.0 us,
+    // 1152x768x3072 40.2 -> 33.4; K = 768 shapes are unchanged -- their 13-15 us are launch + prologue + epilogue).  MMHIP_RING3=0: off
+    static int ring3 = -1;
+    if (ring3 < 0) { const char* e = getenv("MMHIP_RING3"); ring3 = e ? atoi(e) : 1; }
+    if (ring3 && a.N % 128 == 0 && a.K >= 2048 && (long)((a.M + 127) / 128) * (a.N / 128) <= 256) return 21;
     if (a.N % 128 == 0 && a.N <= 768 && a.K >= 2048 && a.M >= 4096) return 9;
     if (a.N % 128 == 0) return 1;
     if (a.N % 192 == 0) return 6;
@@ -702,12 +709,15 @@ static int choose_nt_tile(const GemmNTArgs& a) {
 template <typename T>
 static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
     const int tile = choose_nt_tile(a);
-    if (tile >= 13) {      // deep-pipelined persistent-capable tiles (gemm8.hip): 13 / 15 = 256x256, 14 / 16 = 256x128, 17 / 18 = 256x192; even >= 16 and 15: persistent
+    if (tile >= 13 && tile <= 18) {      // deep-pipelined persistent-capable tiles (gemm8.hip): 13 / 15 = 256x256, 14 / 16 = 256x128, 17 / 18 = 256x192; even >= 16 and 15: persistent
         const int dt = sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16;
         const int bn = tile >= 17 ? 192 : ((tile == 13 || tile == 15) ? 256 : 128);
         if (launch_gemm_nt8(a, dt, bn, tile == 15 || tile == 16 || tile == 18, s)) return;
     }
-    switch (tile >= 13 ? 1 : tile) {
+    switch ((tile >= 13 && tile <= 18) ? 1 : tile) {
+        case 20: launch_nt_t<T, 128, 128, 2, 2, 4>(a, s); break;      // 128 x 128 on a 4-deep LDS ring (one block per CU): grids of <= 256 tiles, where
+                                                                      // nothing else on the CU hides the load latency of the 2-stage variant
+        case 21: launch_nt_t<T, 128, 128, 2, 2, 3>(a, s); break;      // ... 3-deep
         case 12: launch_nt_t<T, 256, 96, 4, 2, 3, 4>(a, s); break;    // role-specialised (8 MFMA + 4 LDS-DMA loader waves), 256 tiles for 8192 x 768: one tile per CU
         case 10: launch_nt_t<T, 128, 96, 2, 2, 2>(a, s); break;       // N that only 96 divides
         case 9: launch_nt_t<T, 256, 128, 4, 2, 3, 4>(a, s); break;    // role-specialised, 3-stage ring

@@ -35,6 +35,23 @@ def main():
               ("txt dx_qkv", 8192, 768, 2304), ("vit qkv", 12608, 2304, 768), ("vit ao", 12608, 768, 768), ("vit fc1", 12608, 3072, 768),
               ("vit fc2", 12608, 768, 3072), ("itm qkv", 16384, 2304, 768), ("itm ao", 16384, 768, 768), ("itm fc2", 16384, 768, 3072),
               ("square 4096", 4096, 4096, 4096)]
+    if "--early" in sys.argv:      # config 5 (LXMERT): 32 posts x 128 tokens = 4096 language rows, 32 x 36 = 1152 vision rows
+        shapes = [("lang qkv", 4096, 2304, 768), ("lang ao", 4096, 768, 768), ("lang fc1", 4096, 3072, 768), ("lang fc2", 4096, 768, 3072),
+                  ("lang kv", 4096, 1536, 768), ("lang dqkv", 4096, 768, 2304), ("visn q", 1152, 768, 768), ("visn qkv", 1152, 2304, 768),
+                  ("visn fc1", 1152, 3072, 768), ("visn fc2", 1152, 768, 3072), ("visn feat", 1152, 768, 2048)]
+        print(f"{'shape':14s} {'M':>6} {'N':>5} {'K':>5} | " + " | ".join(f"{n:>18s}" for n in ("128x128 2-stage", "128x128 ring3", "128x128 ring4", "WS 256x128", "auto")))
+        for name, M, N, K in shapes:
+            A = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+            B = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+            Cm = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            bias = torch.randn(N, device=dev)
+            cells = []
+            for tile in (1, 21, 20, 9, 0):
+                fn = lambda: lib.mmhip_op_gemm_nt(0, p(A), K, p(B), K, p(Cm), N, M, N, K, p(bias), 0, None, 0, None, 0, 0.0, 0, 0, None, 0, 0, tile << 4, st())
+                us = time_it(fn)
+                cells.append(f"{us:7.1f}us {2.0 * M * N * K / us / 1e6:6.0f}TF")
+            print(f"{name:14s} {M:6d} {N:5d} {K:5d} | " + " | ".join(cells), flush=True)
+        return
     print(f"{'shape':14s} {'M':>6} {'N':>5} {'K':>5} | " + " | ".join(f"{n:>18s}" for n in ("128x128", "128x96", "128x192", "WS 256x128", "auto")))
     for name, M, N, K in shapes:
         A = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
