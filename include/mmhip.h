@@ -303,7 +303,10 @@ int mmhip_op_self_att_block_bwd(int dtype, const void* dy, const float* maskbias
  * [3H, H] copy and bias; keybias [posts, S] additive key mask padded with -inf past Sk, S = max(Sq, Sk).  qkv [posts*S, 3H] and att
  * [posts*S, H] are the packed tensors the attention kernels work on (saved for the backward with lse, pre, mean, rstd); tq / attq
  * [posts*Sq, H] (needed when Sq < S) and tkv [posts*Sk, 2H] (when Sk < S) are scratch.  Backward: dxq (incl. the residual branch), dxc;
- * weight-gradient operands: dd / attq-or-att (Wo), dq-or-dqkv[:, :H] / xq (Wq), dkv-or-dqkv[:, H:] / xc (Wk, Wv). */
+ * weight-gradient operands: dd / attq-or-att (Wo), dq-or-dqkv[:, :H] / xq (Wq), dkv-or-dqkv[:, H:] / xc (Wk, Wv).
+ * Round 4: with a 16-bit dtype (and H a multiple of 128) nothing is padded -- the projections write their rows into the posts' S-row blocks
+ * directly and the attention kernels are given the live row counts, so rows of qkv / att / datt / dqkv past Sq (queries) or Sk (keys) are
+ * neither read nor written and need no initialisation; tq, tkv and dattq are then unused and may be NULL.  MMHIP_F32 keeps the padded form. */
 int mmhip_op_cross_att_block_fwd(int dtype, const void* xq, const void* xc, const float* keybias, const void* wqkv, const float* bqkv, const void* wo,
                                  const float* bo, const float* gamma, const float* beta, float eps, int posts, int Sq, int Sk, int heads, float p_att,
                                  float p_hid, uint64_t seed, void* qkv, void* att, float* lse, void* tq, void* tkv, void* attq, void* pre, float* mean,

@@ -70,20 +70,21 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int head = blockIdx.x, post = blockIdx.y;
     const int S = a.S;
+    const int Sq = a.Sq_live > 0 ? a.Sq_live : S, Sk = a.Sk_live > 0 ? a.Sk_live : S;      // live rows of the post's S-row block (cross attention)
     const T* base = (const T*)a.qkv + (size_t)post * S * a.ld_qkv + head * HD;
-    stage_image<T>(Kimg, base + a.hidden, a.ld_qkv, S, SP, false, tid, NW * 64);
-    stage_image<T>(Vimg, base + 2 * a.hidden, a.ld_qkv, S, SP, true, tid, NW * 64);
+    stage_image<T>(Kimg, base + a.hidden, a.ld_qkv, Sk, SP, false, tid, NW * 64);
+    stage_image<T>(Vimg, base + 2 * a.hidden, a.ld_qkv, Sk, SP, true, tid, NW * 64);
     for (int k = tid; k < SP; k += NW * 64) {
-        float b = (k < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f) : -INFINITY;
+        float b = (k < Sk) ? (a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f) : -INFINITY;
         mb[k] = b * LOG2E;
     }
     __syncthreads();
     const int r = lane & 31, h2 = lane >> 5;
     const float sc = a.scale * LOG2E;
-    const int nqt = a.q_tiles > 0 ? min((S + 31) / 32, a.q_tiles) : (S + 31) / 32;
+    const int nqt = a.q_tiles > 0 ? min((Sq + 31) / 32, a.q_tiles) : (Sq + 31) / 32;
     for (int qt = w; qt < nqt; qt += NW) {
         const int q = qt * 32 + r;
-        const int qrow = min(q, S - 1);
+        const int qrow = min(q, Sq - 1);
         const T* qp = base + (size_t)qrow * a.ld_qkv + 8 * h2;
         v8 qf[4];
 #pragma unroll
@@ -154,10 +155,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(AttnArgs a) {
                 }
             }
         }
-        if (a.lse && h2 == 0 && q < S) a.lse[((size_t)post * a.heads + head) * S + q] = (m_run + log2f(l_run)) * (1.0f / LOG2E);
+        if (a.lse && h2 == 0 && q < Sq) a.lse[((size_t)post * a.heads + head) * S + q] = (m_run + log2f(l_run)) * (1.0f / LOG2E);
         const float inv = 1.0f / l_run;
         // oacc[dt][reg] = O(query q, d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h2), still to be divided by the soft-max sum
-        if (q < S) {
+        if (q < Sq) {
             T* op = (T*)a.ctx + ((size_t)post * S + q) * a.ld_ctx + head * HD;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -194,18 +195,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int head = blockIdx.x, post = blockIdx.y;
     const int S = a.S;
+    const int Sq = a.Sq_live > 0 ? a.Sq_live : S, Sk = a.Sk_live > 0 ? a.Sk_live : S;      // live rows of the post's S-row block (cross attention)
     const size_t row0 = (size_t)post * S;
     const T* qb = (const T*)a.qkv + row0 * a.ld_qkv + head * HD;
     const T* kb = qb + a.hidden;
     const T* vb = qb + 2 * a.hidden;
     const T* dob = (const T*)a.dctx + row0 * a.ld_ctx + head * HD;
     const T* ob = (const T*)a.ctx + row0 * a.ld_ctx + head * HD;
-    stage_image<T>(Qtr, qb, a.ld_qkv, S, SP, true, tid, 256);
-    stage_image<T>(dOtr, dob, a.ld_ctx, S, SP, true, tid, 256);
-    stage_image<T>(Ktr, kb, a.ld_qkv, S, SP, true, tid, 256);
+    stage_image<T>(Qtr, qb, a.ld_qkv, Sq, SP, true, tid, 256);
+    stage_image<T>(dOtr, dob, a.ld_ctx, Sq, SP, true, tid, 256);
+    stage_image<T>(Ktr, kb, a.ld_qkv, Sk, SP, true, tid, 256);
     for (int q = tid; q < SP; q += 256) {
         float d = 0.f, l = 0.f;
-        if (q < S) {
+        if (q < Sq) {
             const T* o = ob + (size_t)q * a.ld_ctx;
             const T* g = dob + (size_t)q * a.ld_ctx;
 #pragma unroll
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
     const int r = lane & 31, h2 = lane >> 5;
     const bool has_keys = w < NKT;              // wave w owns keys 32w .. 32w+31
     const int key = w * 32 + r;
-    const int krow = min(key, S - 1);
+    const int krow = min(key, Sk - 1);
     v8 kf[4], vf[4];
     float mbk = 0.f;
     if (has_keys) {
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
             kf[s] = *reinterpret_cast<const v8*>(kb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2);
             vf[s] = *reinterpret_cast<const v8*>(vb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2);
         }
-        mbk = (key < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + key] : 0.f) : -INFINITY;
+        mbk = (key < Sk) ? (a.maskbias ? a.maskbias[(size_t)post * S + key] : 0.f) : -INFINITY;
         mbk *= LOG2E;
     }
     __syncthreads();
@@ -241,7 +243,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
     const uint32_t e_lane = (uint32_t)(((size_t)post * a.heads + head) * S) * (uint32_t)S + (uint32_t)key + (uint32_t)(4 * h2) * (uint32_t)S;
     f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
     constexpr int NQT = NKT;
-    const int qlim = a.q_tiles > 0 ? min(NQT, a.q_tiles) : NQT;      // later tiles carry a zero d ctx: nothing to do
+    int qlim = a.q_tiles > 0 ? min(NQT, a.q_tiles) : NQT;            // later tiles carry a zero d ctx: nothing to do
+    qlim = min(qlim, (Sq + 31) / 32);                                // ... or hold no live query at all
     for (int pair = 0; pair < (qlim + 1) / 2; ++pair) {
         if (has_keys) {
 #pragma unroll
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
                         const int reg = 4 * g + e;
                         const int q = q0 + 8 * g + 4 * h2 + e;
                         float p = fast_exp2(sacc[reg] * sc + mbk - l4[e]);
-                        if (q >= S) p = 0.f;
+                        if (q >= Sq) p = 0.f;
                         float pd = p, dpd = pacc[reg];
                         if (DROP) {
                             const bool kp = mm_keep(e_el, a.drop);
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
                 }
                 // dq[reg] = dQ(query qt*32 + r, d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h2): four consecutive d per register quad -> 8-byte stores
                 const int q = qt * 32 + r;
-                if (q < S) {
+                if (q < Sq) {
                     T* dqp = (T*)a.dqkv + (row0 + q) * a.ld_qkv + head * HD + dt * 32 + 4 * h2;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
         }
         __syncthreads();
     }
-    if (has_keys && key < S) {
+    if (has_keys && key < Sk) {
         // dk[dt][reg] = dK(key, d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h2)
         T* dkp = (T*)a.dqkv + (row0 + key) * a.ld_qkv + a.hidden + head * HD;
         T* dvp = dkp + a.hidden;
@@ -859,7 +862,8 @@ static bool x3_mfma_attention() {
     return on != 0;
 }
 hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s) {
-    if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1) return hipErrorInvalidValue;
+    if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1 || a.Sq_live > a.S || a.Sk_live > a.S) return hipErrorInvalidValue;
+    if (dtype == DT_F32 && (a.Sq_live > 0 || a.Sk_live > 0)) return hipErrorInvalidValue;      // live-row counts: 16-bit kernels only
     if (dtype == DT_F32) {
         // parity mode: split operands on the matrix cores; two 16-bit images per tensor fit the CU's LDS up to S = 288 (148 KB), longer
         // sequences (up to 768) walk the keys in LDS-sized chunks (attn_fwd_x3_long_kernel); MMHIP_X3_FAST=0: fp32 on the vector ALUs
@@ -921,7 +925,8 @@ static void launch_bwd_x3_t(const AttnBwdArgs& a, hipStream_t s) {
     else launch_bwd_x3_tp<NKT, false>(a, s);
 }
 hipError_t launch_attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t s) {
-    if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1) return hipErrorInvalidValue;
+    if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1 || a.Sq_live > a.S || a.Sk_live > a.S) return hipErrorInvalidValue;
+    if (dtype == DT_F32 && (a.Sq_live > 0 || a.Sk_live > 0)) return hipErrorInvalidValue;      // live-row counts: 16-bit kernels only
     if (dtype == DT_F32) {
         auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
         if (!x3_mfma_attention() || a.S > 128 || !al(a.qkv) || !al(a.ctx) || !al(a.dctx) || !al(a.dqkv)) {

@@ -268,26 +268,35 @@ int mmhip_op_cross_att_block_fwd(int dtype, const void* xq, const void* xc, cons
     hipStream_t s = (hipStream_t)stream;
     const int H = heads * 64, S = Sq > Sk ? Sq : Sk, Mq = posts * Sq, Mc = posts * Sk, M = posts * S;
     const size_t Z = esz_of(dtype);
-    if ((Sq < S && (!tq || !attq)) || (Sk < S && !tkv)) return MMHIP_E_INVALID;
+    // 16-bit dtypes: no padding passes.  The two projections write their rows straight into the posts' S-row blocks of the packed buffer
+    // (GemmNTArgs::c_rps) and the attention kernel is told how many query / key rows of a block exist (AttnArgs::Sq_live / Sk_live): the
+    // other rows are never read, so nothing has to be cleared or copied.  fp32 (parity mode): the padded form -- clear, project into
+    // compact scratch, copy the rows in -- which the parity kernels take as an ordinary self-attention over S rows.
+    const bool direct = dtype != MMHIP_F32 && H % 128 == 0;
+    if (!direct && ((Sq < S && !tq) || (Sk < S && !tkv))) return MMHIP_E_INVALID;
+    if (Sq < S && !attq) return MMHIP_E_INVALID;
     const char* w = (const char*)wqkv;
-    if (Sq < S || Sk < S) CHECK_HIP(hipMemsetAsync(qkv, 0, (size_t)M * 3 * H * Z, s));
+    if (!direct && (Sq < S || Sk < S)) CHECK_HIP(hipMemsetAsync(qkv, 0, (size_t)M * 3 * H * Z, s));
     {   // Q = xq Wq^T + bq  -> columns [0, H)
-        GemmNTArgs a = Sq == S ? nt(xq, H, w, H, qkv, 3 * H, Mq, H, H) : nt(xq, H, w, H, tq, H, Mq, H, H);
+        GemmNTArgs a = (Sq == S || direct) ? nt(xq, H, w, H, qkv, 3 * H, Mq, H, H) : nt(xq, H, w, H, tq, H, Mq, H, H);
         a.bias = bqkv; a.flags = GEMM_BIAS;
+        if (direct && Sq < S) { a.c_rps = Sq; a.c_rps_stride = S; }
         CHECK_HIP(launch_gemm_nt(a, dtype, s));
-        if (Sq < S) CHECK_HIP(copy_post_rows(tq, (size_t)H * Z, Sq, qkv, (size_t)3 * H * Z, S, posts, Sq, (size_t)H * Z, s));
+        if (!direct && Sq < S) CHECK_HIP(copy_post_rows(tq, (size_t)H * Z, Sq, qkv, (size_t)3 * H * Z, S, posts, Sq, (size_t)H * Z, s));
     }
     {   // [K | V] = xc [Wk; Wv]^T + [bk; bv]  -> columns [H, 3H)
         char* dst = (char*)qkv + (size_t)H * Z;
-        GemmNTArgs a = Sk == S ? nt(xc, H, w + (size_t)H * H * Z, H, dst, 3 * H, Mc, 2 * H, H) : nt(xc, H, w + (size_t)H * H * Z, H, tkv, 2 * H, Mc, 2 * H, H);
+        GemmNTArgs a = (Sk == S || direct) ? nt(xc, H, w + (size_t)H * H * Z, H, dst, 3 * H, Mc, 2 * H, H) : nt(xc, H, w + (size_t)H * H * Z, H, tkv, 2 * H, Mc, 2 * H, H);
         a.bias = bqkv + H; a.flags = GEMM_BIAS;
+        if (direct && Sk < S) { a.c_rps = Sk; a.c_rps_stride = S; }
         CHECK_HIP(launch_gemm_nt(a, dtype, s));
-        if (Sk < S) CHECK_HIP(copy_post_rows(tkv, (size_t)2 * H * Z, Sk, dst, (size_t)3 * H * Z, S, posts, Sk, (size_t)2 * H * Z, s));
+        if (!direct && Sk < S) CHECK_HIP(copy_post_rows(tkv, (size_t)2 * H * Z, Sk, dst, (size_t)3 * H * Z, S, posts, Sk, (size_t)2 * H * Z, s));
     }
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.qkv = qkv; at.maskbias = keybias; at.ctx = att; at.lse = lse; at.posts = posts; at.S = S; at.heads = heads;
     at.hidden = H; at.ld_qkv = 3 * H; at.ld_ctx = H; at.scale = 0.125f; at.drop = drop_of(p_att, seed, 7);
+    if (direct) { at.Sq_live = Sq; at.Sk_live = Sk; }
     CHECK_HIP(launch_attn_fwd(at, dtype, s));
     const void* aq = att;
     if (Sq < S) { CHECK_HIP(copy_post_rows(att, (size_t)H * Z, S, attq, (size_t)H * Z, Sq, posts, Sq, (size_t)H * Z, s)); aq = attq; }
@@ -309,7 +318,8 @@ int mmhip_op_cross_att_block_bwd(int dtype, const void* dy, const float* keybias
     hipStream_t s = (hipStream_t)stream;
     const int H = heads * 64, S = Sq > Sk ? Sq : Sk, Mq = posts * Sq, Mc = posts * Sk, M = posts * S;
     const size_t Z = esz_of(dtype);
-    if ((Sq < S && (!dattq || !dq)) || (Sk < S && !dkv)) return MMHIP_E_INVALID;
+    const bool direct = dtype != MMHIP_F32 && H % 128 == 0;      // as in the forward
+    if ((Sq < S && ((!direct && !dattq) || !dq)) || (Sk < S && !dkv)) return MMHIP_E_INVALID;
     LNBwdArgs b;
     memset(&b, 0, sizeof(b));
     b.dy = dy; b.x = pre; b.gamma = gamma; b.mean = mean; b.rstd = rstd; b.dx = dpre; b.dgamma = dgamma; b.dbeta = dbeta; b.rows = Mq; b.width = H; b.alpha = 1.0f;
@@ -319,6 +329,10 @@ int mmhip_op_cross_att_block_bwd(int dtype, const void* dy, const float* keybias
     const void* dsrc = dropping ? dd : dpre;
     if (Sq == S) {
         GemmNTArgs a = nt(dsrc, H, woT, H, datt, H, Mq, H, H);
+        CHECK_HIP(launch_gemm_nt(a, dtype, s));
+    } else if (direct) {      // rows written in place; the attention backward takes the rows past Sq as absent (AttnBwdArgs::Sq_live)
+        GemmNTArgs a = nt(dsrc, H, woT, H, datt, H, Mq, H, H);
+        a.c_rps = Sq; a.c_rps_stride = S;
         CHECK_HIP(launch_gemm_nt(a, dtype, s));
     } else {          // the gradient of the dropped query rows is zero
         GemmNTArgs a = nt(dsrc, H, woT, H, dattq, H, Mq, H, H);
@@ -330,6 +344,7 @@ int mmhip_op_cross_att_block_bwd(int dtype, const void* dy, const float* keybias
     memset(&ab, 0, sizeof(ab));
     ab.qkv = qkv; ab.maskbias = keybias; ab.ctx = att; ab.dctx = datt; ab.lse = lse; ab.dqkv = dqkv; ab.posts = posts; ab.S = S; ab.heads = heads;
     ab.hidden = H; ab.ld_qkv = 3 * H; ab.ld_ctx = H; ab.scale = 0.125f; ab.drop = drop_of(p_att, seed, 7);
+    if (direct) { ab.Sq_live = Sq; ab.Sk_live = Sk; }
     CHECK_HIP(launch_attn_bwd(ab, dtype, s));
     const char* wt = (const char*)wqkvT;              // [H, 3H]: columns [0,H) = Wq^T, [H,3H) = [Wk; Wv]^T
     {   // d xq = dQ Wq + d pre (residual branch)

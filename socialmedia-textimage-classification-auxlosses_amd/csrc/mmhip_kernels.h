@@ -47,6 +47,9 @@ struct GemmNTArgs {
                               // text layer) is cut along K into slices that run side by side; a second kernel sums them and applies the epilogue
     int a_pair, b_pair;       // parity mode: A / B is a plane pair (lda / ldb in 16-bit elements), lo plane a_lo / b_lo elements behind the hi plane
     int a_lo, b_lo, c_lo;     // c_lo: lo-plane offset of C with GEMM_OUT_PAIR (ldc in 16-bit elements)
+    int c_rps, c_rps_stride;  // > 0: output row m lands in row (m / c_rps) * c_rps_stride + m % c_rps of C -- the rows of a post written into a
+                              // per-post padded layout (cross attention: Sq rows of a post inside its S-row block of the packed q|k|v buffer).
+                              // gemm_nt_kernel tiles only (launch_gemm_nt routes such a problem there or fails); bias / aux / residual rows stay m
 };
 struct GemmNTPair { GemmNTArgs p[2]; int count; int gw; };      // gw: N-tiles per column group of the tile walk (0 = 8)      // gemm8.hip: one or two problems of equal N and K per launch
 static constexpr int GEMM_TN_MAX_GROUP = 8;
@@ -101,6 +104,9 @@ struct AttnArgs {
     int q_tiles;          // > 0: only the first q_tiles 32-row query tiles are computed / written (last layer: CLS row only)
     int pair;             // parity mode: qkv and ctx are plane pairs (ld_qkv / ld_ctx in 16-bit elements), lo planes lo_qkv / lo_ctx elements behind
     int lo_qkv, lo_ctx;
+    int Sq_live, Sk_live; // > 0 (16-bit kernels): only the first Sq_live query rows / Sk_live key rows of each post's S-row block exist -- the other rows
+                          // of qkv are never read (keys past Sk_live are masked, whatever maskbias holds there) and the other rows of ctx / lse never
+                          // written.  Layout strides and the dropout element index stay those of S.  (Cross attention, Sq != Sk, without padding passes.)
 };
 struct AttnBwdArgs {
     const void* qkv; const float* maskbias; const void* ctx; const void* dctx; const float* lse;
@@ -111,6 +117,8 @@ struct AttnBwdArgs {
     int q_tiles;          // > 0: d ctx is zero outside the first q_tiles query tiles; dQ of the other tiles is NOT written
     int pair;             // parity mode: qkv, ctx, dctx, dqkv are plane pairs (qkv and dqkv share ld_qkv / lo_qkv; ctx and dctx ld_ctx / lo_ctx)
     int lo_qkv, lo_ctx;
+    int Sq_live, Sk_live; // as in AttnArgs: rows of ctx / dctx past Sq_live are never read (their gradient is taken as zero), dQ rows past Sq_live and
+                          // dK / dV rows past Sk_live are not written
 };
 hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s);
 hipError_t launch_attn_fwd_f32(const AttnArgs& a, hipStream_t s);

@@ -170,6 +170,70 @@ def test_cross_attention_with_text_longer_than_boxes_matches_the_oracle():
     print("early cross orientation: worst gradient error", worst)
 
 
+@pytest.mark.parametrize("Sq,Sk", [(36, 48), (48, 36), (40, 40)])
+def test_cross_attention_block_takes_no_padding_passes(Sq, Sk):
+    """round 4: with a 16-bit dtype the cross-attention block operator writes its projections straight into the posts' S-row blocks
+    (GemmNTArgs::c_rps) and tells the attention kernels the live row counts (Sq_live / Sk_live) -- no clear, no row copies.  Every work
+    buffer is poisoned with NaN before the call: a single read of a padding row would surface in y / dxq / dxc / the weight-gradient
+    operands.  Reference: the same block in torch fp32 on the same bf16-rounded operands (HF LxmertCrossAttentionLayer arithmetic)."""
+    from smtc_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Sq * 100 + Sk)
+    posts, heads, H, S = 3, 2, 128, max(Sq, Sk)
+    rb = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(torch.bfloat16)
+    xq, xc = rb(posts * Sq, H), rb(posts * Sk, H)
+    wqkv, wo = rb(3 * H, H, sc=0.08), rb(H, H, sc=0.08)
+    bqkv, bo = torch.randn(3 * H, generator=g) * 0.1, torch.randn(H, generator=g) * 0.1
+    gamma, beta = 1 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
+    live = torch.ones(posts, Sk)
+    live[1, Sk - 5:] = 0                                              # one post with masked keys
+    keybias = torch.full((posts, S), float("-inf"))
+    keybias[:, :Sk] = torch.where(live > 0, 0.0, float("-inf"))
+    dy = rb(posts * Sq, H)
+    # ---- reference (fp32 on the rounded operands)
+    Xq, Xc, W, Wo = (t.float().requires_grad_(True) for t in (xq, xc, wqkv, wo))
+    q = (Xq @ W[:H].T + bqkv[:H]).view(posts, Sq, heads, 64).transpose(1, 2)
+    k = (Xc @ W[H:2 * H].T + bqkv[H:2 * H]).view(posts, Sk, heads, 64).transpose(1, 2)
+    v = (Xc @ W[2 * H:].T + bqkv[2 * H:]).view(posts, Sk, heads, 64).transpose(1, 2)
+    pr = torch.softmax(q @ k.transpose(-1, -2) * 0.125 + keybias[:, None, None, :Sk], -1)
+    ctx = (pr @ v).transpose(1, 2).reshape(posts * Sq, H)
+    y_ref = torch.nn.functional.layer_norm(ctx @ Wo.T + bo + Xq, (H,), gamma, beta, 1e-12)
+    (y_ref * dy.float()).sum().backward()
+    # ---- the operator, every work buffer NaN
+    cu = lambda t: t.to(dev).contiguous()
+    nan16 = lambda *sh: torch.full(sh, float("nan"), dtype=torch.bfloat16, device=dev)
+    nan32 = lambda *sh: torch.full(sh, float("nan"), dtype=torch.float32, device=dev)
+    d_xq, d_xc, d_w, d_wo, d_wT, d_woT = cu(xq), cu(xc), cu(wqkv), cu(wo), cu(wqkv.T), cu(wo.T)
+    d_bqkv, d_bo, d_gamma, d_beta, d_kb, d_dy = cu(bqkv), cu(bo), cu(gamma), cu(beta), cu(keybias), cu(dy)
+    qkv, att, lse = nan16(posts * S, 3 * H), nan16(posts * S, H), nan32(posts, heads, S)
+    attq, pre, mean, rstd, y = nan16(posts * Sq, H), nan16(posts * Sq, H), nan32(posts * Sq), nan32(posts * Sq), nan16(posts * Sq, H)
+    P_, st = _lib.ptr, _lib.stream_ptr()
+    _lib.check(lib.mmhip_op_cross_att_block_fwd(_lib.BF16, P_(d_xq), P_(d_xc), P_(d_kb), P_(d_w), P_(d_bqkv), P_(d_wo), P_(d_bo), P_(d_gamma), P_(d_beta), 1e-12,
+                                                posts, Sq, Sk, heads, 0.0, 0.0, 1, P_(qkv), P_(att), P_(lse), None, None, P_(attq), P_(pre), P_(mean), P_(rstd),
+                                                P_(y), st))
+    dgamma, dbeta = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    dpre, datt, dqkv = nan16(posts * Sq, H), nan16(posts * S, H), nan16(posts * S, 3 * H)
+    dq, dkv, dxq, dxc = nan16(posts * Sq, H), nan16(posts * Sk, 2 * H), nan16(posts * Sq, H), nan16(posts * Sk, H)
+    _lib.check(lib.mmhip_op_cross_att_block_bwd(_lib.BF16, P_(d_dy), P_(d_kb), P_(d_wT), P_(d_woT), P_(d_gamma), posts, Sq, Sk, heads, 0.0, 0.0, 1, P_(qkv),
+                                                P_(att), P_(lse), P_(pre), P_(mean), P_(rstd), P_(dgamma), P_(dbeta), P_(dpre), P_(dpre), None, P_(datt),
+                                                P_(dqkv), P_(dq), P_(dkv), P_(dxq), P_(dxc), st))
+    torch.cuda.synchronize()
+    for name, got, ref, tol in (("y", y, y_ref, 3e-2), ("dxq", dxq, Xq.grad, 4e-2), ("dxc", dxc, Xc.grad, 4e-2)):
+        assert torch.isfinite(got.float()).all(), name
+        assert rel(got, ref.detach()) < tol, (name, rel(got, ref.detach()))
+    # the operands the weight-gradient GEMMs read: compact copies (or the packed tensors themselves where nothing is padded), live rows only
+    src_q = dq if Sq < S else dqkv[:, :H]
+    src_kv = dkv if Sk < S else dqkv[:, H:]
+    src_att = attq if Sq < S else att
+    assert torch.isfinite(src_q.float()).all() and torch.isfinite(src_kv.float()).all() and torch.isfinite(src_att.float()).all()
+    dWq = src_q.float().T @ d_xq.float()
+    assert rel(dWq, W.grad[:H]) < 4e-2
+    dWkv = src_kv.float().T @ d_xc.float()
+    assert rel(dWkv, W.grad[H:]) < 4e-2
+    assert rel(src_att, ctx.detach()) < 3e-2
+
+
 def test_native_step_equals_the_autograd_path():
     """mmhip_early_train_step (one native call: forward, fused loss mix incl. the ITC similarity, backward, AdamW, refresh) against the
     reference-style path -- Lxmert.forward, MMEarly_Model.loss in torch, loss.backward(), AdamW over grad_ranges -- on the same weights, batch
