@@ -129,8 +129,9 @@ class SharedImageRing:
     the copy out of them has completed.  Create it BEFORE the DataLoader forks its workers; decoded bytes are exactly what PIL produced
     (no draft-mode decode): bit-exactness of the image leg is untouched."""
 
-    def __init__(self, slots, slot_bytes, register=True):
+    def __init__(self, slots, slot_bytes, register=True, timeout=5.0):
         import multiprocessing
+        self.timeout = float(timeout)             # how long a worker waits for a free slot before it packs a plain tensor instead
         self.slots, self.slot_bytes = int(slots), (int(slot_bytes) + 4095) // 4096 * 4096
         self.buf = torch.empty(self.slots * self.slot_bytes, dtype=torch.uint8).share_memory_()
         self.free = multiprocessing.Queue()
@@ -146,12 +147,12 @@ class SharedImageRing:
         o = slot * self.slot_bytes
         return self.buf[o: o + nbytes]
 
-    def take(self, nbytes, timeout=20.0):
+    def take(self, nbytes, timeout=None):
         """(slot, uint8 view) or (None, None) when the batch does not fit a slot or no slot came free in time (the caller packs a plain tensor)"""
         if nbytes > self.slot_bytes:
             return None, None
         try:
-            slot = self.free.get(timeout=timeout)
+            slot = self.free.get(timeout=self.timeout if timeout is None else timeout)
         except Exception:
             return None, None
         return slot, self.view(slot, nbytes)
@@ -171,13 +172,16 @@ class RingCollate:
 
     def __init__(self, processor, ring):
         self.proc, self.ring = processor, ring
+        self._starved = False         # (per worker process) the last attempt timed out: slots were leaked by an abandoned epoch or the consumer
+                                      # stalls -- do not wait again, look once and fall back, until a slot is there again
 
     def __call__(self, items):
         from torch.utils.data import default_collate, get_worker_info
         got = {}
 
         def alloc(nbytes):
-            slot, view = self.ring.take(nbytes)
+            slot, view = self.ring.take(nbytes, timeout=0.0 if self._starved else None)
+            self._starved = slot is None and nbytes <= self.ring.slot_bytes
             got["slot"], got["bytes"] = slot, nbytes
             return view
         packed, plan, n = self.proc.pack([it["image"] for it in items], pin=get_worker_info() is None, alloc=alloc)
@@ -275,20 +279,23 @@ class DevicePrefetcher:
         it = iter(self.loader)
         queue = []
         try:
-            while len(queue) < self.depth:
-                queue.append(self._stage(next(it)))
-        except StopIteration:
-            pass
-        while queue:
-            batch, ev = queue.pop(0)
-            torch.cuda.current_stream(self.device).wait_event(ev)
-            for v in batch.values():
-                if torch.is_tensor(v) and v.is_cuda:
-                    v.record_stream(torch.cuda.current_stream(self.device))
-            yield batch
             try:
-                queue.append(self._stage(next(it)))
+                while len(queue) < self.depth:
+                    queue.append(self._stage(next(it)))
             except StopIteration:
                 pass
-        if self.ring is not None:
-            self._reclaim(wait=True)
+            while queue:
+                batch, ev = queue.pop(0)
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                for v in batch.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(torch.cuda.current_stream(self.device))
+                yield batch
+                try:
+                    queue.append(self._stage(next(it)))
+                except StopIteration:
+                    pass
+        finally:
+            # also when the consumer stops early (break, exception): the slots of staged batches go back once their copies are done
+            if self.ring is not None:
+                self._reclaim(wait=True)

@@ -102,6 +102,26 @@ def test_full_batch_properties_and_prefetcher():
         assert int(b["input_ids"][0, 0, 0]) == int(b["data_id"][0])
         got.append(b["pixel_values"].clone())
     assert torch.equal(torch.cat(got), pv)
+    # (d) round 4: the same batches through the pinned shared-memory ring, written by worker processes -- bit-identical pixels, every slot
+    # back in the free queue after the epoch, and also after an epoch the consumer abandons half-way
+    from smtc_amd.image_processing import RingCollate, SharedImageRing
+    ring = SharedImageRing(3, 16 * 1100 * 1400 * 3 + 4096)
+    assert ring.pinned
+    loader = torch.utils.data.DataLoader(DS(), batch_size=16, shuffle=False, num_workers=2, collate_fn=RingCollate(p, ring), prefetch_factor=2)
+    got = [b["pixel_values"].clone() for b in DevicePrefetcher(loader, "cuda:0", p, depth=2, ring=ring)]
+    assert torch.equal(torch.cat(got), pv) and ring.fallbacks == 0
+    free = lambda: sorted(ring.free.get(timeout=2.0) for _ in range(ring.slots))
+    slots = free()
+    assert slots == [0, 1, 2]
+    for s_ in slots:
+        ring.release(s_)
+    loader = torch.utils.data.DataLoader(DS(), batch_size=16, shuffle=False, num_workers=0, collate_fn=RingCollate(p, ring))
+    for i, b in enumerate(DevicePrefetcher(loader, "cuda:0", p, depth=2, ring=ring)):
+        assert torch.equal(b["pixel_values"], pv[16 * i: 16 * i + 16])
+        if i == 1:
+            break                                                   # two more batches are staged: their slots must come back too
+    assert free() == [0, 1, 2]
+    ring.close()
 
 
 def test_trimmed_padding_gives_the_same_outputs_and_gradients():
