@@ -141,7 +141,6 @@ class SharedImageRing:
         if register and torch.cuda.is_available():
             rc = torch.cuda.cudart().cudaHostRegister(self.buf.data_ptr(), self.buf.numel(), 0)
             self.pinned = int(rc) == 0
-        self.fallbacks = 0
 
     def view(self, slot, nbytes):
         o = slot * self.slot_bytes
@@ -205,6 +204,7 @@ class DevicePrefetcher:
     def __init__(self, loader, device, processor=None, depth=2, trim_padding=True, ring=None):
         self.loader, self.device, self.proc, self.depth = loader, torch.device(device), processor, max(1, depth)
         self.ring, self._held = ring, []          # ring slots whose host-to-device copy is still in flight: (slot, event)
+        self.ring_batches = self.queue_batches = 0   # how the image bytes arrived: through a ring slot / as a packed tensor in the DataLoader queue
         key = (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
         if key not in DevicePrefetcher._streams:
             DevicePrefetcher._streams[key] = torch.cuda.Stream(device=self.device)
@@ -236,17 +236,18 @@ class DevicePrefetcher:
         out = {}
         if self.trim_padding:
             batch = self.trim(batch)
-        self._reclaim()
         slot = None
         with torch.cuda.stream(self.stream):
             if "image_slot" in batch:
                 if self.proc is None or self.ring is None:
                     raise ValueError("ring batches need a GpuImageProcessor and the SharedImageRing they were written to")
                 slot = int(batch["image_slot"])
+                self.ring_batches += 1
                 out["pixel_values"] = self.proc.run(self.ring.view(slot, int(batch["image_bytes"])), batch["image_plan"], int(batch["image_count"]))
             elif "image_packed" in batch:
                 if self.proc is None:
                     raise ValueError("raw-image batches need a GpuImageProcessor")
+                self.queue_batches += 1
                 out["pixel_values"] = self.proc.run(batch["image_packed"], batch["image_plan"], int(batch["image_count"]))
             for k, v in batch.items():
                 if k in ("image_packed", "image_plan", "image_count", "image_slot", "image_bytes"):
@@ -259,43 +260,47 @@ class DevicePrefetcher:
                     out[k] = v
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        if slot is not None:
-            self._held.append((slot, ev))
-        return out, ev
+        return out, ev, slot
 
-    def _reclaim(self, wait=False):
-        """ring slots whose copy has completed go back to the workers"""
-        keep = []
+    def _reclaim(self):
+        """the ring slots of batches already handed to the consumer go back to the workers.  Called before every blocking wait for the next
+        batch: a worker may be waiting for exactly these slots (the loader returns batches in order, so the batch awaited can be the one whose
+        worker has no slot yet) -- leaving the release to "whenever the next batch has arrived" deadlocks until the worker's timeout.  The
+        copies out of these slots were enqueued a batch ago: the host-side wait is over by the time it is asked for."""
         for slot, ev in self._held:
-            if wait:
-                ev.synchronize()
-            if wait or ev.query():
-                self.ring.release(slot)
-            else:
-                keep.append((slot, ev))
-        self._held = keep
+            ev.synchronize()
+            self.ring.release(slot)
+        self._held = []
 
     def __iter__(self):
         it = iter(self.loader)
         queue = []
+
+        def fetch():
+            if self.ring is not None:
+                self._reclaim()
+            queue.append(self._stage(next(it)))
         try:
             try:
                 while len(queue) < self.depth:
-                    queue.append(self._stage(next(it)))
+                    fetch()
             except StopIteration:
                 pass
             while queue:
-                batch, ev = queue.pop(0)
+                batch, ev, slot = queue.pop(0)
                 torch.cuda.current_stream(self.device).wait_event(ev)
                 for v in batch.values():
                     if torch.is_tensor(v) and v.is_cuda:
                         v.record_stream(torch.cuda.current_stream(self.device))
+                if slot is not None:
+                    self._held.append((slot, ev))
                 yield batch
                 try:
-                    queue.append(self._stage(next(it)))
+                    fetch()
                 except StopIteration:
                     pass
         finally:
             # also when the consumer stops early (break, exception): the slots of staged batches go back once their copies are done
             if self.ring is not None:
-                self._reclaim(wait=True)
+                self._held += [(slot, ev) for _, ev, slot in queue if slot is not None]
+                self._reclaim()

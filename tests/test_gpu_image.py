@@ -108,8 +108,9 @@ def test_full_batch_properties_and_prefetcher():
     ring = SharedImageRing(3, 16 * 1100 * 1400 * 3 + 4096)
     assert ring.pinned
     loader = torch.utils.data.DataLoader(DS(), batch_size=16, shuffle=False, num_workers=2, collate_fn=RingCollate(p, ring), prefetch_factor=2)
-    got = [b["pixel_values"].clone() for b in DevicePrefetcher(loader, "cuda:0", p, depth=2, ring=ring)]
-    assert torch.equal(torch.cat(got), pv) and ring.fallbacks == 0
+    pf = DevicePrefetcher(loader, "cuda:0", p, depth=2, ring=ring)
+    got = [b["pixel_values"].clone() for b in pf]
+    assert torch.equal(torch.cat(got), pv) and pf.ring_batches == 4 and pf.queue_batches == 0
     free = lambda: sorted(ring.free.get(timeout=2.0) for _ in range(ring.slots))
     slots = free()
     assert slots == [0, 1, 2]
