@@ -435,9 +435,6 @@ def main():
                                    "note": "the headline dtype itself meets the tolerance"}
         else:
             del trainer, m
-            if os.environ.get("BENCH_GC"):
-                import gc
-                gc.collect()
             torch.cuda.empty_cache()
             t2 = MMLate_Model(cfg, args.txt_model_name, img_name, fusion, dtype=STRICT_DTYPE, seed=0)
             np.random.seed(30 + rank)
