@@ -105,7 +105,7 @@ def test_full_batch_properties_and_prefetcher():
     # (d) round 4: the same batches through the pinned shared-memory ring, written by worker processes -- bit-identical pixels, every slot
     # back in the free queue after the epoch, and also after an epoch the consumer abandons half-way
     from smtc_amd.image_processing import RingCollate, SharedImageRing
-    ring = SharedImageRing(3, 16 * 1100 * 1400 * 3 + 4096)
+    ring = SharedImageRing(3, 16 * 1100 * 1400 * 3 + 4096, timeout=120.0)      # (a worker waits for a slot as long as it takes: this test is about the bytes)
     assert ring.pinned
     loader = torch.utils.data.DataLoader(DS(), batch_size=16, shuffle=False, num_workers=2, collate_fn=RingCollate(p, ring), prefetch_factor=2)
     pf = DevicePrefetcher(loader, "cuda:0", p, depth=2, ring=ring)
