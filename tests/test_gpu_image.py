@@ -106,6 +106,14 @@ def test_full_batch_properties_and_prefetcher():
     # back in the free queue after the epoch, and also after an epoch the consumer abandons half-way
     from smtc_amd.image_processing import RingCollate, SharedImageRing
     ring = SharedImageRing(3, 16 * 1100 * 1400 * 3 + 4096, timeout=120.0)      # (a worker waits for a slot as long as it takes: this test is about the bytes)
+    try:
+        _ring_legs(ring, DS, p, pv)
+    finally:
+        ring.close()
+
+
+def _ring_legs(ring, DS, p, pv):
+    from smtc_amd.image_processing import DevicePrefetcher, RingCollate
     assert ring.pinned
     loader = torch.utils.data.DataLoader(DS(), batch_size=16, shuffle=False, num_workers=2, collate_fn=RingCollate(p, ring), prefetch_factor=2)
     pf = DevicePrefetcher(loader, "cuda:0", p, depth=2, ring=ring)
@@ -122,7 +130,6 @@ def test_full_batch_properties_and_prefetcher():
         if i == 1:
             break                                                   # two more batches are staged: their slots must come back too
     assert free() == [0, 1, 2]
-    ring.close()
 
 
 def test_trimmed_padding_gives_the_same_outputs_and_gradients():
