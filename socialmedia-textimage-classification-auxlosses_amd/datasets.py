@@ -170,11 +170,14 @@ def lxmert_loaders_from_data_key(cfg, args, tokenizer, data_path=None):
     kw = dict(num_workers=int(getattr(args, "num_workers", 0) or 0))
     if kw["num_workers"] > 0:
         kw.update(persistent_workers=True, prefetch_factor=4, worker_init_fn=worker_init)
-    dl = lambda ds, sh: torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh, **kw)
+    def dl(ds, sh, sampler=None):
+        loader = torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size // split, shuffle=sh if sampler is None else None, sampler=sampler, **kw)
+        loader.mmhip_group = split              # image_processing.DevicePrefetcher reassembles the batches
+        return loader
     train_ds = mk(tr, ytr)
     if multi:
         sampler = torch.utils.data.distributed.DistributedSampler(train_ds, shuffle=True, seed=int(args.seed), drop_last=False)
-        train_loader = torch.utils.data.DataLoader(train_ds, batch_size=cfg.batch_size, sampler=sampler, **kw)
+        train_loader = dl(train_ds, None, sampler)
     else:
         train_loader = dl(train_ds, True)
     return train_loader, dl(mk(va, yva), False), dl(mk(te, yte), False), w
@@ -225,8 +228,16 @@ def loaders_from_data_key(cfg, args, trainer):
     batch_tok = not getattr(args, "item_tokenize", False) and getattr(tok, "is_fast", False)
     mk = lambda df, y: MM_Dataset(df.tweet_id.values, df.text.values, y, tok, cfg.max_length, cfg.img_fmt, size, raw_images=gpu, batch_tokenize=batch_tok)
     kw = dict(num_workers=int(getattr(args, "num_workers", 0) or 0))
+    # The workers decode one training batch side by side: the DataLoader cuts the sampler's order into sub-batches of batch_size / split
+    # posts and the device prefetcher puts `split` consecutive ones back together (same posts, same order as one BatchSampler of the full
+    # size).  With whole batches per worker the first batch of every epoch took one worker's 64 JPEG decodes (about 60 ms with the GPU
+    # idle: profiles/r04_loader_bench.txt).  MMHIP_LOADER_SPLIT=1 restores whole batches.
+    split = 1
+    if gpu and kw["num_workers"] > 1:
+        want = int(os.environ.get("MMHIP_LOADER_SPLIT", "8"))
+        split = max([d for d in (8, 4, 2, 1) if d <= max(1, min(want, kw["num_workers"])) and cfg.batch_size % d == 0])
     if kw["num_workers"] > 0:
-        kw.update(persistent_workers=True, prefetch_factor=4, worker_init_fn=worker_init)
+        kw.update(persistent_workers=True, prefetch_factor=4 * split, worker_init_fn=worker_init)
     inner = None
     if gpu:
         from .image_processing import GpuImageProcessor, RawImageCollate, RingCollate, SharedImageRing
@@ -235,20 +246,23 @@ def loaders_from_data_key(cfg, args, trainer):
         if kw["num_workers"] > 0 and os.environ.get("MMHIP_IMAGE_RING", "1") != "0":
             # decoded images reach the training process through a pinned shared-memory ring instead of the DataLoader's result queue
             # (image_processing.SharedImageRing); a batch that does not fit its slot falls back to the queue
-            slot_mb = float(os.environ.get("MMHIP_RING_SLOT_MB", str(1.5 * cfg.batch_size)))
-            slots = min(kw["num_workers"] * 4 + 6, max(4, int(4096 / slot_mb)))
+            slot_mb = float(os.environ.get("MMHIP_RING_SLOT_MB", str(1.5 * cfg.batch_size))) / split      # per (sub-)batch
+            slots = min((kw["num_workers"] * 4 + 6) * split, max(4, int(4096 / slot_mb)))
             trainer.image_ring = SharedImageRing(slots, int(slot_mb * (1 << 20)))
             inner = RingCollate(trainer.image_processor, trainer.image_ring)
         kw["collate_fn"] = inner
     if batch_tok:
         kw["collate_fn"] = BatchTokenizeCollate(tok, cfg.max_length, inner)
-    dl = lambda ds, sh: torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh, **kw)
+    def dl(ds, sh, sampler=None):
+        loader = torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size // split, shuffle=sh if sampler is None else None, sampler=sampler, **kw)
+        loader.mmhip_group = split              # image_processing.DevicePrefetcher reassembles the batches
+        return loader
     train_ds = mk(tr, ytr)
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         # data parallel: every rank trains on its own shard (equal length on all ranks, so the per-stage all-reduces pair up);
         # MMLate_Model.train calls sampler.set_epoch.  Validation / test stay whole on every rank (rank 0 writes the files).
         sampler = torch.utils.data.distributed.DistributedSampler(train_ds, shuffle=True, seed=int(args.seed), drop_last=False)
-        train_loader = torch.utils.data.DataLoader(train_ds, batch_size=cfg.batch_size, sampler=sampler, **kw)
+        train_loader = dl(train_ds, None, sampler)
     else:
         train_loader = dl(train_ds, True)
     return train_loader, dl(mk(va, yva), False), dl(mk(te, yte), False), w

@@ -212,10 +212,19 @@ class DevicePrefetcher:
     _streams = {}        # one copy stream per device for every prefetcher: the caching allocator pools blocks per stream, and a
                          # fresh stream per epoch strands the previous one's cached blocks (reserved memory grew 0.1-0.3 GiB per instance)
 
-    def __init__(self, loader, device, processor=None, depth=2, trim_padding=True, ring=None):
+    def __init__(self, loader, device, processor=None, depth=2, trim_padding=True, ring=None, group=None):
         self.loader, self.device, self.proc, self.depth = loader, torch.device(device), processor, max(1, depth)
         self.ring, self._held = ring, []          # ring slots whose host-to-device copy is still in flight: (slot, event)
         self.ring_batches = self.queue_batches = 0   # how the image bytes arrived: through a ring slot / as a packed tensor in the DataLoader queue
+        # group > 1: the loader delivers SUB-batches (batch_size / group posts each) and `group` consecutive ones make one training batch --
+        # the same posts in the same order as one batch of the full size (a BatchSampler cuts the sampler's order into consecutive chunks),
+        # but the workers decode one batch side by side instead of one worker decoding all of it: the first batch of an epoch is there after
+        # 1 / group of the time (datasets.loaders_from_data_key sets `loader.mmhip_group`)
+        self.group = max(1, int(group if group is not None else getattr(loader, "mmhip_group", 1)))
+        if ring is not None and ring.slots < self.group * (self.depth + 1):
+            # `depth` staged batches plus the one being assembled hold group slots each; with fewer the workers wait for slots that only
+            # come back after a batch has been handed over -- a stall until their timeout
+            raise ValueError(f"SharedImageRing of {ring.slots} slots is too small for {self.depth} staged batches of {self.group} sub-batches")
         key = (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
         if key not in DevicePrefetcher._streams:
             DevicePrefetcher._streams[key] = torch.cuda.Stream(device=self.device)
@@ -241,28 +250,45 @@ class DevicePrefetcher:
         return batch
 
     def __len__(self):
-        return len(self.loader)
+        return (len(self.loader) + self.group - 1) // self.group
 
-    def _stage(self, batch):
+    _IMAGE_KEYS = ("image_packed", "image_plan", "image_count", "image_slot", "image_bytes")
+
+    def _stage(self, parts):
+        """`parts`: the sub-batches of one training batch (a single one unless the loader is grouped)"""
+        if isinstance(parts, dict):
+            parts = [parts]
+        # everything but the images: one host-side concatenation of small tensors, then trimmed and copied as ONE batch
+        batch = {}
+        for k in parts[0]:
+            if k in self._IMAGE_KEYS:
+                continue
+            vs = [p[k] for p in parts]
+            batch[k] = vs[0] if len(vs) == 1 else (torch.cat(vs, 0) if torch.is_tensor(vs[0]) else [x for v in vs for x in (v if isinstance(v, (list, tuple)) else [v])])
         out = {}
         if self.trim_padding:
             batch = self.trim(batch)
-        slot = None
+        slots = []
         with torch.cuda.stream(self.stream):
-            if "image_slot" in batch:
-                if self.proc is None or self.ring is None:
-                    raise ValueError("ring batches need a GpuImageProcessor and the SharedImageRing they were written to")
-                slot = int(batch["image_slot"])
-                self.ring_batches += 1
-                out["pixel_values"] = self.proc.run(self.ring.view(slot, int(batch["image_bytes"])), batch["image_plan"], int(batch["image_count"]))
-            elif "image_packed" in batch:
-                if self.proc is None:
-                    raise ValueError("raw-image batches need a GpuImageProcessor")
-                self.queue_batches += 1
-                out["pixel_values"] = self.proc.run(batch["image_packed"], batch["image_plan"], int(batch["image_count"]))
+            pix = []
+            for p in parts:
+                if "image_slot" in p:
+                    if self.proc is None or self.ring is None:
+                        raise ValueError("ring batches need a GpuImageProcessor and the SharedImageRing they were written to")
+                    slot = int(p["image_slot"])
+                    slots.append(slot)
+                    self.ring_batches += 1
+                    pix.append(self.proc.run(self.ring.view(slot, int(p["image_bytes"])), p["image_plan"], int(p["image_count"])))
+                elif "image_packed" in p:
+                    if self.proc is None:
+                        raise ValueError("raw-image batches need a GpuImageProcessor")
+                    self.queue_batches += 1
+                    pix.append(self.proc.run(p["image_packed"], p["image_plan"], int(p["image_count"])))
+            if pix:
+                out["pixel_values"] = pix[0] if len(pix) == 1 else torch.cat(pix, 0)
+                if len(pix) > 1:
+                    out["pixel_values"]._mmhip_keep = pix          # (the parts keep their pinned staging buffers alive)
             for k, v in batch.items():
-                if k in ("image_packed", "image_plan", "image_count", "image_slot", "image_bytes"):
-                    continue
                 if torch.is_tensor(v) and k != "data_id":
                     h = v if v.is_pinned() else v.pin_memory()
                     out[k] = h.to(self.device, non_blocking=True)
@@ -271,7 +297,7 @@ class DevicePrefetcher:
                     out[k] = v
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        return out, ev, slot
+        return out, ev, slots
 
     def _reclaim(self):
         """the ring slots of batches already handed to the consumer go back to the workers.  Called before every blocking wait for the next
@@ -290,7 +316,13 @@ class DevicePrefetcher:
         def fetch():
             if self.ring is not None:
                 self._reclaim()
-            queue.append(self._stage(next(it)))
+            parts = [next(it)]                    # StopIteration here ends the epoch; a short last group is a short last batch
+            try:
+                while len(parts) < self.group:
+                    parts.append(next(it))
+            except StopIteration:
+                pass
+            queue.append(self._stage(parts))
         try:
             try:
                 while len(queue) < self.depth:
@@ -298,13 +330,12 @@ class DevicePrefetcher:
             except StopIteration:
                 pass
             while queue:
-                batch, ev, slot = queue.pop(0)
+                batch, ev, slots = queue.pop(0)
                 torch.cuda.current_stream(self.device).wait_event(ev)
                 for v in batch.values():
                     if torch.is_tensor(v) and v.is_cuda:
                         v.record_stream(torch.cuda.current_stream(self.device))
-                if slot is not None:
-                    self._held.append((slot, ev))
+                self._held += [(slot, ev) for slot in slots]
                 yield batch
                 try:
                     fetch()
@@ -313,5 +344,5 @@ class DevicePrefetcher:
         finally:
             # also when the consumer stops early (break, exception): the slots of staged batches go back once their copies are done
             if self.ring is not None:
-                self._held += [(slot, ev) for _, ev, slot in queue if slot is not None]
+                self._held += [(slot, ev) for _, ev, slots in queue for slot in slots]
                 self._reclaim()

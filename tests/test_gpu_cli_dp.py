@@ -137,6 +137,29 @@ def test_cli_config0_real_pipeline(tmp_path):
     assert m and int(m.group(3)) == 64 and int(m.group(2)) == 64 and int(m.group(1)) == 2 * 64, m and m.groups()
 
 
+def test_split_loader_trains_on_the_same_batches(tmp_path):
+    """round 4: with workers the DataLoader delivers sub-batches that the prefetcher reassembles (the workers decode one batch side by side).
+    The posts of every training batch and their order must be those of whole batches: two deterministic runs of the CLI with the same seed,
+    MMHIP_LOADER_SPLIT=1 (whole batches per worker) and the default, write identical metrics and predictions"""
+    import pandas as pd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_dummy_task
+    import smtc_amd  # noqa: F401
+    run_dir = make_dummy_task.main(str(tmp_path), 96, 1)
+    out = os.path.join(os.path.dirname(run_dir), "results", "mm_late", "testing")
+    got = {}
+    for split in ("1", "8"):
+        env = dict(os.environ, PYTHONPATH=ROOT, MMHIP_DETERMINISTIC="1", MMHIP_LOADER_SPLIT=split)
+        r = subprocess.run([sys.executable, "-m", "smtc_amd.run_mm_late", "--txt_model_name", "bernice", "--img_model_name", "vit", "--fusion_name", "attention",
+                            "--task", "2", "--testing", "--use_clip_loss", "--use_tim_loss", "--epochs", "2", "--batch_size", "16", "--seed", "33",
+                            "--num_workers", "4", "--save_preds"], cwd=run_dir, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        stem = os.path.join(out, "bernice-vit-attention_task2_seed33_itc0.1itm0.1_")
+        got[split] = (pd.read_csv(stem + "metrics_val.csv"), pd.read_csv(stem + "preds.csv"))
+    assert got["1"][0].equals(got["8"][0]), (got["1"][0], got["8"][0])
+    assert got["1"][1].equals(got["8"][1])
+
+
 RCCL_SCRIPT = r'''
 import os, sys, types, numpy as np, torch
 sys.path.insert(0, os.environ["ROOT"])

@@ -130,6 +130,25 @@ def _ring_legs(ring, DS, p, pv):
         if i == 1:
             break                                                   # two more batches are staged: their slots must come back too
     assert free() == [0, 1, 2]
+    for s_ in (0, 1, 2):
+        ring.release(s_)
+    # (e) sub-batches reassembled: the loader delivers 4 posts at a time, the prefetcher puts four of them back together -- the same
+    # 16-post batches, pixels and every other field
+    from smtc_amd.image_processing import SharedImageRing
+    with pytest.raises(ValueError):
+        DevicePrefetcher([], "cuda:0", p, depth=2, ring=ring, group=4)       # 3 slots cannot hold two staged batches of four sub-batches
+    ring4 = SharedImageRing(16, 4 * 1100 * 1400 * 3 + 4096, timeout=120.0)
+    try:
+        loader = torch.utils.data.DataLoader(DS(), batch_size=4, shuffle=False, num_workers=2, collate_fn=RingCollate(p, ring4), prefetch_factor=4)
+        pf = DevicePrefetcher(loader, "cuda:0", p, depth=2, ring=ring4, group=4)
+        assert len(pf) == 4
+        for i, b in enumerate(pf):
+            assert torch.equal(b["pixel_values"], pv[16 * i: 16 * i + 16]) and b["input_ids"].shape == (16, 1, 8) and b["labels"].shape == (16, 2)
+            assert b["data_id"].tolist() == list(range(16 * i, 16 * i + 16)) and int(b["input_ids"][5, 0, 0]) == 16 * i + 5
+        assert i == 3 and pf.ring_batches == 16 and pf.queue_batches == 0
+        assert sorted(ring4.free.get(timeout=2.0) for _ in range(16)) == list(range(16))
+    finally:
+        ring4.close()
 
 
 def test_trimmed_padding_gives_the_same_outputs_and_gradients():
