@@ -228,13 +228,15 @@ def loaders_from_data_key(cfg, args, trainer):
     batch_tok = not getattr(args, "item_tokenize", False) and getattr(tok, "is_fast", False)
     mk = lambda df, y: MM_Dataset(df.tweet_id.values, df.text.values, y, tok, cfg.max_length, cfg.img_fmt, size, raw_images=gpu, batch_tokenize=batch_tok)
     kw = dict(num_workers=int(getattr(args, "num_workers", 0) or 0))
-    # The workers decode one training batch side by side: the DataLoader cuts the sampler's order into sub-batches of batch_size / split
-    # posts and the device prefetcher puts `split` consecutive ones back together (same posts, same order as one BatchSampler of the full
-    # size).  With whole batches per worker the first batch of every epoch took one worker's 64 JPEG decodes (about 60 ms with the GPU
-    # idle: profiles/r04_loader_bench.txt).  MMHIP_LOADER_SPLIT=1 restores whole batches.
+    # MMHIP_LOADER_SPLIT=s (opt-in): the workers decode one training batch side by side -- the DataLoader cuts the sampler's order into
+    # sub-batches of batch_size / s posts and the device prefetcher puts s consecutive ones back together (same posts, same order as one
+    # BatchSampler of the full size; tests/test_gpu_cli_dp.py).  With whole batches per worker the first batch of every epoch takes one
+    # worker's 64 JPEG decodes with the GPU idle (64 ms); s = 8 brings that to 36 ms but costs 3 % of the steady rate (eight times the
+    # items through the result queue, eight preprocess launches per batch): +0.7 % over a 4 096-post epoch, a loss on long epochs
+    # (profiles/r04_loader_bench.txt) -- hence off by default.
     split = 1
     if gpu and kw["num_workers"] > 1:
-        want = int(os.environ.get("MMHIP_LOADER_SPLIT", "8"))
+        want = int(os.environ.get("MMHIP_LOADER_SPLIT", "1"))
         split = max([d for d in (8, 4, 2, 1) if d <= max(1, min(want, kw["num_workers"])) and cfg.batch_size % d == 0])
     if kw["num_workers"] > 0:
         kw.update(persistent_workers=True, prefetch_factor=4 * split, worker_init_fn=worker_init)

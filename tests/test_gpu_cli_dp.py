@@ -140,7 +140,7 @@ def test_cli_config0_real_pipeline(tmp_path):
 def test_split_loader_trains_on_the_same_batches(tmp_path):
     """round 4: with workers the DataLoader delivers sub-batches that the prefetcher reassembles (the workers decode one batch side by side).
     The posts of every training batch and their order must be those of whole batches: two deterministic runs of the CLI with the same seed,
-    MMHIP_LOADER_SPLIT=1 (whole batches per worker) and the default, write identical metrics and predictions"""
+    MMHIP_LOADER_SPLIT=1 (whole batches per worker, the default) and 8, write identical metrics and predictions"""
     import pandas as pd
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_dummy_task

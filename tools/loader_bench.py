@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--image_px", default="480x360")
     ap.add_argument("--item_tokenize", action="store_true")
-    ap.add_argument("--split", type=int, default=8, help="sub-batches per batch: the workers decode one batch side by side and the prefetcher reassembles it (1: whole batches per worker, rounds 3-4a)")
+    ap.add_argument("--split", type=int, default=1, help="sub-batches per batch (MMHIP_LOADER_SPLIT): the workers decode one batch side by side and the prefetcher reassembles it; 1 = whole batches per worker (the default)")
     ap.add_argument("--no_ring", action="store_true", help="A/B: decoded images through the DataLoader's result queue (round 3) instead of the pinned shared-memory ring")
     ap.add_argument("--resident_last", action="store_true", help="A/B: only MMLate_Model.warm_start() runs before the workers fork; the resident step is not timed")
     args = ap.parse_args()
