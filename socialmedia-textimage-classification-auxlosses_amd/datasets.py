@@ -170,14 +170,11 @@ def lxmert_loaders_from_data_key(cfg, args, tokenizer, data_path=None):
     kw = dict(num_workers=int(getattr(args, "num_workers", 0) or 0))
     if kw["num_workers"] > 0:
         kw.update(persistent_workers=True, prefetch_factor=4, worker_init_fn=worker_init)
-    def dl(ds, sh, sampler=None):
-        loader = torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size // split, shuffle=sh if sampler is None else None, sampler=sampler, **kw)
-        loader.mmhip_group = split              # image_processing.DevicePrefetcher reassembles the batches
-        return loader
+    dl = lambda ds, sh: torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh, **kw)
     train_ds = mk(tr, ytr)
     if multi:
         sampler = torch.utils.data.distributed.DistributedSampler(train_ds, shuffle=True, seed=int(args.seed), drop_last=False)
-        train_loader = dl(train_ds, None, sampler)
+        train_loader = torch.utils.data.DataLoader(train_ds, batch_size=cfg.batch_size, sampler=sampler, **kw)
     else:
         train_loader = dl(train_ds, True)
     return train_loader, dl(mk(va, yva), False), dl(mk(te, yte), False), w
@@ -249,9 +246,13 @@ def loaders_from_data_key(cfg, args, trainer):
             # decoded images reach the training process through a pinned shared-memory ring instead of the DataLoader's result queue
             # (image_processing.SharedImageRing); a batch that does not fit its slot falls back to the queue
             slot_mb = float(os.environ.get("MMHIP_RING_SLOT_MB", str(1.5 * cfg.batch_size))) / split      # per (sub-)batch
-            slots = min((kw["num_workers"] * 4 + 6) * split, max(4, int(4096 / slot_mb)))
-            trainer.image_ring = SharedImageRing(slots, int(slot_mb * (1 << 20)))
-            inner = RingCollate(trainer.image_processor, trainer.image_ring)
+            slots = min((kw["num_workers"] * 4 + 6) * split, max(4, int(4096 / slot_mb)))                  # at most 4 GB of pinned shared memory
+            # every batch the loader can have outstanding needs a slot, beside the 3 * split the prefetcher holds (SharedImageRing: why)
+            pf = min(4 * split, (slots - 3 * split) // kw["num_workers"])
+            if pf >= 1:
+                kw["prefetch_factor"] = pf
+                trainer.image_ring = SharedImageRing(slots, int(slot_mb * (1 << 20)))
+                inner = RingCollate(trainer.image_processor, trainer.image_ring)
         kw["collate_fn"] = inner
     if batch_tok:
         kw["collate_fn"] = BatchTokenizeCollate(tok, cfg.max_length, inner)

@@ -127,7 +127,12 @@ class SharedImageRing:
     staging buffer by the training thread; the loader fed 0.66 of the step (profiles/r03_loader_bench.txt) with neither side out of cores.
     Slots are handed out through a queue of free slot numbers (back-pressure: a worker waits for a slot) and returned by the prefetcher once
     the copy out of them has completed.  Create it BEFORE the DataLoader forks its workers; decoded bytes are exactly what PIL produced
-    (no draft-mode decode): bit-exactness of the image leg is untouched."""
+    (no draft-mode decode): bit-exactness of the image leg is untouched.
+    How many slots: the loader delivers in order but the workers take slots in whatever order they get to it, so the batch the consumer waits
+    for can belong to the one worker without a slot while later batches hold them all -- nobody moves until that worker's timeout (it then
+    packs a plain tensor; correct, but a stall).  With at least num_workers * prefetch_factor slots (every batch the loader can have
+    outstanding) plus those the consumer holds (DevicePrefetcher: group * (depth + 1)) that cannot happen; datasets.loaders_from_data_key
+    sizes ring and prefetch_factor accordingly."""
 
     def __init__(self, slots, slot_bytes, register=True, timeout=5.0):
         import multiprocessing

@@ -115,8 +115,10 @@ def test_full_batch_properties_and_prefetcher():
 def _ring_legs(ring, DS, p, pv):
     from smtc_amd.image_processing import DevicePrefetcher, RingCollate
     assert ring.pinned
-    loader = torch.utils.data.DataLoader(DS(), batch_size=16, shuffle=False, num_workers=2, collate_fn=RingCollate(p, ring), prefetch_factor=2)
-    pf = DevicePrefetcher(loader, "cuda:0", p, depth=2, ring=ring)
+    # (3 slots: one per batch the loader can have outstanding -- 2 workers x prefetch 1 -- is not enough beside the 2 the prefetcher stages;
+    # depth 1 stages one and hands its slot back before it blocks: 2 + 1)
+    loader = torch.utils.data.DataLoader(DS(), batch_size=16, shuffle=False, num_workers=2, collate_fn=RingCollate(p, ring), prefetch_factor=1)
+    pf = DevicePrefetcher(loader, "cuda:0", p, depth=1, ring=ring)
     got = [b["pixel_values"].clone() for b in pf]
     assert torch.equal(torch.cat(got), pv) and pf.ring_batches == 4 and pf.queue_batches == 0
     free = lambda: sorted(ring.free.get(timeout=2.0) for _ in range(ring.slots))
