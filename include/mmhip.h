@@ -83,7 +83,10 @@ int mmhip_refresh_weights(mmhip_handle h, int which, void* stream);
 
 /* ---- MM_Model.forward (models/mm_late.py:148-193).  ids/mask/tim_* are int64 [B,T]; pixels fp32 [B,3,image,image];
  * outputs fp32: out_cls [B,num_labels], logits_per_text [B,B], out_tim [B,2] (only when tim_ids != NULL),
- * mm_features [B,hidden].  train != 0 applies dropout with masks derived from `seed`. */
+ * mm_features [B,hidden].  train != 0 applies dropout with masks derived from `seed`.
+ * Token ids are clamped into [0, vocab) as they are copied into the engine (mmhip_early_forward: token types into [0, type_vocab), ITM source
+ * rows into [0, B) as well): an id outside its table would send the embedding gather and the gradient scatter outside the table -- a GPU
+ * fault, where the reference raises IndexError on the CPU.  Out-of-range ids are therefore a caller error that degrades to a wrong row, never a fault. */
 /* (pixels may be NULL after mmhip_vision_import, see below) */
 int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const float* pixels, const int64_t* tim_ids,
                   const int64_t* tim_mask, int B, int T, int train, uint64_t seed, float* out_cls, float* logits_per_text,

@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void gather_rows_i64_kernel(const int64_t* __r
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * T) return;
     const int b = idx / T, t = idx % T;
-    out[idx] = in[(size_t)src[b] * T + t];
+    const int64_t r = src[b];
+    out[idx] = in[(size_t)(r < 0 ? 0 : (r >= B ? B - 1 : r)) * T + t];      // (a source row outside the batch would read outside the tensor)
 }
 
 // key biases at the packed cross-attention length S = max(T, boxes): live keys copy their bias, keys past the stream's own length get -inf
@@ -935,14 +936,16 @@ static int forward_impl(mmhip_early_handle h, const int64_t* ids, const int64_t*
     e.fwd_done = false; e.itc_done = false; e.bd_out = e.bd_embv = e.bd_tim = nullptr;
     CHECK_RC(side_init(e));
     const size_t nb = (size_t)B * T * 8;
-    CHECK_HIP(hipMemcpyAsync(e.ws + e.ids_all, ids, nb, hipMemcpyDeviceToDevice, s));
+    // indices are clamped into their tables on the way into the engine's copies (launch_copy_ids_clamped: why)
+    const size_t nt = (size_t)B * T;
+    CHECK_HIP(launch_copy_ids_clamped(ids, e.wsp<int64_t>(e.ids_all), nt, e.cfg.vocab, nullptr, s));
     CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all, mask, nb, hipMemcpyDeviceToDevice, s));
-    if (token_type_ids) CHECK_HIP(hipMemcpyAsync(e.ws + e.tt_all, token_type_ids, nb, hipMemcpyDeviceToDevice, s));
+    if (token_type_ids) CHECK_HIP(launch_copy_ids_clamped(token_type_ids, e.wsp<int64_t>(e.tt_all), nt, e.cfg.type_vocab, nullptr, s));
     else CHECK_HIP(hipMemsetAsync(e.ws + e.tt_all, 0, nb, s));
     if (tim_ids) {
-        CHECK_HIP(hipMemcpyAsync(e.ws + e.ids_all + nb, tim_ids, nb, hipMemcpyDeviceToDevice, s));
+        CHECK_HIP(launch_copy_ids_clamped(tim_ids, e.wsp<int64_t>(e.ids_all) + nt, nt, e.cfg.vocab, nullptr, s));
         CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all + nb, tim_mask, nb, hipMemcpyDeviceToDevice, s));
-        if (tim_token_type_ids) CHECK_HIP(hipMemcpyAsync(e.ws + e.tt_all + nb, tim_token_type_ids, nb, hipMemcpyDeviceToDevice, s));
+        if (tim_token_type_ids) CHECK_HIP(launch_copy_ids_clamped(tim_token_type_ids, e.wsp<int64_t>(e.tt_all) + nt, nt, e.cfg.type_vocab, nullptr, s));
         else CHECK_HIP(hipMemsetAsync(e.ws + e.tt_all + nb, 0, nb, s));
     } else if (itm_src) {
         const int grid = (B * T + 255) / 256;

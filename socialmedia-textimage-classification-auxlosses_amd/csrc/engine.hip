@@ -1164,10 +1164,11 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
     e.B = B; e.T = T; e.itm = tim_ids != nullptr; e.Bt = e.itm ? 2 * B : B; e.train_mode = train != 0; e.seed = seed;
     e.fwd_done = false; e.bwd_begun = false;
     const size_t nb = (size_t)B * T * 8;
-    CHECK_HIP(hipMemcpyAsync(e.ws + e.ids_all, ids, nb, hipMemcpyDeviceToDevice, s));
+    // token ids are clamped into the word table on their way into the engine's copy (launch_copy_ids_clamped: why)
+    CHECK_HIP(launch_copy_ids_clamped(ids, e.wsp<int64_t>(e.ids_all), (size_t)B * T, e.cfg.vocab, nullptr, s));
     CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all, mask, nb, hipMemcpyDeviceToDevice, s));
     if (e.itm) {
-        CHECK_HIP(hipMemcpyAsync(e.ws + e.ids_all + nb, tim_ids, nb, hipMemcpyDeviceToDevice, s));
+        CHECK_HIP(launch_copy_ids_clamped(tim_ids, e.wsp<int64_t>(e.ids_all) + (size_t)B * T, (size_t)B * T, e.cfg.vocab, nullptr, s));
         CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all + nb, tim_mask, nb, hipMemcpyDeviceToDevice, s));
     }
     if (int r = side_init(e)) return r;

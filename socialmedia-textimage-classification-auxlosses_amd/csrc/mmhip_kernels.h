@@ -193,6 +193,10 @@ size_t partial_floats_rows(int rows, int width, int nvec);
 size_t partial_floats_colsum(int rows, int cols);
 size_t partial_floats_embed(int posts, int T, int width);
 hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s);
+// out[i] = min(max(in[i], 0), hi - 1): the engines' private copies of caller-supplied indices (token ids, token types).  An id outside its table --
+// a tokenizer that does not match the checkpoint -- would otherwise send the embedding gather / scatter outside the table (a GPU fault); the
+// reference raises IndexError on the CPU, here the step goes on with the clamped row and `*bad` (optional device word) counts the offenders
+hipError_t launch_copy_ids_clamped(const int64_t* in, int64_t* out, size_t n, int64_t hi, unsigned* bad, hipStream_t s);
 static constexpr int CAST_MAX_GROUP = 4;
 struct CastMat { const float* src; void* dst; void* dstT; int rows, cols, tile_start; };
 struct CastGroup { CastMat m[CAST_MAX_GROUP]; int count; };

@@ -914,6 +914,20 @@ hipError_t launch_colsum(const void* x, int rows, int cols, int ld, float* out, 
     if (partial) launch_reduce_partials(partial, (int)grid.y, cols, out, s, alpha);
     return hipGetLastError();
 }
+__global__ __launch_bounds__(256) void copy_ids_clamped_kernel(const int64_t* __restrict__ in, int64_t* __restrict__ out, size_t n, int64_t hi, unsigned* bad) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int64_t v = in[i];
+        const int64_t c = v < 0 ? 0 : (v >= hi ? hi - 1 : v);
+        if (c != v && bad) atomicAdd(bad, 1u);
+        out[i] = c;
+    }
+}
+hipError_t launch_copy_ids_clamped(const int64_t* in, int64_t* out, size_t n, int64_t hi, unsigned* bad, hipStream_t s) {
+    if (!n) return hipSuccess;
+    if (hi < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(copy_ids_clamped_kernel, dim3(cap_grid(n)), dim3(256), 0, s, in, out, n, hi, bad);
+    return hipGetLastError();
+}
 hipError_t launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s) {
     if (!n) return hipSuccess;
     if (dtype == DT_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(cap_grid(n / 4 + 1)), dim3(256), 0, s, src, (bf16_t*)dst, n);

@@ -698,6 +698,33 @@ def test_ragged_shapes_match_oracle(B, T, itm):
         assert e < 0.05, (k, e)            # tiny batches (1-5 posts): more cancellation per tensor than the golden case behind TOL_GRAD
 
 
+def test_token_ids_outside_the_table_are_clamped_not_followed():
+    """a token id outside the word table (a tokenizer that does not match the checkpoint) must not send the embedding gather / the
+    gradient scatter outside the table: the engine clamps ids into [0, vocab) on their way into its own copy, so forward, backward and the
+    row-sparse optimizer see row vocab - 1 (the reference raises IndexError on the CPU; a GPU kernel reading past the table faults the card)"""
+    from smtc_amd import _lib
+    cfg = O.OracleConfig(layers_txt=1, layers_img=1, vocab=300, max_pos=130, num_labels=2)
+    model = build(cfg, "bf16", "bernice", 4, 32)
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, 4, 32, 3, True)
+    bad = ids.clone()
+    bad[0, 3], bad[1, 5], bad[2, 7] = 10 ** 12, 300, -7
+    want = bad.clamp(0, 299)
+    model.train()
+    outs = []
+    for x in (bad, want):
+        model._flat_grad.zero_()
+        o = model._engine_forward(x, mask, pixels, x.flip(0), mask.flip(0), seed=5)      # (same dropout masks in both runs)
+        lo = torch.empty(4, device=model.device_)
+        oh, lt = onehot.to(model.device_).contiguous(), torch.tensor([1, 0, 1, 0], device=model.device_)
+        _lib.check(_lib.lib().mmhip_loss(model._handle, _lib.ptr(oh), None, _lib.ptr(lt), 0.8, 0.1, 0.1, _lib.ptr(lo), None, _lib.stream_ptr()))
+        _lib.check(_lib.lib().mmhip_backward(model._handle, None, None, None, None, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(([t.clone() for t in o if t is not None], lo.clone(), model._flat_grad.clone()))
+    (oa, la, ga), (ob, lb, gb) = outs
+    assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and torch.equal(la, lb) and torch.isfinite(ga).all()
+    assert rel_err(ga, gb) < 1e-6                      # (atomics: the order of the word-row sums is not fixed)
+
+
 def test_capacity_growth_param_updates_and_errors():
     from smtc_amd import _lib
     cfg = O.OracleConfig(layers_txt=1, layers_img=1, vocab=300, max_pos=130, num_labels=2)
