@@ -234,6 +234,53 @@ def test_cross_attention_block_takes_no_padding_passes(Sq, Sk):
     assert rel(src_att, ctx.detach()) < 3e-2
 
 
+@pytest.mark.parametrize("Sq,Sk", [(128, 36), (36, 128), (20, 100), (33, 1)])
+def test_cross_attention_direct_and_padded_forms_agree_with_dropout_on(Sq, Sk):
+    """the 16-bit form (rows written in place, live-row counts) against the fp32 / parity form (clear, project, copy rows in) of the same
+    operator with dropout ON in both places: the two share the element-index convention of the masks (indices of the padded S x S layout), so
+    they must drop the same attention probabilities and the same hidden units and agree to bf16 accuracy -- outputs and both input gradients"""
+    from smtc_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Sq * 131 + Sk)
+    posts, heads, H, S = 3, 2, 128, max(Sq, Sk)
+    r32 = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(torch.bfloat16).float()      # bf16-representable values in both forms
+    xq, xc, dy = r32(posts * Sq, H), r32(posts * Sk, H), r32(posts * Sq, H)
+    wqkv, wo = r32(3 * H, H, sc=0.08), r32(H, H, sc=0.08)
+    bqkv, bo = torch.randn(3 * H, generator=g) * 0.1, torch.randn(H, generator=g) * 0.1
+    gamma, beta = 1 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
+    keybias = torch.full((posts, S), float("-inf"))
+    keybias[:, :Sk] = 0.0
+    if Sk > 4:
+        keybias[1, Sk - 3:Sk] = float("-inf")
+    res = {}
+    for name, code, tdt in (("bf16", _lib.BF16, torch.bfloat16), ("f32", _lib.F32, torch.float32)):
+        cu = lambda t: t.to(tdt).to(dev).contiguous()
+        f = lambda t: t.to(dev).contiguous()
+        z = lambda *sh: torch.zeros(sh, dtype=tdt, device=dev)
+        z32 = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
+        d = dict(xq=cu(xq), xc=cu(xc), w=cu(wqkv), wo=cu(wo), wT=cu(wqkv.T), woT=cu(wo.T), dy=cu(dy))
+        qkv, att, lse = z(posts * S, 3 * H), z(posts * S, H), z32(posts, heads, S)
+        tq, tkv, attq = z(posts * Sq, H), z(posts * Sk, 2 * H), z(posts * Sq, H)
+        pre, mean, rstd, y = z(posts * Sq, H), z32(posts * Sq), z32(posts * Sq), z(posts * Sq, H)
+        P_, st = _lib.ptr, _lib.stream_ptr()
+        kb, bq, bo_, ga, be = f(keybias), f(bqkv), f(bo), f(gamma), f(beta)
+        _lib.check(lib.mmhip_op_cross_att_block_fwd(code, P_(d["xq"]), P_(d["xc"]), P_(kb), P_(d["w"]), P_(bq), P_(d["wo"]), P_(bo_), P_(ga), P_(be), 1e-12, posts,
+                                                    Sq, Sk, heads, 0.1, 0.1, 77, P_(qkv), P_(att), P_(lse), P_(tq), P_(tkv), P_(attq), P_(pre), P_(mean), P_(rstd), P_(y), st))
+        dgamma, dbeta = z32(H), z32(H)
+        dpre, dd, dattq, datt, dqkv = z(posts * Sq, H), z(posts * Sq, H), z(posts * Sq, H), z(posts * S, H), z(posts * S, 3 * H)
+        dq, dkv, dxq, dxc = z(posts * Sq, H), z(posts * Sk, 2 * H), z(posts * Sq, H), z(posts * Sk, H)
+        _lib.check(lib.mmhip_op_cross_att_block_bwd(code, P_(d["dy"]), P_(kb), P_(d["wT"]), P_(d["woT"]), P_(ga), posts, Sq, Sk, heads, 0.1, 0.1, 77, P_(qkv), P_(att),
+                                                    P_(lse), P_(pre), P_(mean), P_(rstd), P_(dgamma), P_(dbeta), P_(dpre), P_(dd), P_(dattq), P_(datt), P_(dqkv), P_(dq),
+                                                    P_(dkv), P_(dxq), P_(dxc), st))
+        torch.cuda.synchronize()
+        res[name] = (y.float().cpu(), dxq.float().cpu(), dxc.float().cpu(), dgamma.cpu())
+    for a_, b_, what in zip(res["bf16"], res["f32"], ("y", "dxq", "dxc", "dgamma")):
+        assert torch.isfinite(a_).all() and rel(a_, b_) < 5e-2, (what, rel(a_, b_))
+    # the same hidden units are dropped in both forms: pre = dropout(att Wo^T + bo) + xq, so y differs from LN(xq)-like rows in the same places
+    # (a mismatch of the mask indices would show as O(1) differences above, far outside the bf16 band)
+
+
 def test_native_step_equals_the_autograd_path():
     """mmhip_early_train_step (one native call: forward, fused loss mix incl. the ITC similarity, backward, AdamW, refresh) against the
     reference-style path -- Lxmert.forward, MMEarly_Model.loss in torch, loss.backward(), AdamW over grad_ranges -- on the same weights, batch
