@@ -175,9 +175,11 @@ ids, mask, px, oh = synthetic_batch(300, 3, 4, 64, 77, pad=True)
 os.environ["MMHIP_DETERMINISTIC"] = "1"    # single-writer reductions: identical arithmetic gives identical bits, so three steps compare exactly
 out = {}
 # exchange forced through RCCL: the native data-parallel step (mmhip_train_step_dp + callbacks) and the staged Python step; no exchange: the native step
-for name, force, native_dp in (("rccl_native", "1", "1"), ("rccl_staged", "1", "0"), ("plain", "0", "1")):
+for name, force, native_dp, opt in (("rccl_native", "1", "1", "allreduce"), ("rccl_staged", "1", "0", "allreduce"), ("rccl_shard", "1", "1", "shard"),
+                                    ("plain", "0", "1", "allreduce")):
     os.environ["MMHIP_FORCE_EXCHANGE"] = force
     os.environ["MMHIP_NATIVE_DP"] = native_dp
+    os.environ["MMHIP_DP_OPT"] = opt          # shard: in-place reduce_scatter_tensor -> AdamW on the rank's shard (all of it at one rank) -> in-place all_gather_into_tensor
     tr = MMLate_Model(cfg, "bernice", "vit", "attention", arch=arch, seed=5)
     np.random.seed(30)
     losses = []
@@ -185,11 +187,12 @@ for name, force, native_dp in (("rccl_native", "1", "1"), ("rccl_staged", "1", "
         loss, _ = tr.train_step(ids.cuda(), mask.cuda(), px, oh, None, 1e-3, 0.00025, step)
         losses.append(float(loss[0]))
     torch.cuda.synchronize()
-    out[name] = (tr.model._flat_train.clone(), tr._opt[0].clone(), tr.model._word_row_state.clone(), losses, int(tr.model._last.get("exchange_bytes", 0)))
+    mom = tr._opt[0].clone() if opt == "allreduce" else None          # (the sharded optimizer keeps its dense moments per shard, elsewhere)
+    out[name] = (tr.model._flat_train.clone(), mom, tr.model._word_row_state.clone(), losses, int(tr.model._last.get("exchange_bytes", 0)))
 ref = out["plain"]
-ok = {k: all(torch.equal(a, b) for a, b in zip(v[:3], ref[:3])) and v[3] == ref[3] for k, v in out.items()}
+ok = {k: all(a is None or torch.equal(a, b) for a, b in zip(v[:3], ref[:3])) and v[3] == ref[3] for k, v in out.items()}
 moved = float((ref[0] - MMLate_Model(cfg, "bernice", "vit", "attention", arch=arch, seed=5).model._flat_train).abs().max())
-print("RCCL_EQ", ok["rccl_native"], ok["rccl_staged"], torch.distributed.get_backend(), out["rccl_native"][4] > 0, out["rccl_staged"][4] > 0, moved > 1e-4, ref[3])
+print("RCCL_EQ", ok["rccl_native"], ok["rccl_staged"], torch.distributed.get_backend(), out["rccl_native"][4] > 0, out["rccl_staged"][4] > 0, moved > 1e-4, ok["rccl_shard"], ref[3])
 torch.distributed.destroy_process_group()
 '''
 
@@ -206,6 +209,7 @@ def test_rccl_call_pattern_at_world_size_one(tmp_path):
     r = run([sys.executable, str(script)], env={"ROOT": ROOT, "PORT": str(29900 + os.getpid() % 90), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_EQ")][0].split()
     assert line[1] == "True" and line[2] == "True" and line[3] == "nccl" and line[4] == "True" and line[5] == "True" and line[6] == "True", line
+    assert line[7] == "True", line          # round 4: the sharded optimizer's in-place reduce-scatter / all-gather through RCCL, same bits
 
 
 def test_cli_two_ranks_shard_the_real_data(tmp_path):

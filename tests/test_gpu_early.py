@@ -462,3 +462,47 @@ def test_two_rank_step_equals_averaged_single_process(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("DP_EARLY")][0].split()
     assert float(line[1]) < 1e-4 and line[2] == "True", line          # parameter deltas agree to 1e-4 of the largest delta; replicas bit-identical
+
+
+RCCL_EARLY = r'''
+import os, sys, types, numpy as np, torch
+sys.path.insert(0, os.environ["ROOT"])
+import smtc_amd
+from smtc_amd.mm_early import MMEarly_Model
+from oracle import lxmert_oracle as L
+torch.cuda.set_device(0)
+torch.distributed.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:" + os.environ["PORT"], rank=0, world_size=1)
+cfg = types.SimpleNamespace(batch_size=4, num_labels=3, use_clip_loss=True, beta_itc=0.1, use_tim_loss=True, beta_itm=0.1, max_length=20, dropout=0.0)
+arch = dict(l_layers=1, r_layers=1, x_layers=1, vocab=300, max_pos=64, p_hidden=0.0, p_attn=0.0)
+c = L.LxmertConfig(l_layers=1, r_layers=1, x_layers=1, vocab=300, max_pos=64, num_labels=3)
+ids, mask, tt, feats, boxes, onehot = L.synthetic_batch(c, 4, 20, 5)
+out = {}
+for name, force in (("rccl", "1"), ("plain", "0")):
+    os.environ["MMHIP_FORCE_EXCHANGE"] = force
+    tr = MMEarly_Model(cfg, "lxmert", arch=arch, seed=5, dtype="bf16x3")
+    tr.adam_eps = 1e-2
+    p0 = tr.model._flat.clone()
+    np.random.seed(30)
+    losses = [float(tr.train_step(ids, mask, tt, feats, boxes, onehot, None, 1e-3, 0.00025, s)) for s in (1, 2)]
+    torch.cuda.synchronize()
+    out[name] = (tr.model._flat.clone() - p0, losses, int(getattr(tr.model, "_last_exchange_bytes", 0)))
+d = (out["rccl"][0] - out["plain"][0]).abs().max().item() / out["plain"][0].abs().max().item()
+print("RCCL_EARLY", d, out["rccl"][2] > 0, torch.distributed.get_backend(), abs(out["rccl"][1][1] - out["plain"][1][1]))
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_rccl_call_pattern_of_the_early_step_at_world_size_one(tmp_path):
+    """the staged exchange of the early-fusion step issued through RCCL itself (backend "nccl", one rank, exchange forced): the engine calls back at
+    every backward stage boundary, the stage ranges leave as bucketed all-reduces of slices of the flat gradient, AdamW waits for them -- the
+    parameter deltas of two steps equal those of the step without any collective (atomics in the shared cross-modality gradients: 1e-4 of the
+    largest delta, not bits).  Two ranks over gloo pin the arithmetic across ranks (test_two_rank_step_equals_averaged_single_process)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_early.py"
+    script.write_text(RCCL_EARLY)
+    r = subprocess.run([sys.executable, str(script)], cwd=root, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONPATH=root, ROOT=root, PORT=str(29950 + os.getpid() % 40), HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_EARLY")][0].split()
+    assert float(line[1]) < 1e-4 and line[2] == "True" and line[3] == "nccl" and float(line[4]) < 1e-5, line
