@@ -242,8 +242,9 @@ def main():
     dev = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}")
     torch.cuda.set_device(dev)
     # as run_mm_late.py does: torch's default intra-op pool is one thread per HOST core (256 on a GPU box that grants about 16); the
-    # idle threads of CPU-side tensor work (weight init, the parity checker's parameter recipe) spin and throttle the thread that
-    # enqueues the step -- measured: the strict-dtype loop below 27.0 vs 24.5 ms after the parity pass
+    # idle threads of CPU-side tensor work (weight init, the parity checker's parameter recipe) spin on the box's CPU share beside the
+    # thread that enqueues the step (round 3's loader finding).  It was NOT what slowed the strict-dtype loop below after the parity
+    # pass -- that was streams sharing a hardware queue -- but the pin stays: the bench then runs like the trainer does
     torch.set_num_threads(int(os.environ.get("MMHIP_HOST_THREADS", "4")))
 
     B, T, C = args.batch, 128, (3 if args.aux else 2)
