@@ -292,6 +292,7 @@ def main():
     # (the same steps timed without the collectives; the replicas diverge, which no longer matters after the timed region)
     exch = None
     if world > 1:
+        exch_bytes = int(trainer.model._last.get("exchange_bytes", 0))      # of the last exchanging step (the steps below skip the collectives)
         mmdist.SKIP_EXCHANGE = True
         for _ in range(2):
             step_no += 1
@@ -305,7 +306,7 @@ def main():
         sync()
         noex_ms = (time.perf_counter() - t2) / nx * 1e3
         mmdist.SKIP_EXCHANGE = False
-        exch = {"exchange_bytes_per_step": int(trainer.model._last.get("exchange_bytes", 0)), "ms_per_step_without_exchange": round(noex_ms, 3),
+        exch = {"exchange_bytes_per_step": exch_bytes, "ms_per_step_without_exchange": round(noex_ms, 3),
                 "exposed_exchange_ms": round(ms_step - noex_ms, 3), "hardware_note": "RCCL path measured only where the driver provides > 1 GPU"}
 
     # ---- extra: forward+backward only (no optimizer / refresh), same batch
