@@ -187,6 +187,14 @@ int mmhip_adamw_rows_guarded(float* p, float* g, float* m, float* v, int rows, i
                              float beta2, float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream,
                              uint32_t* guard_words2);
 int mmhip_set_loss_scale(mmhip_handle h, float loss_scale);
+/* Parity mode (MMHIP_BF16X3) only: how many bf16 MFMA products the BACKWARD's matrix products (activation gradients dX = dY . W, weight
+ * gradients dW = dY^T . X of the text tower) take per reduction slice.  3 (default): hi.hi + lo.hi + hi.lo, as the forward -- gradients
+ * within 1e-3 of the fp32 reference (measured 3e-5).  2: hi.hi + lo.hi -- the second operand (W, X) is read rounded to bf16.  1: hi.hi --
+ * both operands rounded to bf16 at the matrix cores; tensors stay stored as plane pairs / fp32, accumulation, row operations and the attention
+ * backward are unchanged.  The FORWARD (logits, loss: what the reference's tolerance is stated on, BASELINE.json north_star) always takes
+ * three.  Measured gradient bounds per setting: DESIGN.md section 4c.  Env MMHIP_X3_BWD=n sets the default at mmhip_create.
+ * Returns MMHIP_E_STATE for products != 3 on a handle of another dtype. */
+int mmhip_set_backward_products(mmhip_handle h, int products);
 
 /* ---- one whole training step of MMLate_Model.train (models/mm_late.py:452-491: zero_grad, forward, loss mix, backward,
  * optimizer.step) in ONE call: mmhip_forward(train) + mmhip_loss + mmhip_backward + AdamW over exactly the parameter ranges

@@ -85,6 +85,7 @@ _SIGS = {
     "mmhip_adamw_guarded": (I, [P, P, P, P, U64, F, F, F, F, F, I, F, I, P, P]),
     "mmhip_adamw_rows_guarded": (I, [P, P, P, P, I, I, P, F, F, F, F, F, I, F, I, P, P]),
     "mmhip_set_loss_scale": (I, [P, F]),
+    "mmhip_set_backward_products": (I, [P, I]),
     "mmhip_train_step": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P]),
     "mmhip_train_step_dp": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P, P, P]),
     "mmhip_image_plan_words": (U64, [I, P, P, I]),

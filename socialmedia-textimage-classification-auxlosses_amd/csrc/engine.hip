@@ -61,6 +61,7 @@ struct mmhip_engine {
     // qkv / ctx / h / patches, and in the backward du, dqkv, d ctx and the LayerNorm-backward outputs the GEMMs read.  fp32: the residual
     // stream (pre1, pre2, x, d pre, dx), the GELU stash u, everything the heads touch.
     bool px = false;
+    int bwd_np = 3;          // parity mode, plane pairs: products per k slice in the BACKWARD's matrix products (3 = as the forward; 2; 1) -- mmhip_set_backward_products
     size_t v_patches, v_pe, v_x, v_ln, v_qkv, v_ctx, v_h, v_out;                             // ViT ping-pong
     size_t g_partial, g_partial_side, g_det_rows = 0;
     size_t g_lnp[2][2];      // LN-backward partials per (layer parity, LN index): reduced on the side stream with the layer's dW
@@ -415,7 +416,7 @@ struct G {
     G& dropout(const DropCfg& d, int row_mul = 1) { a.drop = d; a.drop_row_mul = row_mul; if (d.thresh16) a.flags |= GEMM_DROPOUT; return *this; }
     // parity mode with plane pairs: both operands are pairs whose rows hold [hi(W) | lo(W)] -- the leading dimensions given in logical
     // elements double, the lo planes sit K elements behind; px_out: C as a pair, rows [hi(N) | lo(N)]
-    G& px_in(bool px) { if (px) { a.a_pair = a.b_pair = 1; a.lda *= 2; a.ldb *= 2; a.a_lo = a.b_lo = a.K; } return *this; }
+    G& px_in(bool px, int nprod = 0) { if (px) { a.a_pair = a.b_pair = 1; a.lda *= 2; a.ldb *= 2; a.a_lo = a.b_lo = a.K; a.nprod = nprod; } return *this; }
     G& px_out(bool px) { if (px) { a.flags |= GEMM_OUT_PAIR; a.ldc *= 2; a.c_lo = a.N; } return *this; }
 };
 // forward GEMM of tower `which` (0 text, 1 image) under the CU partition: persistent 256 x 256 tiles on at most cur_part[which] workgroups
@@ -919,6 +920,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     const LayerW16& w = e.txt_w16[l];
     const TextAct& a = e.tact[l];
     const bool px = e.px;
+    const int np = e.bwd_np;          // parity mode: MFMA products per k slice of the backward's GEMMs (mmhip_set_backward_products)
     const char* x_in = px ? (l ? e.ws + e.tact[l - 1].outp : e.ws + e.x0p) : (l ? e.ws + e.tact[l - 1].out : e.ws + e.x0);      // as the dWqkv product reads it
     const bool tr = e.train_mode;
     // temporaries that the weight-gradient GEMMs read are double-buffered per layer parity so that the side stream may
@@ -951,14 +953,14 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     auto part_bwd = [&](G& g, int bit) {
         if (e.part_bwd > 0 && (bwd_mask & bit) && side && g.a.M >= 2048 && g.a.N % 256 == 0 && g.a.K % 64 == 0 && (dt == DT_BF16 || dt == DT_F16)) { g.a.tile = 15; g.a.grid = e.part_bwd; }
     };
-    { G g(df, H, e.ws + w.fc2T, H, du, I, Mr, I, H); g.mul_gelu_grad(e.ws + a.u, I).px_in(px).px_out(px); part_bwd(g, 1); if (int r = run_gemm(e, g, s)) return r; }
+    { G g(df, H, e.ws + w.fc2T, H, du, I, Mr, I, H); g.mul_gelu_grad(e.ws + a.u, I).px_in(px, np).px_out(px); part_bwd(g, 1); if (int r = run_gemm(e, g, s)) return r; }
     // the two long-K activation-gradient GEMMs of the layer (768 wide): one role-specialised 256x96 tile per CU when M gives
     // exactly <= 256 of them -- in isolation 7 % faster than the 192 tiles of 256x128, in the step -0.05 ms (same-box A/B; the
     // same tile in the FORWARD costs +0.3 ms: it leaves no CU to the image tower).  MMHIP_BWD_TILE12=0 turns it off.
     static int bt12 = -1;
     if (bt12 < 0) { const char* v = getenv("MMHIP_BWD_TILE12"); bt12 = v ? atoi(v) : 1; }
     const int nt = (bt12 && Mr >= 4096 && Mr <= 8192 && H % 96 == 0) ? 12 : 0;
-    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mr, H, I); g.residual(dpre2, H).px_in(px); g.a.tile = nt; part_bwd(g, 2); if (int r = run_gemm(e, g, s)) return r; }
+    { G g(du, I, e.ws + w.fc1T, I, dx2, H, Mr, H, I); g.residual(dpre2, H).px_in(px, np); g.a.tile = nt; part_bwd(g, 2); if (int r = run_gemm(e, g, s)) return r; }
     // ---- a1 = LN1(pre1), pre1 = drop(ao(ctx)) + x_in        (dx2 = d_a1)
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
     LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mr, H,
@@ -969,13 +971,13 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     if (compact) {
         // d ctx for the CLS rows only, spread into an otherwise-zero full tensor for the attention backward (parity mode: pair rows of 2 H 16-bit
         // elements are moved as the H 4-byte words they occupy; an all-zero pair is zero)
-        { G g(dout, H, e.ws + w.aoT, H, dx2, H, Mr, H, H); g.px_in(px).px_out(px); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(dout, H, e.ws + w.aoT, H, dx2, H, Mr, H, H); g.px_in(px, np).px_out(px); if (int r = run_gemm(e, g, s)) return r; }
         CHECK_HIP(hipMemsetAsync(dctx, 0, (size_t)Mt * H * e.esz(), s));
         CHECK_HIP(launch_scatter_rows16(dx2, dctx, Bt, (size_t)T * H, H, 0, dt, s));
         CHECK_HIP(hipMemsetAsync(dqkv, 0, (size_t)Mt * 3 * H * e.esz(), s));      // dQ of the skipped query tiles is zero
     } else {
         G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H);
-        g.px_in(px).px_out(px);
+        g.px_in(px, np).px_out(px);
         g.a.tile = (bt12 & 2) ? nt : 0;
         part_bwd(g, 4);
         if (int r = run_gemm(e, g, s)) return r;
@@ -999,11 +1001,11 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     }
     if (compact) {
         // dx_in = dqkv . Wqkv, plus d pre1 on the CLS rows (the residual branch of the CLS rows)
-        { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.px_in(px); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.px_in(px, np); if (int r = run_gemm(e, g, s)) return r; }
         CHECK_HIP(launch_scatter_rows16(dpre1, dx, Bt, (size_t)T * H, H, 1, dt, s));
     } else {
         G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H);
-        g.residual(dpre1, H).px_in(px);
+        g.residual(dpre1, H).px_in(px, np);
         g.a.tile = nt;
         part_bwd(g, 8);
         if (int r = run_gemm(e, g, s)) return r;
@@ -1018,7 +1020,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     pr[3] = GemmTNProblem{dout, e.ws + a.ctx, Gd + o.ao_w, Mr, H, H, H, rs, H, 0, Gd + o.ao_b};        // dWo[H,H]   = dout^T ctx (CLS rows: stride T*H)
     if (px) {
         pr[1].B = e.ws + a.a1p;
-        for (auto& q : pr) { q.pair = 1; q.lda *= 2; q.ldb *= 2; q.a_lo = q.Nn; q.b_lo = q.Nc; }
+        for (auto& q : pr) { q.pair = 1; q.lda *= 2; q.ldb *= 2; q.a_lo = q.Nn; q.b_lo = q.Nc; q.nprod = np; }
     }
     {
         const int i = e.side && ps == e.side ? 1 : 0;
@@ -1100,6 +1102,7 @@ int mmhip_create(const mmhip_config* cfg, mmhip_handle* out) {
     if (!e) return MMHIP_E_INVALID;
     e->cfg = c;
     if (c.dtype == MMHIP_BF16X3) { const char* v = getenv("MMHIP_X3_PAIRS"); e->px = v ? atoi(v) != 0 : true; }
+    if (c.dtype == MMHIP_BF16X3) { const char* v = getenv("MMHIP_X3_BWD"); const int n = v ? atoi(v) : 3; e->bwd_np = n >= 1 && n <= 3 ? n : 3; }
     build_layout(*e);
     build_workspace(*e);
     *out = e;
@@ -1366,6 +1369,12 @@ int mmhip_set_step_guard(uint32_t* device_words2) {
 int mmhip_set_guard(mmhip_handle h, uint32_t* device_words2) {
     if (!h || ((uintptr_t)device_words2 & 3)) return MMHIP_E_INVALID;
     h->guard = device_words2;
+    return 0;
+}
+int mmhip_set_backward_products(mmhip_handle h, int products) {
+    if (!h || products < 1 || products > 3) return MMHIP_E_INVALID;
+    if (h->cfg.dtype != MMHIP_BF16X3 || !h->px) return products == 3 ? 0 : MMHIP_E_STATE;      // the 16-bit modes have one product; round 3's copy form has three
+    h->bwd_np = products;
     return 0;
 }
 int mmhip_set_loss_scale(mmhip_handle h, float loss_scale) {

@@ -360,12 +360,13 @@ void gemm_tn_kernel(GemmTNGroup g) {
     }
     // parity mode, plane pairs (mmhip_kernels.h): the M rows are walked three times -- (A hi, B hi), (A lo, B hi), (A hi, B lo)
     const int msteps = P.M / 64;
+    const int npr = P.pair ? (P.nprod == 2 ? 2 : 3) : 1;          // products per 64-row slice (GemmTNProblem::nprod; 1 comes in as plain hi planes)
     auto stage = [&](int buf, int mstep) {
         char* base = smem + buf * C::STAGE;
         size_t ao, bo;
         if (P.pair) {
             // the three products of one 64-row slice follow each other (second uses of a slice served from L2), g.pair_serial = the round-3 order
-            const int seg = g.pair_serial ? mstep / msteps : mstep % 3, r = g.pair_serial ? mstep - seg * msteps : mstep / 3;
+            const int seg = g.pair_serial ? mstep / msteps : mstep % npr, r = g.pair_serial ? mstep - seg * msteps : mstep / npr;
             ao = (size_t)r * 64 * P.lda + (seg == 1 ? (size_t)P.a_lo : 0);
             bo = (size_t)r * 64 * P.ldb + (seg == 2 ? (size_t)P.b_lo : 0);
         } else {
@@ -425,7 +426,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
             }
         }
     };
-    const int nsteps = P.pair ? 3 * msteps : msteps;
+    const int nsteps = npr * msteps;
     // the column sums may cover the first rows only (parity mode: the hi and lo planes of A = the first two of the three passes)
     const int cs_steps = P.pair ? nsteps : (P.colsum_rows > 0 ? P.colsum_rows / 64 : nsteps);
     const bool pair_ilv = P.pair && !g.pair_serial;          // (pairs: the column sums take A hi and A lo = the first two of every three steps)
@@ -451,7 +452,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
         for (int t = 0; t < nsteps; ++t) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            cs_now = with_colsum && t < cs_steps && (!P.pair || (pair_ilv ? t % 3 != 2 : t < 2 * msteps));
+            cs_now = with_colsum && t < cs_steps && (!P.pair || (pair_ilv ? t % npr != 2 : t < 2 * msteps));
             compute(buf);
             buf = (buf + 1 == NS) ? 0 : buf + 1;
         }
@@ -461,7 +462,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
         for (int t = 0; t < nsteps; ++t) {
             const int cur = t & 1;
             if (t + 1 < nsteps) stage(cur ^ 1, t + 1);
-            cs_now = with_colsum && t < cs_steps && (!P.pair || (pair_ilv ? t % 3 != 2 : t < 2 * msteps));
+            cs_now = with_colsum && t < cs_steps && (!P.pair || (pair_ilv ? t % npr != 2 : t < 2 * msteps));
             compute(cur);
             __syncthreads();
         }
@@ -477,7 +478,7 @@ void gemm_tn_kernel(GemmTNGroup g) {
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (t + NS - 1 < nsteps) stage(sbuf, t + NS - 1);
-            cs_now = with_colsum && t < cs_steps && (!P.pair || (pair_ilv ? t % 3 != 2 : t < 2 * msteps));
+            cs_now = with_colsum && t < cs_steps && (!P.pair || (pair_ilv ? t % npr != 2 : t < 2 * msteps));
             compute(buf);
             buf = (buf + 1 == NS) ? 0 : buf + 1;
             sbuf = (sbuf + 1 == NS) ? 0 : sbuf + 1;

@@ -256,7 +256,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
     const int tilesM0 = (g.p[0].M + C::BM - 1) / C::BM, tiles0 = tilesN * tilesM0;
     const int tilesM1 = g.count > 1 ? (g.p[1].M + C::BM - 1) / C::BM : 0, ntiles = tiles0 + tilesN * tilesM1;
     const int kseg = g.p[0].K / C::BK;               // K-tiles of one plane
-    const int nk = SEG ? 3 * kseg : kseg;
+    // SEG = 2 may run only the first two products of every slice -- (A hi, B hi), (A lo, B hi): GemmNTArgs::nprod = 2, B rounded to its hi plane
+    const int np2 = SEG == 2 && g.p[0].nprod == 2 ? 1 : 0;
+    const int nk = SEG ? (np2 ? 2 : 3) * kseg : kseg;
     // byte steps of the operand pointers at the two segment ends (on top of the ordinary 128 bytes): A hi -> A lo -> A hi, B hi -> B hi -> B lo
     const int segA1 = SEG == 1 ? (g.p[0].a_lo - g.p[0].K) * 2 : 0, segA2 = SEG == 1 ? -(g.p[0].a_lo + g.p[0].K) * 2 : 0;
     const int segB1 = SEG == 1 ? -g.p[0].K * 2 : 0, segB2 = SEG == 1 ? (g.p[0].b_lo - g.p[0].K) * 2 : 0;
@@ -337,9 +339,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
                 // g_ph = the product (0, 1, 2) just issued within its k slice (never moving while the group runs on past the end of the work
                 // list: g_inc = 0 there)
                 const int lv = g_inc[p] >> 7, ph = g_ph[p];
-                gA[p] += lv * (ph == 0 ? aLo2 : (ph == 1 ? -aLo2 : 128));
-                gB[p] += lv * (ph == 0 ? 0 : (ph == 1 ? bLo2 : 128 - bLo2));
-                g_ph[p] = ph == 2 ? 0 : ph + 1;
+                if (np2) {          // two products per slice: A +lo, then 128 - lo; B 0, then +128
+                    gA[p] += lv * (ph == 0 ? aLo2 : 128 - aLo2);
+                    gB[p] += lv * (ph == 0 ? 0 : 128);
+                    g_ph[p] = ph ^ 1;
+                } else {
+                    gA[p] += lv * (ph == 0 ? aLo2 : (ph == 1 ? -aLo2 : 128));
+                    gB[p] += lv * (ph == 0 ? 0 : (ph == 1 ? bLo2 : 128 - bLo2));
+                    g_ph[p] = ph == 2 ? 0 : ph + 1;
+                }
             } else if constexpr (SEG == 1) {
                 // g_rem K-tiles of the group's current tile are still to be issued: the next one opens segment 1 / segment 2
                 const int j1 = g_rem[p] == 2 * kseg ? (g_inc[p] >> 7) : 0, j2 = g_rem[p] == kseg ? (g_inc[p] >> 7) : 0;
@@ -610,7 +618,7 @@ static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
 static void launch_nt8_d(const GemmNTPair& g, int dtype, int bn, int persistent, hipStream_t s) {
     static int ilv = -1;
     if (ilv < 0) { const char* e = getenv("MMHIP_X3_INTERLEAVE"); ilv = e ? atoi(e) : 1; }
-    if (dtype == DT_F32 && g.p[0].a_pair && ilv) {          // parity mode, operands as plane pairs: the three products interleaved per k slice
+    if (dtype == DT_F32 && g.p[0].a_pair && (ilv || g.p[0].nprod == 2)) {          // parity mode, operands as plane pairs: the three (two) products interleaved per k slice
         if (bn == 256) launch_nt8_t<bf16_t, 256, float, 2>(g, persistent, s);
         else if (bn == 192) launch_nt8_t<bf16_t, 192, float, 2>(g, persistent, s);
         else launch_nt8_t<bf16_t, 128, float, 2>(g, persistent, s);

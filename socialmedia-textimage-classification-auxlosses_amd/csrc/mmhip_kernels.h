@@ -47,6 +47,9 @@ struct GemmNTArgs {
                               // text layer) is cut along K into slices that run side by side; a second kernel sums them and applies the epilogue
     int a_pair, b_pair;       // parity mode: A / B is a plane pair (lda / ldb in 16-bit elements), lo plane a_lo / b_lo elements behind the hi plane
     int a_lo, b_lo, c_lo;     // c_lo: lo-plane offset of C with GEMM_OUT_PAIR (ldc in 16-bit elements)
+    int nprod;                // plane pairs only: MFMA products per k slice -- 0 / 3: hi.hi + lo.hi + hi.lo (parity on the result); 2: hi.hi + lo.hi (B rounded
+                              // to its hi plane); 1: hi.hi only (both operands rounded to bf16, pair / fp32 epilogue kept).  The engine's backward policy
+                              // (mmhip_set_backward_products): north_star's 1e-3 is on logits and loss, the gradient bound is stated in DESIGN.md 4c
     int c_rps, c_rps_stride;  // > 0: output row m lands in row (m / c_rps) * c_rps_stride + m % c_rps of C -- the rows of a post written into a
                               // per-post padded layout (cross attention: Sq rows of a post inside its S-row block of the packed q|k|v buffer).
                               // gemm_nt_kernel tiles only (launch_gemm_nt routes such a problem there or fails); bias / aux / residual rows stay m
@@ -61,6 +64,7 @@ struct GemmTNProblem {
     int colsum_rows;          // > 0: the column sums cover rows 0 .. colsum_rows-1 only (a multiple of 64)
     int pair;                 // parity mode: A and B are plane pairs (lda / ldb in 16-bit elements, lo planes a_lo / b_lo elements behind): the kernel
     int a_lo, b_lo;           // walks the M rows three times -- (A hi, B hi), (A lo, B hi), (A hi, B lo) -- and the column sums cover A hi + A lo
+    int nprod;                // pairs: products per 64-row slice (0 / 3: all three; 2: (A hi, B hi), (A lo, B hi); 1: (A hi, B hi) -- GemmNTArgs::nprod)
 };
 struct GemmTNGroup {
     GemmTNProblem p[GEMM_TN_MAX_GROUP];

@@ -217,6 +217,7 @@ static bool nt_x3_fast(const GemmNTArgs& a, hipStream_t s) {
     if (pairs) {
         GemmNTArgs b = a;
         b.x3_ws = nullptr; b.splitk_ws = nullptr;
+        if (a.nprod == 1) { b.a_pair = b.b_pair = 0; }      // hi . hi only: the hi planes are ordinary bf16 matrices of leading dimension lda / ldb
         return launch_gemm_nt8(b, DT_F32, bn, 1, s);
     }
     GemmNTArgs b = a;
@@ -329,7 +330,9 @@ hipError_t launch_gemm_tn_x3(const GemmTNProblem* probs, int count, int accumula
         const GemmTNProblem& P = probs[i];
         if (P.pair) {          // plane pairs: the grouped kernel walks the planes itself (gemm.hip), no scratch
             if (P.M <= 0 || P.M % 64 || P.Nn % 256 || P.Nc % 128 || P.lda % 8 || P.ldb % 8 || P.a_lo % 8 || P.b_lo % 8 || !al(P.A) || !al(P.B) || nfast == GEMM_TN_MAX_GROUP) continue;
-            fastp[nfast++] = P;
+            fastp[nfast] = P;
+            if (P.nprod == 1) fastp[nfast].pair = 0;      // hi . hi only: the hi planes as ordinary bf16 matrices (the column sums then cover dY's hi plane)
+            ++nfast;
             taken[i] = true;
             continue;
         }

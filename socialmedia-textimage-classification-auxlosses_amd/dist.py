@@ -34,6 +34,43 @@ def init_from_env(backend=None):
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
     td.init_process_group(backend=backend)
+    check_shared_device()
+
+
+def _physical_device():
+    """(host, PCI location) of the GPU this rank drives, or None without one"""
+    if not torch.cuda.is_available():
+        return None
+    import socket
+    p = torch.cuda.get_device_properties(torch.cuda.current_device())
+    loc = tuple(getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    if all(v is None for v in loc):
+        loc = (os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")), torch.cuda.current_device())
+    return (socket.gethostname(),) + loc
+
+
+def check_shared_device(max_queues=4):
+    """Two ranks on ONE GPU (the gloo rehearsal of the N > 1 path on a one-GPU box) with GPU_MAX_HW_QUEUES above ROCm's default of 4 deadlocked in
+    round 4 (profiles/r04_hw_queues.txt, r05_two_ranks_hw_queues.txt): every process then maps its streams onto up to 8 hardware queues PER PRIORITY
+    LEVEL (the engine's side streams, torch's pool, and the high-priority pool streams gloo's device-tensor collectives copy on), two processes ask
+    for more hardware queues than the device has slots for, and the step's cross-queue event waits stop making progress once queues are
+    time-sliced.  One GPU per rank -- production -- never gets there.  So: refuse that combination (MMHIP_ALLOW_SHARED_HW_QUEUES=1 overrides, for
+    the one confirming run).  Returns the number of ranks sharing this rank's device."""
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() < 2:
+        return 1
+    mine = _physical_device()
+    all_ = [None] * td.get_world_size()
+    td.all_gather_object(all_, mine)
+    sharing = sum(1 for d in all_ if d is not None and d == mine)
+    q = os.environ.get("GPU_MAX_HW_QUEUES")
+    if sharing > 1 and q is not None and q.isdigit() and int(q) > max_queues:
+        msg = (f"{sharing} ranks share GPU {mine} and GPU_MAX_HW_QUEUES={q} (> {max_queues}): this combination deadlocked in the step's first collective wait "
+               "(DESIGN.md 6); unset GPU_MAX_HW_QUEUES or give every rank its own GPU")
+        if os.environ.get("MMHIP_ALLOW_SHARED_HW_QUEUES", "0") != "1":
+            raise RuntimeError(msg)
+        import warnings
+        warnings.warn(msg + " -- MMHIP_ALLOW_SHARED_HW_QUEUES=1: going on")
+    return sharing
 
 
 SKIP_EXCHANGE = False      # bench.py only: time the step without its collectives (replicas diverge; never set while training)

@@ -113,14 +113,15 @@ class MM_Model(nn.Module):
     """reference models/mm_late.py:50-193.
 
     MM_Model(num_labels, txt_model_name, img_model_name, dropout, fusion_name='concat'); keyword-only extras are
-    additive: `arch` overrides (layer counts, vocab ... for tests), `dtype` ('bf16' | 'f16' | 'bf16x3' = strict-parity mode), `max_posts` /
+    additive: `arch` overrides (layer counts, vocab ... for tests), `dtype` ('bf16' | 'f16' | 'bf16x3' = strict-parity mode; with it
+    `backward_products` = 3 | 2 | 1 bf16 MFMA products in the backward's matrix products, the forward always three), `max_posts` /
     `max_text_len` (capacity the workspace is sized for), `device`, `seed`.
     Weights: loaded from the local directories of config.MODEL_DIR_DICT when they exist (HF layout), else random
     init at the architecture's true shapes (no network in this environment).
     """
 
     def __init__(self, num_labels, txt_model_name, img_model_name, dropout, fusion_name="concat", *, arch=None,
-                 dtype="bf16", max_posts=64, max_text_len=128, device=None, seed=0):
+                 dtype="bf16", max_posts=64, max_text_len=128, device=None, seed=0, backward_products=None):
         super().__init__()
         if not torch.cuda.is_available():
             raise _lib.MMHipError("MM_Model needs an MI355X (gfx950) GPU: the HIP path has no CPU fallback")
@@ -151,6 +152,11 @@ class MM_Model(nn.Module):
                                       "models/mm_late.py:74-75): use fusion_name='concat' with the CLIP-ViT-L/14 tower")
         self.arch = a
         self.dtype_name = dtype
+        # parity mode only (include/mmhip.h mmhip_set_backward_products): MFMA products per reduction slice in the backward's matrix products;
+        # None = the library's default (3, or MMHIP_X3_BWD).  The forward -- logits and loss -- always takes three.
+        if backward_products is not None and (dtype != "bf16x3" or int(backward_products) not in (1, 2, 3)):
+            raise ValueError("backward_products is 1, 2 or 3 and belongs to dtype='bf16x3'")
+        self.backward_products = None if backward_products is None else int(backward_products)
         self._cfg_kw = dict(hidden=a["hidden"], heads=a["heads"], inter=a["inter"], layers_txt=a["layers_txt"], layers_img=a["layers_img"],
                             vocab=a["vocab"], max_pos=a["max_pos"], type_vocab=a["type_vocab"],
                             txt_kind=_lib.TXT_XLMR if a["txt_kind"] == "xlmr" else _lib.TXT_BERT, pad_id=a["pad_id"],
@@ -209,6 +215,8 @@ class MM_Model(nn.Module):
         _lib.check(lib.mmhip_set_guard(h, _lib.ptr(self._nonfinite)), "set_guard")
         if self._loss_scale > 0:
             _lib.check(lib.mmhip_set_loss_scale(h, self._loss_scale), "set_loss_scale")
+        if self.backward_products is not None:
+            _lib.check(lib.mmhip_set_backward_products(h, self.backward_products), "set_backward_products")
         self._ws = None
         torch.cuda.empty_cache()
         self._ws = torch.empty(lib.mmhip_workspace_bytes(h), dtype=torch.uint8, device=dev)

@@ -160,3 +160,49 @@ def test_sharded_optimizer_exchange_equals_allreduce(world):
     for _, err, same, covered, frac, nplan, nbytes in res:
         assert err < 1e-5 and same and covered and nbytes == 203 * 4 and nplan >= 2
         assert frac < 1.0 / world + 0.25, frac
+
+
+def _guard_worker(rank, world, port, q):
+    """dist.check_shared_device: two ranks that report the same physical GPU and GPU_MAX_HW_QUEUES > 4 is the combination that deadlocked in round 4
+    (profiles/r04_hw_queues.txt) -- refused unless overridden; the default queue count, or a GPU per rank, passes"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.pop("GPU_MAX_HW_QUEUES", None)
+    os.environ.pop("MMHIP_ALLOW_SHARED_HW_QUEUES", None)
+    mmdist.init_from_env(backend="gloo")
+    out = []
+    real = mmdist._physical_device
+    mmdist._physical_device = lambda: ("host", 0, 5, 0)              # both ranks on one card
+    out.append(mmdist.check_shared_device())                         # default queue count: fine, 2 ranks share
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    try:
+        mmdist.check_shared_device()
+        out.append("no error")
+    except RuntimeError as exc:
+        out.append("refused" if "GPU_MAX_HW_QUEUES=8" in str(exc) else str(exc))
+    os.environ["MMHIP_ALLOW_SHARED_HW_QUEUES"] = "1"
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out.append(mmdist.check_shared_device())
+        out.append(len(w))
+    os.environ.pop("MMHIP_ALLOW_SHARED_HW_QUEUES")
+    mmdist._physical_device = lambda: ("host", 0, 5 + rank, 0)       # a card per rank: 8 queues are the user's business
+    out.append(mmdist.check_shared_device())
+    mmdist._physical_device = real
+    q.put((rank, out))
+    td.destroy_process_group()
+
+
+def test_shared_device_with_many_hardware_queues_is_refused():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, out in res:
+        assert out == [2, "refused", 2, 1, 1], out

@@ -157,6 +157,89 @@ def test_train_losses_and_grads_match_reference_golden(dtype, path):
         assert float(np.median(list(worst.values()))) < TOL_GRAD_MEDIAN[dtype], (mix, sorted(worst.values()))
 
 
+# Parity mode, backward product count (include/mmhip.h mmhip_set_backward_products).  The forward always takes three bf16 MFMA
+# products per reduction slice, so logits and loss keep bf16x3's tolerance whatever the backward does; with 2 / 1 products the gradients carry
+# the bf16 rounding of one / both operands of the backward's matrix products AT THE MATRIX CORES (stores stay plane pairs / fp32).
+# Measured (tools/x3_bwd_policy.py, profiles/r05_x3_bwd_policy.txt), relative L2 per tensor against the fp32 oracle, worst tensor:
+#   2 text layers   3: 4.4e-5   2: 2.8e-3   1: 4.2e-3        12 text layers   3: 4.2e-5   2: 4.4e-3   1: 6.1e-3   (1 - cos of the flat gradient: 7e-6)
+TOL_GRAD_BWD_PRODUCTS = {2: 8e-3, 1: 1.2e-2}
+
+
+@pytest.mark.parametrize("products", [2, 1])
+def test_backward_product_policy_keeps_outputs_and_bounds_gradients(products):
+    """(a) one step: outputs and loss within bf16x3's tolerance, every gradient tensor within the stated bound, flat gradient parallel to the
+    oracle's to 1e-4; (b) four AdamW steps at lr 1e-4 (ten times the reference's): the loss trajectory and the logits after the last step stay
+    within north_star's 1e-3 of the fp32 oracle trained by its own AdamW -- the looser backward does not leak into what the tolerance is stated on"""
+    from smtc_amd import _lib
+    cfg = O.OracleConfig(layers_txt=4, layers_img=2, vocab=800, max_pos=130, num_labels=3, p_hidden=0.0, p_attn=0.0, p_head=0.0)
+    B, T = 4, 64
+    arch = dict(layers_txt=cfg.layers_txt, layers_img=cfg.layers_img, vocab=cfg.vocab, max_pos=cfg.max_pos, type_vocab=cfg.type_vocab, p_hidden=0.0, p_attn=0.0)
+    model = MM_Model(3, "bernice", "vit", 0.0, "attention", arch=arch, dtype="bf16x3", max_posts=B, max_text_len=T, backward_products=products)
+    with pytest.raises(ValueError):
+        MM_Model(3, "bernice", "vit", 0.0, "attention", arch=arch, dtype="bf16", max_posts=B, max_text_len=T, backward_products=1)
+    P = O.make_params(cfg, 21)
+    load_oracle_params(model, P)
+    model.train()
+    ids, mask, pixels, onehot = O.synthetic_batch(cfg, B, T, 9, True)
+    np.random.seed(30)
+    tim_ids, tim_mask, lbl = O.prepare_itm_inputs(ids, mask)
+    dev = model.device_
+    model._flat_grad.zero_()
+    model._engine_forward(ids, mask, pixels, tim_ids, tim_mask, seed=3)
+    lo = torch.empty(4, device=dev)
+    oh, lt = onehot.to(dev).contiguous(), lbl.to(dev)
+    _lib.check(_lib.lib().mmhip_loss(model._handle, _lib.ptr(oh), None, _lib.ptr(lt), 0.8, 0.1, 0.1, _lib.ptr(lo), None, _lib.stream_ptr()))
+    _lib.check(_lib.lib().mmhip_backward(model._handle, None, None, None, None, _lib.stream_ptr()))
+    Pg = {k: v.clone().requires_grad_(O.trainable(k)) for k, v in P.items()}
+    r_cls, r_lpt, r_tim, _, _ = O.mm_forward(Pg, ids, mask, pixels, cfg, (tim_ids, tim_mask))
+    ref = O.mix_loss(r_cls, onehot, None, r_lpt, r_tim, lbl, True, True)
+    ref.backward()
+    assert abs(lo[0].item() - ref.item()) < TOL_LOSS["bf16x3"] * abs(ref.item())
+    errs, dot, na, nb = {}, 0.0, 0.0, 0.0
+    for i in model._train_params:
+        k = i["name"]
+        if Pg[k].grad is None or k.endswith("key.bias") or k == "fc_K.bias":
+            continue
+        g = model._flat_grad[i["offset"]: i["offset"] + i["numel"]].view(i["shape"]).double().cpu()
+        r = Pg[k].grad.double()
+        errs[k] = (g - r).norm().item() / max(r.norm().item(), 1e-30)
+        dot += float((g * r).sum()); na += float((g * g).sum()); nb += float((r * r).sum())
+    worst = max(errs, key=errs.get)
+    print("BWD_PRODUCTS", products, "worst", worst, "%.3g" % errs[worst], "median %.3g" % float(np.median(list(errs.values()))), "1-cos %.3g" % (1 - dot / (na * nb) ** 0.5))
+    assert errs[worst] < TOL_GRAD_BWD_PRODUCTS[products], (worst, errs[worst])
+    assert errs[worst] > 1e-4, "the policy did not take effect (gradients as exact as with three products)"
+    assert 1 - dot / (na * nb) ** 0.5 < 1e-4
+    # ---- (b) a short training run on both sides
+    import types
+    cfgd = types.SimpleNamespace(batch_size=B, num_labels=3, use_clip_loss=True, beta_itc=0.1, use_tim_loss=True, beta_itm=0.1, max_length=T, dropout=0.0)
+    tr = MMLate_Model(cfgd, "bernice", "vit", "attention", arch=arch, seed=3, dtype="bf16x3", backward_products=products)
+    load_oracle_params(tr.model, P)
+    tr.model._refresh_weights(3)
+    Pt = {k: v.clone().requires_grad_(O.trainable(k)) for k, v in P.items()}
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in Pt.items()}
+    lr, wd = 1e-4, 2.5e-4
+    for step in range(1, 5):
+        loss, _ = tr.train_step(ids.to(dev), mask.to(dev), pixels, onehot, None, lr, wd, step, tim=(tim_ids.to(dev), tim_mask.to(dev), lbl.to(dev)))
+        for q in Pt.values():
+            q.grad = None
+        o_cls, o_lpt, o_tim, _, _ = O.mm_forward(Pt, ids, mask, pixels, cfg, (tim_ids, tim_mask))
+        rl = O.mix_loss(o_cls, onehot, None, o_lpt, o_tim, lbl, True, True)
+        rl.backward()
+        assert abs(loss[0].item() - rl.item()) < 1e-3 * abs(rl.item()), (step, loss[0].item(), rl.item())
+        with torch.no_grad():
+            for k, q in Pt.items():
+                if q.grad is not None:                      # torch.optim.AdamW skips `grad is None` tensors (SURVEY.md 8c (4))
+                    O.adamw_step(q, q.grad, mom[k][0], mom[k][1], step, lr, wd)
+    tr.model.eval()
+    with torch.no_grad():
+        g_cls, g_lpt, g_tim, _, g_feats = tr.model(ids, mask, pixels, tim_inputs=(tim_ids, tim_mask))
+        o_cls, o_lpt, o_tim, _, o_feats = O.mm_forward({k: v.detach() for k, v in Pt.items()}, ids, mask, pixels, cfg, (tim_ids, tim_mask))
+    after = {k: rel_err(a, b) for k, a, b in (("out_cls", g_cls, o_cls), ("logits_per_text", g_lpt, o_lpt), ("out_tim", g_tim, o_tim), ("mm_features", g_feats, o_feats))}
+    print("BWD_PRODUCTS", products, "after 4 steps", after)
+    for k, e in after.items():
+        assert e < 1e-3, (k, e)
+
+
 # per-tensor bounds against the ROUNDING-EMULATING oracle (oracle/mm_oracle.py `rounding`): an fp32 execution that rounds both operands of
 # every tower matrix product, every stored activation and every stored gradient to the dtype where the HIP path does.  What is left
 # between the two is the noise of single rounding decisions (fp32 summation order flips an operand by one 16-bit ulp), not twelve layers
