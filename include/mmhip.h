@@ -28,7 +28,9 @@ extern "C" {
 /* MMHIP_BF16X3 (as mmhip_config.dtype): the strict-parity mode -- activations stay fp32 in HBM (same value as MMHIP_F32, the
  * element type the op-level entry points then take) and every Linear runs as three bf16 MFMA products of hi/lo-split
  * operands (csrc/x3.hip); ~1e-5 on the logits against the fp32 reference, where bf16 gives 5e-3..2e-2 and f16 1e-3..3e-3 */
-enum { MMHIP_BF16 = 0, MMHIP_F16 = 1, MMHIP_F32 = 2, MMHIP_BF16X3 = 2 };
+enum { MMHIP_BF16 = 0, MMHIP_F16 = 1, MMHIP_F32 = 2, MMHIP_BF16X3 = 2,
+       MMHIP_PAIR = 3 };   /* op-level entry points that say so only: the parity mode's tensors as the engine stores them -- bf16 PLANE PAIRS, a row of W values =
+                              [hi = bf16(x) (W) | lo = bf16(x - hi) (W)], the same bytes as the fp32 row (csrc/mmhip_kernels.h) */
 enum { MMHIP_TXT_BERT = 0, MMHIP_TXT_XLMR = 1 };
 enum { MMHIP_IMG_VIT = 0, MMHIP_IMG_CLIP = 1 };   /* HF ViTModel | HF CLIPVisionModel (pre-LN, quick-GELU, bias-free patch conv, pre_layrnorm) */
 enum { MMHIP_FUSION_CONCAT = 0, MMHIP_FUSION_ATTENTION = 1 };
@@ -187,6 +189,12 @@ int mmhip_adamw_rows_guarded(float* p, float* g, float* m, float* v, int rows, i
                              float beta2, float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream,
                              uint32_t* guard_words2);
 int mmhip_set_loss_scale(mmhip_handle h, float loss_scale);
+/* Clamped-index counter.  mmhip_forward / mmhip_train_step clamp token ids into [0, vocab) on their way into the engine (above: why); the reference
+ * raises IndexError for such an id on the CPU (nn.Embedding).  With a device word registered here every clamped index adds 1 to it, so a caller can
+ * turn the silent wrong row into the reference's error one step late and without a synchronisation (the shipped binding copies the word to pinned
+ * memory with the overflow guard's and raises IndexError at the next step / at the end of an evaluation loop).  NULL = do not count.
+ * mmhip_early_set_index_counter: the same for the early-fusion engine (token ids, token types). */
+int mmhip_set_index_counter(mmhip_handle h, uint32_t* device_word);
 /* Parity mode (MMHIP_BF16X3) only: how many bf16 MFMA products the BACKWARD's matrix products (activation gradients dX = dY . W, weight
  * gradients dW = dY^T . X of the text tower) take per reduction slice.  3 (default): hi.hi + lo.hi + hi.lo, as the forward -- gradients
  * within 1e-3 of the fp32 reference (measured 3e-5).  2: hi.hi + lo.hi -- the second operand (W, X) is read rounded to bf16.  1: hi.hi --
@@ -220,7 +228,17 @@ int mmhip_train_step(mmhip_handle h, const int64_t* ids, const int64_t* mask, co
  *   on_stage(user, MMHIP_CB_FINISH_ROWS)  after the dense AdamW and the 16-bit weight refresh were enqueued: finish the row-sparse
  *                       word-table exchange (it travelled meanwhile); the row-lazy AdamW of the table follows.
  * A non-zero return aborts the step with that code.  grad_scale = 1 / world.  Everything else as mmhip_train_step. */
-enum { MMHIP_CB_WAIT_DENSE = -1, MMHIP_CB_FINISH_ROWS = -2 };
+enum { MMHIP_CB_WAIT_DENSE = -1, MMHIP_CB_FINISH_ROWS = -2, MMHIP_CB_WAIT_BUCKET = -3 };
+/* Per-bucket optimizer (round 5).  on_stage(user, st) may return MMHIP_CB_BUCKET instead of 0: "the collective that carries the gradients of every
+ * stage since my last MMHIP_CB_BUCKET answer, st included, has been started".  If the library runs the layer optimizers beside the backward (side
+ * stream on), it then calls on_stage(user, MMHIP_CB_WAIT_BUCKET): the caller makes the library's SIDE stream (mmhip_side_stream) wait for that
+ * collective -- with RCCL a stream-side wait, nothing blocks on the host -- and returns 0, upon which the AdamW and the operand refresh of the text
+ * layers the bucket carries are enqueued on the side stream, beside the backward stages below, exactly as in the single-rank step; or it returns
+ * MMHIP_CB_HANDLED after running the optimizer of the bucket's dense ranges itself ON THAT STREAM (sharded optimizer), and only the refresh follows.
+ * Ranges that are not text layers, and stages after the last MMHIP_CB_BUCKET answer, stay behind MMHIP_CB_WAIT_DENSE.  A caller that never answers
+ * MMHIP_CB_BUCKET gets round 4's single barrier. */
+enum { MMHIP_CB_BUCKET = 2 };
+void* mmhip_side_stream(mmhip_handle h);      /* hipStream_t of the library's side stream of the backward, NULL when MMHIP_OVERLAP=0 */
 /* on_stage(user, MMHIP_CB_WAIT_DENSE) may return MMHIP_CB_HANDLED instead of 0: the caller has run the optimizer over the DENSE parameter
  * ranges itself (sharded: reduce-scatter of the gradients, AdamW on the rank's own shard with moments only it keeps, all-gather of the updated
  * parameters -- smtc_amd/dist.py ShardedBuckets); the library then skips its dense AdamW launches and goes on with the 16-bit weight refresh
@@ -338,7 +356,9 @@ int mmhip_op_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma
                            int rows, int width, float eps, void* stream);
 int mmhip_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                            void* dx, const void* dres, float* dgamma, float* dbeta, int rows, int width, void* stream);
-/* qkv [posts*S, 3*hidden] packed q|k|v; maskbias fp32 [posts,S] additive (0 / -inf) or NULL; lse fp32 [posts,heads,S] */
+/* qkv [posts*S, 3*hidden] packed q|k|v; maskbias fp32 [posts,S] additive (0 / -inf) or NULL; lse fp32 [posts,heads,S].
+ * dtype MMHIP_PAIR: qkv / ctx / dctx / dqkv are plane pairs (rows of 2 * 3 * hidden resp. 2 * hidden bf16), three MFMA products per matrix product;
+ * mmhip_op_layernorm_fwd with MMHIP_PAIR: x fp32, y a plane pair (rows of 2 * width bf16) */
 int mmhip_op_attn_fwd(int dtype, const void* qkv, const float* maskbias, void* ctx, float* lse, int posts, int S, int heads,
                       float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
 int mmhip_op_attn_bwd(int dtype, const void* qkv, const float* maskbias, const void* ctx, const void* dctx, const float* lse,
@@ -380,6 +400,7 @@ uint64_t mmhip_early_workspace_bytes(mmhip_early_handle h);
 int mmhip_early_bind(mmhip_early_handle h, float* params, float* grads, void* workspace, uint64_t workspace_bytes, void* stream);
 /* 16-bit (parity mode: fp32) operand copies of the weights + transposed copies; call after the parameters changed */
 int mmhip_early_refresh_weights(mmhip_early_handle h, void* stream);
+int mmhip_early_set_index_counter(mmhip_early_handle h, uint32_t* device_word);      /* see mmhip_set_index_counter */
 /* Lxmert.forward.  ids / mask / token_type_ids (may be NULL = zeros): int64 [B, T]; feats fp32 [B, Nb, feat_dim]; boxes fp32 [B, Nb, pos_dim];
  * tim_*: the swapped texts of the ITM pass (NULL = no ITM) -- both passes run as ONE encoder pass of 2B posts.  Outputs (may be NULL) fp32:
  * out [B, num_labels], emb_t [B, H] (masked max over tokens, detached), emb_v [B, H] (max over boxes), out_tim [B, 2]. */

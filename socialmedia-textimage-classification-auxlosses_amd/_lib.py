@@ -50,8 +50,9 @@ class MMHipError(RuntimeError):
 
 
 EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)      # include/mmhip.h: mmhip_exchange_cb
-CB_WAIT_DENSE, CB_FINISH_ROWS = -1, -2
+CB_WAIT_DENSE, CB_FINISH_ROWS, CB_WAIT_BUCKET = -1, -2, -3
 CB_HANDLED = 1               # include/mmhip.h MMHIP_CB_HANDLED: the caller ran the dense optimizer itself
+CB_BUCKET = 2                # include/mmhip.h MMHIP_CB_BUCKET: a collective carrying every stage since the last such answer has been started
 _lib = None
 P, I, F, U64, U32, I64P = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p
 
@@ -86,6 +87,9 @@ _SIGS = {
     "mmhip_adamw_rows_guarded": (I, [P, P, P, P, I, I, P, F, F, F, F, F, I, F, I, P, P]),
     "mmhip_set_loss_scale": (I, [P, F]),
     "mmhip_set_backward_products": (I, [P, I]),
+    "mmhip_side_stream": (P, [P]),
+    "mmhip_set_index_counter": (I, [P, P]),
+    "mmhip_early_set_index_counter": (I, [P, P]),
     "mmhip_train_step": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P]),
     "mmhip_train_step_dp": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P, P, P]),
     "mmhip_image_plan_words": (U64, [I, P, P, I]),

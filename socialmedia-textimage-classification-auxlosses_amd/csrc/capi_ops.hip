@@ -398,6 +398,10 @@ int mmhip_op_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma
                            int rows, int width, float eps, void* stream) {
     if (!x || !y || !gamma || !beta) return MMHIP_E_INVALID;
     LNArgs a{x, y, gamma, beta, mean, rstd, rows, width, width, width, eps};
+    if (dtype == MMHIP_PAIR) {          // parity mode as the engine runs it: fp32 rows in, the output as a plane pair only ([hi(width) | lo(width)] per row)
+        a.y = nullptr; a.y_pair = y; a.ld_pair = 2 * width; a.lo_pair = width;
+        dtype = MMHIP_F32;
+    }
     CHECK_HIP(launch_layernorm_fwd(a, dtype, (hipStream_t)stream));
     return 0;
 }
@@ -419,6 +423,7 @@ int mmhip_op_attn_fwd(int dtype, const void* qkv, const float* maskbias, void* c
     a.qkv = qkv; a.maskbias = maskbias; a.ctx = ctx; a.lse = lse; a.posts = posts; a.S = S; a.heads = heads;
     a.hidden = heads * 64; a.ld_qkv = 3 * a.hidden; a.ld_ctx = a.hidden; a.scale = 0.125f;
     a.drop = drop_of(p_drop, seed, stream_id);
+    if (dtype == MMHIP_PAIR) { a.pair = 1; a.ld_qkv = 6 * a.hidden; a.lo_qkv = 3 * a.hidden; a.ld_ctx = 2 * a.hidden; a.lo_ctx = a.hidden; dtype = MMHIP_F32; }
     CHECK_HIP(launch_attn_fwd(a, dtype, (hipStream_t)stream));
     return 0;
 }
@@ -430,6 +435,7 @@ int mmhip_op_attn_bwd(int dtype, const void* qkv, const float* maskbias, const v
     a.qkv = qkv; a.maskbias = maskbias; a.ctx = ctx; a.dctx = dctx; a.lse = lse; a.dqkv = dqkv; a.posts = posts; a.S = S; a.heads = heads;
     a.hidden = heads * 64; a.ld_qkv = 3 * a.hidden; a.ld_ctx = a.hidden; a.scale = 0.125f;
     a.drop = drop_of(p_drop, seed, stream_id);
+    if (dtype == MMHIP_PAIR) { a.pair = 1; a.ld_qkv = 6 * a.hidden; a.lo_qkv = 3 * a.hidden; a.ld_ctx = 2 * a.hidden; a.lo_ctx = a.hidden; dtype = MMHIP_F32; }
     CHECK_HIP(launch_attn_bwd(a, dtype, (hipStream_t)stream));
     return 0;
 }

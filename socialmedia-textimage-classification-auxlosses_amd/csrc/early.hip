@@ -204,6 +204,7 @@ DropCfg drop_cfg(float p, uint64_t seed, uint32_t stream, bool on) {
 }  // namespace
 
 struct mmhip_early {
+    unsigned* bad_index = nullptr;      // caller-owned device word: indices (token ids, token types, ITM source rows) that had to be clamped (mmhip_early_set_index_counter)
     mmhip_early_config cfg;
     std::vector<mmhip_param_info> params;
     size_t n_params = 0;
@@ -902,6 +903,11 @@ int mmhip_early_bind(mmhip_early_handle h, float* params, float* grads, void* wo
     CHECK_HIP(hipMemsetAsync(h->ws + h->vbias, 0, Pm * h->cfg.max_boxes * 4, (hipStream_t)stream));      // every box is a live key
     return 0;
 }
+int mmhip_early_set_index_counter(mmhip_early_handle h, uint32_t* device_word) {
+    if (!h || ((uintptr_t)device_word & 3)) return MMHIP_E_INVALID;
+    h->bad_index = device_word;
+    return 0;
+}
 int mmhip_early_refresh_weights(mmhip_early_handle h, void* stream) {
     if (!h || !h->ws) return MMHIP_E_STATE;
     return refresh(*h, (hipStream_t)stream);
@@ -938,14 +944,14 @@ static int forward_impl(mmhip_early_handle h, const int64_t* ids, const int64_t*
     const size_t nb = (size_t)B * T * 8;
     // indices are clamped into their tables on the way into the engine's copies (launch_copy_ids_clamped: why)
     const size_t nt = (size_t)B * T;
-    CHECK_HIP(launch_copy_ids_clamped(ids, e.wsp<int64_t>(e.ids_all), nt, e.cfg.vocab, nullptr, s));
+    CHECK_HIP(launch_copy_ids_clamped(ids, e.wsp<int64_t>(e.ids_all), nt, e.cfg.vocab, e.bad_index, s));
     CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all, mask, nb, hipMemcpyDeviceToDevice, s));
-    if (token_type_ids) CHECK_HIP(launch_copy_ids_clamped(token_type_ids, e.wsp<int64_t>(e.tt_all), nt, e.cfg.type_vocab, nullptr, s));
+    if (token_type_ids) CHECK_HIP(launch_copy_ids_clamped(token_type_ids, e.wsp<int64_t>(e.tt_all), nt, e.cfg.type_vocab, e.bad_index, s));
     else CHECK_HIP(hipMemsetAsync(e.ws + e.tt_all, 0, nb, s));
     if (tim_ids) {
-        CHECK_HIP(launch_copy_ids_clamped(tim_ids, e.wsp<int64_t>(e.ids_all) + nt, nt, e.cfg.vocab, nullptr, s));
+        CHECK_HIP(launch_copy_ids_clamped(tim_ids, e.wsp<int64_t>(e.ids_all) + nt, nt, e.cfg.vocab, e.bad_index, s));
         CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all + nb, tim_mask, nb, hipMemcpyDeviceToDevice, s));
-        if (tim_token_type_ids) CHECK_HIP(launch_copy_ids_clamped(tim_token_type_ids, e.wsp<int64_t>(e.tt_all) + nt, nt, e.cfg.type_vocab, nullptr, s));
+        if (tim_token_type_ids) CHECK_HIP(launch_copy_ids_clamped(tim_token_type_ids, e.wsp<int64_t>(e.tt_all) + nt, nt, e.cfg.type_vocab, e.bad_index, s));
         else CHECK_HIP(hipMemsetAsync(e.ws + e.tt_all + nb, 0, nb, s));
     } else if (itm_src) {
         const int grid = (B * T + 255) / 256;

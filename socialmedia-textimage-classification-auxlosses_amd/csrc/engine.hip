@@ -66,6 +66,7 @@ struct mmhip_engine {
     size_t g_partial, g_partial_side, g_det_rows = 0;
     size_t g_lnp[2][2];      // LN-backward partials per (layer parity, LN index): reduced on the side stream with the layer's dW
     uint8_t* word_row_state = nullptr;     // caller-owned row flags of the word table (mmhip_set_row_state)
+    unsigned* bad_index = nullptr;         // caller-owned device word counting token ids that had to be clamped into the word table (mmhip_set_index_counter)
     unsigned* guard = nullptr;             // caller-owned overflow-guard words of THIS handle, {counter, void-step flag} (mmhip_set_guard); null: the
                                            // process-wide registration of mmhip_set_step_guard, if any
     size_t g_set[2][6];      // double-buffered backward temporaries read by the side stream: dpre2, ddrop2, du, dpre1, ddrop1, dqkv
@@ -458,7 +459,7 @@ int run_gemm(mmhip_engine& e, G& g, hipStream_t s) {
 }
 // two GEMMs of equal N and K (the two towers' same-named GEMM of one layer) in ONE persistent launch; falls back to two launches
 int run_gemm_pair(mmhip_engine& e, G& g0, G& g1, hipStream_t s) {
-    const bool pairable = (e.dt() == DT_BF16 || e.dt() == DT_F16) && g0.a.N == g1.a.N && g0.a.K == g1.a.K;
+    const bool pairable = (e.dt() == DT_BF16 || e.dt() == DT_F16 || (e.dt() == DT_F32 && g0.a.a_pair && g1.a.a_pair)) && g0.a.N == g1.a.N && g0.a.K == g1.a.K;
     mmhip_engine::Ev* ev = nullptr;
     if (e.timing && pairable) {
         if (e.ev_used == e.evs.size()) {
@@ -648,9 +649,14 @@ int text_forward(mmhip_engine& e, hipStream_t s) {
 // (every kernel alone on the chip), and the step takes 11.2 ms against 12.2 ms with the side streams off -- but 10.4 ms with the
 // image tower on its own stream, where kernels of the two towers share CUs.  Hence opt-in: MMHIP_LOCKSTEP=1.
 bool lockstep_ok(const mmhip_engine& e) {
-    static int on = -1;
-    if (on < 0) { const char* v = getenv("MMHIP_LOCKSTEP"); on = v ? atoi(v) : 0; }
-    return on && (e.dt() == DT_BF16 || e.dt() == DT_F16) && !e.clip() && e.Hv() == e.cfg.hidden && e.Iv() == e.cfg.inter &&
+    // MMHIP_LOCKSTEP: 1 = on, 0 = off; unset = on in the parity mode with plane pairs only.  There every GEMM is three times as long, two towers on
+    // two streams finish together in the SUM of their kernels' times (13.0 ms of forward for 12.4 ms of GEMMs measured alone, round 5) -- the
+    // streams buy nothing -- while the paired launches fill 96 % of their rounds instead of 78 % / 75 % (QKV: 600 + 384 tiles of 256 x 192 =
+    // 3.84 rounds of 256 instead of 2.34 -> 3 and 1.5 -> 2).  In the 16-bit modes the two streams win (above).
+    static int on = -2;
+    if (on == -2) { const char* v = getenv("MMHIP_LOCKSTEP"); on = v ? atoi(v) : -1; }
+    const bool want = on > 0 || (on < 0 && e.dt() == DT_F32 && e.px);
+    return want && (e.dt() == DT_BF16 || e.dt() == DT_F16 || (e.dt() == DT_F32 && e.px)) && !e.clip() && e.Hv() == e.cfg.hidden && e.Iv() == e.cfg.inter &&
            e.cfg.layers_txt > 0 && e.cfg.layers_img > 0;
 }
 int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s) {
@@ -659,10 +665,14 @@ int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s)
     const int Mv = B * P;
     const float* W = e.train;
     const float* F = e.frozen;
-    const bool tr = e.train_mode;
+    const bool tr = e.train_mode, px = e.px;
+    auto ln_to = [&](LNArgs& ln, size_t pair_buf, int Wd) {          // parity mode: a LayerNorm output that only GEMMs read goes out as a plane pair only
+        if (px) { ln.y = nullptr; ln.y_pair = e.ws + pair_buf; ln.ld_pair = 2 * Wd; ln.lo_pair = Wd; }
+    };
+    if (int r = e.span(0, s)) return r;
     // ---- embeddings of both towers
-    CHECK_HIP(launch_patchify(pixels, e.ws + e.v_patches, B, c.image, c.patch, Kpp, dt, s));
-    { G g(e.ws + e.v_patches, Kpp, e.ws + e.patch_w16, Kpp, e.ws + e.v_pe, H, B * (P - 1), H, Kpp); g.bias(F + e.v_patch_b); if (int r = run_gemm(e, g, s)) return r; }
+    CHECK_HIP(launch_patchify(pixels, e.ws + e.v_patches, B, c.image, c.patch, Kpp, px ? DT_PAIR : dt, s));
+    { G g(e.ws + e.v_patches, Kpp, e.ws + e.patch_w16, Kpp, e.ws + e.v_pe, H, B * (P - 1), H, Kpp); g.bias(F + e.v_patch_b).px_in(px); if (int r = run_gemm(e, g, s)) return r; }
     CHECK_HIP(launch_vit_assemble(e.ws + e.v_pe, F + e.v_cls, F + e.v_pos, e.ws + e.v_x, B, P, H, dt, s));
     char* xv = e.ws + e.v_x;
     EmbedArgs ea;
@@ -673,11 +683,24 @@ int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s)
     ea.maskbias = e.wsp<float>(e.maskbias);
     ea.posts = Bt; ea.T = T; ea.H = H; ea.xlmr = c.txt_kind == MMHIP_TXT_XLMR; ea.pad_id = c.pad_id; ea.eps = c.ln_eps_txt;
     ea.drop = make_drop(c.p_hidden, e.seed, STREAM_EMBED, tr);
+    if (px) { ea.x_pair = e.ws + e.x0p; ea.ld_pair = 2 * H; ea.lo_pair = H; }
     CHECK_HIP(launch_embed_fwd(ea, dt, s));
     const char* xt = e.ws + e.x0;
+    const char* xtg = px ? e.ws + e.x0p : xt;          // the text layer input as the GEMMs read it
     if (e.cls_only < 0) { const char* v = getenv("MMHIP_CLS_ONLY"); e.cls_only = v ? atoi(v) : 1; }
     e.cls_compact = false;
     const int L = c.layers_txt > c.layers_img ? c.layers_txt : c.layers_img;
+    auto attn = [&](const char* qkv, const float* mb, char* ctx, float* lse, int posts, int S, int heads, const DropCfg* d, int q_tiles) -> int {
+        AttnArgs at;
+        memset(&at, 0, sizeof(at));
+        at.qkv = qkv; at.maskbias = mb; at.ctx = ctx; at.lse = lse; at.posts = posts; at.S = S; at.heads = heads; at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
+        if (px) { at.pair = 1; at.ld_qkv = 6 * H; at.lo_qkv = 3 * H; at.ld_ctx = 2 * H; at.lo_ctx = H; }
+        at.scale = 1.0f / sqrtf((float)(H / heads));
+        if (d) at.drop = *d;
+        at.q_tiles = q_tiles;
+        CHECK_HIP(launch_attn_fwd(at, dt, s));
+        return 0;
+    };
     for (int l = 0; l < L; ++l) {
         const bool ht = l < c.layers_txt, hv = l < c.layers_img;
         const LayerOff& ot = e.txt[ht ? l : 0];
@@ -694,70 +717,64 @@ int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s)
         // ---- QKV (image tower: pre-LN)
         if (hv) {
             LNArgs ln{xv, e.ws + e.v_ln, F + ov.ln1_w, F + ov.ln1_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+            ln_to(ln, e.v_ln, H);
             CHECK_HIP(launch_layernorm_fwd(ln, dt, s));
         }
         {
-            G gt(xt, H, e.ws + wt.qkv, H, e.ws + a.qkv, 3 * H, Mt, 3 * H, H); gt.bias(W + ot.qkv_b);
-            G gv(e.ws + e.v_ln, H, e.ws + wv.qkv, H, e.ws + e.v_qkv, 3 * H, Mv, 3 * H, H); gv.bias(F + ov.qkv_b);
+            G gt(xtg, H, e.ws + wt.qkv, H, e.ws + a.qkv, 3 * H, Mt, 3 * H, H); gt.bias(W + ot.qkv_b).px_in(px).px_out(px);
+            G gv(e.ws + e.v_ln, H, e.ws + wv.qkv, H, e.ws + e.v_qkv, 3 * H, Mv, 3 * H, H); gv.bias(F + ov.qkv_b).px_in(px).px_out(px);
             if (int r = both(gt, gv)) return r;
         }
         // ---- attention
         if (ht) {
-            AttnArgs at;
-            memset(&at, 0, sizeof(at));
-            at.qkv = e.ws + a.qkv; at.maskbias = e.wsp<float>(e.maskbias); at.ctx = e.ws + a.ctx; at.lse = e.wsp<float>(a.lse);
-            at.posts = Bt; at.S = T; at.heads = c.heads; at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
-            at.scale = 1.0f / sqrtf((float)(H / c.heads));
-            at.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
-            at.q_tiles = compact ? 1 : 0;
-            CHECK_HIP(launch_attn_fwd(at, dt, s));
+            const DropCfg d = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
+            if (int r = attn(e.ws + a.qkv, e.wsp<float>(e.maskbias), e.ws + a.ctx, e.wsp<float>(a.lse), Bt, T, c.heads, &d, compact ? 1 : 0)) return r;
         }
-        if (hv) {
-            AttnArgs at;
-            memset(&at, 0, sizeof(at));
-            at.qkv = e.ws + e.v_qkv; at.ctx = e.ws + e.v_ctx; at.posts = B; at.S = P; at.heads = e.heads_v(); at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
-            at.scale = 1.0f / sqrtf((float)(H / e.heads_v()));
-            CHECK_HIP(launch_attn_fwd(at, dt, s));
-        }
+        if (hv) if (int r = attn(e.ws + e.v_qkv, nullptr, e.ws + e.v_ctx, nullptr, B, P, e.heads_v(), nullptr, 0)) return r;
         // ---- attention output (+ residual)
         {
             G gt(e.ws + a.ctx, rs, e.ws + wt.ao, H, e.ws + a.pre1, H, Mr, H, H);
-            gt.bias(W + ot.ao_b).dropout(make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr), rmul).residual(xt, rs);
-            G gv(e.ws + e.v_ctx, H, e.ws + wv.ao, H, xv, H, Mv, H, H); gv.bias(F + ov.ao_b).residual(xv, H);
+            gt.bias(W + ot.ao_b).dropout(make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr), rmul).residual(xt, rs).px_in(px);
+            G gv(e.ws + e.v_ctx, H, e.ws + wv.ao, H, xv, H, Mv, H, H); gv.bias(F + ov.ao_b).residual(xv, H).px_in(px);
             if (int r = both(gt, gv)) return r;
         }
         if (ht) {
             LNArgs ln1{e.ws + a.pre1, e.ws + a.a1, W + ot.ln1_w, W + ot.ln1_b, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), Mr, H, H, H, c.ln_eps_txt};
+            if (px) { ln1.y_pair = e.ws + a.a1p; ln1.ld_pair = 2 * H; ln1.lo_pair = H; }
             CHECK_HIP(launch_layernorm_fwd(ln1, dt, s));
         }
         if (hv) {
             LNArgs ln2{xv, e.ws + e.v_ln, F + ov.ln2_w, F + ov.ln2_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+            ln_to(ln2, e.v_ln, H);
             CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
         }
         // ---- feed-forward
         {
-            G gt(e.ws + a.a1, H, e.ws + wt.fc1, H, e.ws + a.h, I, Mr, I, H); gt.bias(W + ot.fc1_b).aux(e.ws + a.u, I).gelu();
-            G gv(e.ws + e.v_ln, H, e.ws + wv.fc1, H, e.ws + e.v_h, I, Mv, I, H); gv.bias(F + ov.fc1_b).gelu();
+            G gt(e.ws + (px ? a.a1p : a.a1), H, e.ws + wt.fc1, H, e.ws + a.h, I, Mr, I, H); gt.bias(W + ot.fc1_b).aux(e.ws + a.u, I).gelu().px_in(px).px_out(px);
+            G gv(e.ws + e.v_ln, H, e.ws + wv.fc1, H, e.ws + e.v_h, I, Mv, I, H); gv.bias(F + ov.fc1_b).gelu().px_in(px).px_out(px);
             if (int r = both(gt, gv)) return r;
         }
         {
             G gt(e.ws + a.h, I, e.ws + wt.fc2, I, e.ws + a.pre2, H, Mr, H, I);
-            gt.bias(W + ot.fc2_b).dropout(make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr), rmul).residual(e.ws + a.a1, H);
-            G gv(e.ws + e.v_h, I, e.ws + wv.fc2, I, xv, H, Mv, H, I); gv.bias(F + ov.fc2_b).residual(xv, H);
+            gt.bias(W + ot.fc2_b).dropout(make_drop(c.p_hidden, e.seed, stream_ffn_out(l), tr), rmul).residual(e.ws + a.a1, H).px_in(px);
+            G gv(e.ws + e.v_h, I, e.ws + wv.fc2, I, xv, H, Mv, H, I); gv.bias(F + ov.fc2_b).residual(xv, H).px_in(px);
             if (int r = both(gt, gv)) return r;
         }
         if (ht) {
             LNArgs ln2{e.ws + a.pre2, e.ws + a.out, W + ot.ln2_w, W + ot.ln2_b, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), Mr, H, H, H, c.ln_eps_txt};
+            if (px) { ln2.y_pair = e.ws + a.outp; ln2.ld_pair = 2 * H; ln2.lo_pair = H; }
             CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
             e.cls_compact = compact;
             xt = e.ws + a.out;
+            xtg = px ? e.ws + a.outp : xt;
         }
     }
     LNArgs lnf{xv, e.ws + e.v_out, F + e.v_ln_w, F + e.v_ln_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
     CHECK_HIP(launch_layernorm_fwd(lnf, dt, s));
     SmallGemmArgs sp = small(e.ws + e.v_out, P * H, F + e.v_pool_w, H, F + e.v_pool_b, e.wsp<float>(e.h_vpool), H, B, H, H, ACT_TANH);
     CHECK_HIP(launch_small_nt(sp, dt, s));
-    return 0;
+    if (int r = e.span(1, s)) return r;
+    return e.span(2, s);
 }
 
 // The split of the chip's 256 CUs between the two towers of this forward: both towers' big GEMMs run 256 x 256 tiles of K / 64 K-steps
@@ -1168,10 +1185,10 @@ int mmhip_forward(mmhip_handle h, const int64_t* ids, const int64_t* mask, const
     e.fwd_done = false; e.bwd_begun = false;
     const size_t nb = (size_t)B * T * 8;
     // token ids are clamped into the word table on their way into the engine's copy (launch_copy_ids_clamped: why)
-    CHECK_HIP(launch_copy_ids_clamped(ids, e.wsp<int64_t>(e.ids_all), (size_t)B * T, e.cfg.vocab, nullptr, s));
+    CHECK_HIP(launch_copy_ids_clamped(ids, e.wsp<int64_t>(e.ids_all), (size_t)B * T, e.cfg.vocab, e.bad_index, s));
     CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all, mask, nb, hipMemcpyDeviceToDevice, s));
     if (e.itm) {
-        CHECK_HIP(launch_copy_ids_clamped(tim_ids, e.wsp<int64_t>(e.ids_all) + (size_t)B * T, (size_t)B * T, e.cfg.vocab, nullptr, s));
+        CHECK_HIP(launch_copy_ids_clamped(tim_ids, e.wsp<int64_t>(e.ids_all) + (size_t)B * T, (size_t)B * T, e.cfg.vocab, e.bad_index, s));
         CHECK_HIP(hipMemcpyAsync(e.ws + e.mask_all + nb, tim_mask, nb, hipMemcpyDeviceToDevice, s));
     }
     if (int r = side_init(e)) return r;
@@ -1371,6 +1388,16 @@ int mmhip_set_guard(mmhip_handle h, uint32_t* device_words2) {
     h->guard = device_words2;
     return 0;
 }
+void* mmhip_side_stream(mmhip_handle h) {
+    if (!h) return nullptr;
+    if (side_init(*h)) return nullptr;
+    return use_side(*h) ? (void*)h->side : nullptr;
+}
+int mmhip_set_index_counter(mmhip_handle h, uint32_t* device_word) {
+    if (!h || ((uintptr_t)device_word & 3)) return MMHIP_E_INVALID;
+    h->bad_index = device_word;
+    return 0;
+}
 int mmhip_set_backward_products(mmhip_handle h, int products) {
     if (!h || products < 1 || products > 3) return MMHIP_E_INVALID;
     if (h->cfg.dtype != MMHIP_BF16X3 || !h->px) return products == 3 ? 0 : MMHIP_E_STATE;      // the 16-bit modes have one product; round 3's copy form has three
@@ -1469,16 +1496,47 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
     }
     if (int r = mmhip_backward_begin(h, nullptr, nullptr, nullptr, nullptr, stream)) return r;
     const int L = e.cfg.layers_txt;
-    // data-parallel form (cb): the layer optimizers wait for the gradient exchange, so they run after it (below); the callback is told
-    // about stage st-1 once stage st is enqueued and st-1's weight gradients are ordered in the caller's stream -- its collective
-    // travels while the stages below compute
+    // data-parallel form (cb): the callback is told about stage st-1 once stage st is enqueued and st-1's weight gradients are ordered in the
+    // caller's stream -- its collective travels while the stages below compute.  The layer optimizers wait for the gradient exchange: PER BUCKET
+    // (round 5).  When the callback answers MMHIP_CB_BUCKET -- "the collective that carries every stage since the last such answer has been
+    // started" -- the side stream is made to wait for that collective (on_stage(MMHIP_CB_WAIT_BUCKET): the caller waits on mmhip_side_stream) and
+    // the AdamW + operand refresh of the text layers it carries follow on the side stream, beside the stages below, as in the single-rank step;
+    // before round 5 every layer's optimizer sat behind ONE barrier after the last all-reduce (MMHIP_CB_WAIT_DENSE), which made the N > 1 step
+    // longer than the N = 1 step before any wire time.  Ranges that are not text layers (heads, embeddings) and the last, unflushed bucket keep
+    // that barrier.
     const bool layer_opt = early && use_side(e) && !cb;
+    const bool bucket_opt = early && use_side(e) && cb;
     bool opt_pending = false, dense_by_caller = false;
+    std::vector<char> layer_done((size_t)(L > 0 ? L : 1), 0);
+    std::vector<int> open_layers;          // text layers whose gradient stage lies in the bucket that is still open
     for (int st = 0; st < L + 2; ++st) {
         if (int r = mmhip_backward_stage(h, st, stream)) return r;
         if (cb && st >= 1) {
             if (int r = mmhip_backward_join_stage(h, st - 1, stream)) return r;
-            if (int r = cb(user, st - 1)) return r;
+            const int r = cb(user, st - 1);
+            if (r != 0 && r != MMHIP_CB_BUCKET) return r;
+            if (st - 1 >= 1 && st - 1 <= L) open_layers.push_back(L - (st - 1));
+            if (r == MMHIP_CB_BUCKET) {
+                if (bucket_opt && !open_layers.empty()) {
+                    // the side stream waits for the layers' backward kernels on `s` (they read the fp32 LayerNorm weights and the transposed
+                    // operand copies that the optimizer and the refresh are about to overwrite) and, through the callback, for the collective
+                    CHECK_HIP(hipEventRecord(e.ev_layer[0], s));
+                    CHECK_HIP(hipStreamWaitEvent(e.side, e.ev_layer[0], 0));
+                    const int w = cb(user, MMHIP_CB_WAIT_BUCKET);
+                    if (w != 0 && w != MMHIP_CB_HANDLED) return w;
+                    for (int l : open_layers) {
+                        const LayerOff& o = e.txt[l];
+                        if (w == 0)
+                            if (int r2 = adamw_impl(e.train + o.begin, e.grad + o.begin, adam_m + o.begin, adam_v + o.begin, o.end - o.begin, lr, beta1, beta2, eps,
+                                                    weight_decay, step, grad_scale, 1, e.side, gc, gf)) return r2;
+                        if (int r2 = refresh_layer(e, e.train, o, e.txt_w16[l], true, e.side, e.cfg.hidden, e.cfg.inter)) return r2;
+                        layer_done[l] = w == 0 ? 1 : 2;          // 2: stepped by the caller (MMHIP_CB_HANDLED), refreshed here
+                    }
+                    CHECK_HIP(hipEventRecord(e.ev_opt, e.side));
+                    opt_pending = true;
+                }
+                open_layers.clear();
+            }
         }
         if (layer_opt && st >= 1 && st <= L) {
             const int l = L - st, set = l & 1;
@@ -1488,6 +1546,7 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
             if (int r = adamw_impl(e.train + o.begin, e.grad + o.begin, adam_m + o.begin, adam_v + o.begin, o.end - o.begin, lr, beta1, beta2, eps,
                                    weight_decay, step, grad_scale, 1, e.side, gc, gf)) return r;
             if (int r = refresh_layer(e, e.train, o, e.txt_w16[l], true, e.side, e.cfg.hidden, e.cfg.inter)) return r;
+            layer_done[l] = 1;
             CHECK_HIP(hipEventRecord(e.ev_opt, e.side));
             opt_pending = true;
         }
@@ -1518,9 +1577,8 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
         if (re > w0) rows_due = true;          // the word table goes last: under data parallelism its rows are still travelling
         return 0;
     };
-    auto in_layer = [&](uint64_t off) {
-        if (!opt_pending) return false;
-        for (int l = 0; l < L; ++l) if (off >= e.txt[l].begin && off < e.txt[l].end) return true;
+    auto in_layer = [&](uint64_t off) {          // a text layer whose optimizer has already run (beside the backward)
+        for (int l = 0; l < L; ++l) if (layer_done[l] && off >= e.txt[l].begin && off < e.txt[l].end) return true;
         return false;
     };
     for (const auto& p : e.params) {
@@ -1531,7 +1589,8 @@ static int train_step_impl(mmhip_handle h, const int64_t* ids, const int64_t* ma
         rb = b; re = en; open = true;
     }
     if (int r = flush()) return r;
-    if (!opt_pending) if (int r = mmhip_refresh_weights(h, 2, stream)) return r;      // 16-bit GEMM operand copies: no word-table dependence
+    for (int l = 0; l < L; ++l)          // 16-bit GEMM operand copies of the layers stepped just now: no word-table dependence
+        if (!layer_done[l]) if (int r = refresh_layer(e, e.train, e.txt[l], e.txt_w16[l], true, s, e.cfg.hidden, e.cfg.inter)) return r;
     if (rows_due) {
         if (cb) if (int r = cb(user, MMHIP_CB_FINISH_ROWS)) return r;                 // the exchanged word rows are summed into the gradient
         if (!e.word_row_state) return MMHIP_E_STATE;

@@ -26,6 +26,18 @@ __device__ __forceinline__ void raw_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+// Diagnostic builds only (tools/gemm8_diag.sh: WRONG results, timing experiments that say where a K-tile's cycles go): each macro removes one
+// ingredient of the K loop.  None is defined in the product build.
+#ifdef MMHIP_DIAG_NOBARRIER
+#define KLOOP_BARRIER() asm volatile("" ::: "memory")
+#else
+#define KLOOP_BARRIER() raw_barrier()
+#endif
+#ifdef MMHIP_DIAG_NOWAITVM
+#define KLOOP_WAIT_VM(N) asm volatile("" ::: "memory")
+#else
+#define KLOOP_WAIT_VM(N) wait_vm<N>()
+#endif
 
 template <int BN>
 struct P8 {
@@ -319,6 +331,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
     };
     auto issue = [&](auto pc_, const char* buf) {          // the phase's pieces into K-tile buffer `buf`
         constexpr int p = decltype(pc_)::value;
+#ifdef MMHIP_DIAG_NODMA
+        return;
+#endif
 #pragma unroll
         for (int jj = 0; jj < P::cnt(p); ++jj) {
             const char* src = (P::is_b(p, jj) ? gB[p] : gA[p]) + voff[p][jj];
@@ -388,6 +403,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
     v8 af[4][2], bf[2][2][2];          // A fragments [i][kk] (reloaded in place in a K-tile's last phase); B [set][h][kk], sets alternate by phase
     auto read_b = [&](auto set_, const char* Ks, int p) {
         constexpr int set = decltype(set_)::value;
+#ifdef MMHIP_DIAG_NOLDS
+        if (g.gw != 12345) return;          // (never true: the fragments keep what the prologue read; the compiler cannot drop the reads' code)
+#endif
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -483,12 +501,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNTPair g, int pers
                 // stored (no residual / gelu' loads), those `grace` stores sit inside the window of pieces that may stay in flight as long
                 // as the window still reaches back to pieces issued before the epilogue: the K loop does not wait for HBM writes
                 if (grace && P::wait(p) > P::issued_through(p)) {
-                    if (grace > NST1) wait_vm<P::wait(p) + 2 * NST1>(); else wait_vm<P::wait(p) + NST1>();
+                    if (grace > NST1) KLOOP_WAIT_VM(P::wait(p) + 2 * NST1); else KLOOP_WAIT_VM(P::wait(p) + NST1);
                 } else {
-                    wait_vm<P::wait(p)>();
+                    KLOOP_WAIT_VM(P::wait(p));
                 }
                 lgkm0();                           // this wave's fragment requests are back: the slots they read may be restaged after the barrier
-                raw_barrier();
+                KLOOP_BARRIER();
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
@@ -658,7 +676,10 @@ bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hip
 // two problems of equal N and K in one persistent launch; bn = 0 picks the tile that fills the rounds of 256 workgroups best.
 // false = rules not met (caller launches them one by one)
 bool launch_gemm_nt8_pair(const GemmNTArgs& a0, const GemmNTArgs& a1, int dtype, int bn, hipStream_t s) {
-    if (dtype != DT_BF16 && dtype != DT_F16) return false;
+    if (dtype == DT_F32) {          // parity mode: both problems on plane pairs with the same plane offsets (the K loop reads them from problem 0), all three products
+        if (!a0.a_pair || !a0.b_pair || !a1.a_pair || !a1.b_pair || a0.a_lo != a1.a_lo || a0.b_lo != a1.b_lo || a0.nprod != a1.nprod || a0.nprod == 1) return false;
+        if (a0.M <= 128 || a1.M <= 128) return false;      // the <= 128-row problems of the parity mode take the direct kernel (x3.hip)
+    } else if (dtype != DT_BF16 && dtype != DT_F16) return false;
     if (a0.N != a1.N || a0.K != a1.K) return false;
     if (bn == 0) {
         double best = 0;

@@ -73,6 +73,15 @@ def check_shared_device(max_queues=4):
     return sharing
 
 
+def sync_guard_counter(guard_words):
+    """Sharded optimizer (ShardedBuckets): only the OWNER of a shard runs AdamW over that shard's summed gradient, so the non-finite counter
+    (word [0] of include/mmhip.h mmhip_set_guard) of the dense ranges becomes rank-local -- one rank would raise FloatingPointError (bf16) or halve
+    its f16 loss scale while the others go on into the next step's collectives: a hang until the timeout, or loss scales drifting apart.  MAX-reduce
+    the counter at the end of the step; every rank then polls the same value and takes the same decision in the same step."""
+    if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+        td.all_reduce(guard_words[0:1], op=td.ReduceOp.MAX)
+
+
 SKIP_EXCHANGE = False      # bench.py only: time the step without its collectives (replicas diverge; never set while training)
 
 
@@ -236,10 +245,11 @@ class ShardedBuckets(StageBuckets):
             self.bytes += (e - b) * 4
         self.begin = self.end = None
 
-    def own_ranges(self):
-        """[(begin, end, replicated)] of the gradient elements this rank holds the SUM of after the waits: its shard of every bucket, and the tails"""
+    def own_ranges(self, entries=None):
+        """[(begin, end, replicated)] of the gradient elements this rank holds the SUM of after the waits: its shard of every bucket (of `entries`,
+        a slice of self.plan, when given), and the tails"""
         r, W, out = rank(), world_size(), []
-        for b, s, e, rs, ar in self.plan:
+        for b, s, e, rs, ar in (self.plan if entries is None else entries):
             if rs is not None:
                 rs.wait()
             if ar is not None:
@@ -250,9 +260,9 @@ class ShardedBuckets(StageBuckets):
                 out.append((b + W * s, e, True))
         return out
 
-    def gather_params(self, flat_param):
+    def gather_params(self, flat_param, entries=None):
         W = world_size()
-        works = [_all_gather_inplace(flat_param, b, s, W) for b, s, e, _, _ in self.plan if s > 0]
+        works = [_all_gather_inplace(flat_param, b, s, W) for b, s, e, _, _ in (self.plan if entries is None else entries) if s > 0]
         for w in works:
             w.wait()
 

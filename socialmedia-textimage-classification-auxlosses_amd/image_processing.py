@@ -131,14 +131,21 @@ class SharedImageRing:
     How many slots: the loader delivers in order but the workers take slots in whatever order they get to it, so the batch the consumer waits
     for can belong to the one worker without a slot while later batches hold them all -- nobody moves until that worker's timeout (it then
     packs a plain tensor; correct, but a stall).  With at least num_workers * prefetch_factor slots (every batch the loader can have
-    outstanding) plus those the consumer holds (DevicePrefetcher: group * (depth + 1)) that cannot happen; datasets.loaders_from_data_key
+    outstanding) plus those the consumer holds (DevicePrefetcher: depth + 1) that cannot happen; datasets.loaders_from_data_key
     sizes ring and prefetch_factor accordingly."""
+
+    MAX_OWNERS = 8
 
     def __init__(self, slots, slot_bytes, register=True, timeout=5.0):
         import multiprocessing
         self.timeout = float(timeout)             # how long a worker waits for a free slot before it packs a plain tensor instead
         self.slots, self.slot_bytes = int(slots), (int(slot_bytes) + 4095) // 4096 * 4096
         self.buf = torch.empty(self.slots * self.slot_bytes, dtype=torch.uint8).share_memory_()
+        # lease book in shared memory: meta[o] = epoch counter of owner o (a loader: train / val / test), meta[MAX_OWNERS + slot] = 0 while the slot
+        # is free, else (owner + 1) << 32 | the owner's epoch when a worker took it.  A batch that was prefetched for an epoch the consumer abandoned
+        # is dropped by the DataLoader (its _reset discards outstanding results) and the slot it names would be gone for good: begin_epoch /
+        # recover hand such slots back (ADVICE r4)
+        self.meta = torch.zeros(self.MAX_OWNERS + self.slots, dtype=torch.int64).share_memory_()
         self.free = multiprocessing.Queue()
         for i in range(self.slots):
             self.free.put(i)
@@ -148,12 +155,17 @@ class SharedImageRing:
         if register and torch.cuda.is_available():
             rc = torch.cuda.cudart().cudaHostRegister(self.buf.data_ptr(), self.buf.numel(), 0)
             self.pinned = int(rc) == 0
+            if not self.pinned:
+                import logging
+                logging.getLogger(__name__).warning("SharedImageRing: hipHostRegister of %.0f MB failed (rc %s): the ring stays pageable and every batch takes a "
+                                                    "pinned staging copy -- slower than the DataLoader queue it replaces; MMHIP_IMAGE_RING=0 turns the ring off",
+                                                    self.buf.numel() / 2 ** 20, rc)
 
     def view(self, slot, nbytes):
         o = slot * self.slot_bytes
         return self.buf[o: o + nbytes]
 
-    def take(self, nbytes, timeout=None):
+    def take(self, nbytes, timeout=None, owner=0):
         """(slot, uint8 view) or (None, None) when the batch does not fit a slot or no slot came free in time (the caller packs a plain tensor)"""
         if nbytes > self.slot_bytes:
             return None, None
@@ -161,10 +173,32 @@ class SharedImageRing:
             slot = self.free.get(timeout=self.timeout if timeout is None else timeout)
         except Exception:
             return None, None
+        self.meta[self.MAX_OWNERS + slot] = ((int(owner) % self.MAX_OWNERS + 1) << 32) | int(self.meta[int(owner) % self.MAX_OWNERS])
         return slot, self.view(slot, nbytes)
 
     def release(self, slot):
+        self.meta[self.MAX_OWNERS + int(slot)] = 0
         self.free.put(int(slot))
+
+    def begin_epoch(self, owner=0):
+        """consumer, BEFORE it asks the loader for a new iterator: slots taken from now on carry the new epoch number"""
+        self.meta[int(owner) % self.MAX_OWNERS] += 1
+
+    def recover(self, owner=0, held=()):
+        """consumer, AFTER the loader has handed out the new iterator (its _reset has then dropped every result of earlier epochs): a slot this
+        owner's workers took in an earlier epoch that is neither free nor held by the consumer can never arrive any more -- back to the free queue.
+        Returns how many.  (One live iterator per loader, as DataLoader's persistent workers require anyway.)"""
+        o = int(owner) % self.MAX_OWNERS
+        now, n = int(self.meta[o]), 0
+        for slot in range(self.slots):
+            v = int(self.meta[self.MAX_OWNERS + slot])
+            if v and (v >> 32) == o + 1 and (v & 0xFFFFFFFF) < now and slot not in held:
+                self.release(slot)
+                n += 1
+        if n:
+            import logging
+            logging.getLogger(__name__).warning("SharedImageRing: %d slot(s) of an abandoned epoch handed back to the workers", n)
+        return n
 
     def close(self):
         import os
@@ -185,8 +219,8 @@ class RingCollate:
     """RawImageCollate writing the packed images into a SharedImageRing slot: the batch that crosses the DataLoader queue carries the slot
     number, the byte count and the (small) resampling plan instead of the image bytes"""
 
-    def __init__(self, processor, ring):
-        self.proc, self.ring = processor, ring
+    def __init__(self, processor, ring, owner=0):
+        self.proc, self.ring, self.owner = processor, ring, int(owner)      # owner: which loader's batches these are (SharedImageRing lease book)
         self._starved = False         # (per worker process) the last attempt timed out: slots were leaked by an abandoned epoch or the consumer
                                       # stalls -- do not wait again, look once and fall back, until a slot is there again
 
@@ -195,7 +229,7 @@ class RingCollate:
         got = {}
 
         def alloc(nbytes):
-            slot, view = self.ring.take(nbytes, timeout=0.0 if self._starved else None)
+            slot, view = self.ring.take(nbytes, timeout=0.0 if self._starved else None, owner=self.owner)
             self._starved = slot is None and nbytes <= self.ring.slot_bytes
             got["slot"], got["bytes"] = slot, nbytes
             return view
@@ -217,19 +251,14 @@ class DevicePrefetcher:
     _streams = {}        # one copy stream per device for every prefetcher: the caching allocator pools blocks per stream, and a
                          # fresh stream per epoch strands the previous one's cached blocks (reserved memory grew 0.1-0.3 GiB per instance)
 
-    def __init__(self, loader, device, processor=None, depth=2, trim_padding=True, ring=None, group=None):
+    def __init__(self, loader, device, processor=None, depth=2, trim_padding=True, ring=None):
         self.loader, self.device, self.proc, self.depth = loader, torch.device(device), processor, max(1, depth)
         self.ring, self._held = ring, []          # ring slots whose host-to-device copy is still in flight: (slot, event)
         self.ring_batches = self.queue_batches = 0   # how the image bytes arrived: through a ring slot / as a packed tensor in the DataLoader queue
-        # group > 1: the loader delivers SUB-batches (batch_size / group posts each) and `group` consecutive ones make one training batch --
-        # the same posts in the same order as one batch of the full size (a BatchSampler cuts the sampler's order into consecutive chunks),
-        # but the workers decode one batch side by side instead of one worker decoding all of it: the first batch of an epoch is there after
-        # 1 / group of the time (datasets.loaders_from_data_key sets `loader.mmhip_group`)
-        self.group = max(1, int(group if group is not None else getattr(loader, "mmhip_group", 1)))
-        if ring is not None and ring.slots < self.group * (self.depth + 1):
-            # `depth` staged batches plus the one being assembled hold group slots each; with fewer the workers wait for slots that only
-            # come back after a batch has been handed over -- a stall until their timeout
-            raise ValueError(f"SharedImageRing of {ring.slots} slots is too small for {self.depth} staged batches of {self.group} sub-batches")
+        if ring is not None and ring.slots < self.depth + 1:
+            # `depth` staged batches plus the one being assembled hold a slot each; with fewer the workers wait for slots that only come back
+            # after a batch has been handed over -- a stall until their timeout
+            raise ValueError(f"SharedImageRing of {ring.slots} slots is too small for {self.depth} staged batches")
         key = (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
         if key not in DevicePrefetcher._streams:
             DevicePrefetcher._streams[key] = torch.cuda.Stream(device=self.device)
@@ -255,44 +284,30 @@ class DevicePrefetcher:
         return batch
 
     def __len__(self):
-        return (len(self.loader) + self.group - 1) // self.group
+        return len(self.loader)
 
     _IMAGE_KEYS = ("image_packed", "image_plan", "image_count", "image_slot", "image_bytes")
 
-    def _stage(self, parts):
-        """`parts`: the sub-batches of one training batch (a single one unless the loader is grouped)"""
-        if isinstance(parts, dict):
-            parts = [parts]
-        # everything but the images: one host-side concatenation of small tensors, then trimmed and copied as ONE batch
-        batch = {}
-        for k in parts[0]:
-            if k in self._IMAGE_KEYS:
-                continue
-            vs = [p[k] for p in parts]
-            batch[k] = vs[0] if len(vs) == 1 else (torch.cat(vs, 0) if torch.is_tensor(vs[0]) else [x for v in vs for x in (v if isinstance(v, (list, tuple)) else [v])])
+    def _stage(self, batch):
+        p = batch
+        batch = {k: v for k, v in p.items() if k not in self._IMAGE_KEYS}      # everything but the images: trimmed and copied as small tensors
         out = {}
         if self.trim_padding:
             batch = self.trim(batch)
         slots = []
         with torch.cuda.stream(self.stream):
-            pix = []
-            for p in parts:
-                if "image_slot" in p:
-                    if self.proc is None or self.ring is None:
-                        raise ValueError("ring batches need a GpuImageProcessor and the SharedImageRing they were written to")
-                    slot = int(p["image_slot"])
-                    slots.append(slot)
-                    self.ring_batches += 1
-                    pix.append(self.proc.run(self.ring.view(slot, int(p["image_bytes"])), p["image_plan"], int(p["image_count"])))
-                elif "image_packed" in p:
-                    if self.proc is None:
-                        raise ValueError("raw-image batches need a GpuImageProcessor")
-                    self.queue_batches += 1
-                    pix.append(self.proc.run(p["image_packed"], p["image_plan"], int(p["image_count"])))
-            if pix:
-                out["pixel_values"] = pix[0] if len(pix) == 1 else torch.cat(pix, 0)
-                if len(pix) > 1:
-                    out["pixel_values"]._mmhip_keep = pix          # (the parts keep their pinned staging buffers alive)
+            if "image_slot" in p:
+                if self.proc is None or self.ring is None:
+                    raise ValueError("ring batches need a GpuImageProcessor and the SharedImageRing they were written to")
+                slot = int(p["image_slot"])
+                slots.append(slot)
+                self.ring_batches += 1
+                out["pixel_values"] = self.proc.run(self.ring.view(slot, int(p["image_bytes"])), p["image_plan"], int(p["image_count"]))
+            elif "image_packed" in p:
+                if self.proc is None:
+                    raise ValueError("raw-image batches need a GpuImageProcessor")
+                self.queue_batches += 1
+                out["pixel_values"] = self.proc.run(p["image_packed"], p["image_plan"], int(p["image_count"]))
             for k, v in batch.items():
                 if torch.is_tensor(v) and k != "data_id":
                     h = v if v.is_pinned() else v.pin_memory()
@@ -314,20 +329,23 @@ class DevicePrefetcher:
             self.ring.release(slot)
         self._held = []
 
+    def _ring_owner(self):
+        c = getattr(self.loader, "collate_fn", None)
+        c = getattr(c, "inner", c)                 # BatchTokenizeCollate wraps the image collate
+        return getattr(c, "owner", 0)
+
     def __iter__(self):
+        if self.ring is not None:
+            self.ring.begin_epoch(self._ring_owner())
         it = iter(self.loader)
+        if self.ring is not None:                  # slots named by batches of an abandoned epoch (dropped by the loader's reset) come back
+            self.ring.recover(self._ring_owner(), {slot for slot, _ in self._held})
         queue = []
 
         def fetch():
             if self.ring is not None:
                 self._reclaim()
-            parts = [next(it)]                    # StopIteration here ends the epoch; a short last group is a short last batch
-            try:
-                while len(parts) < self.group:
-                    parts.append(next(it))
-            except StopIteration:
-                pass
-            queue.append(self._stage(parts))
+            queue.append(self._stage(next(it)))       # StopIteration here ends the epoch
         try:
             try:
                 while len(queue) < self.depth:

@@ -129,6 +129,11 @@ class Lxmert(nn.Module):
                 self._infos.append(inf)
                 self._offs[inf["name"]], self._shapes[inf["name"]] = inf["offset"], inf["shape"]
             self._attach_grads()
+        if first:
+            # include/mmhip.h mmhip_early_set_index_counter: token ids / token types that had to be clamped into their tables (the reference's
+            # nn.Embedding raises IndexError for them; MMEarly_Model.check_indices does, at the end of an epoch / an evaluation loop)
+            self._bad_index = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.mmhip_early_set_index_counter(h, _lib.ptr(self._bad_index)), "early_set_index_counter")
         self._ws = None
         torch.cuda.empty_cache()
         self._ws = torch.empty(int(lib.mmhip_early_workspace_bytes(h)), dtype=torch.uint8, device=dev)
@@ -423,6 +428,7 @@ class MMEarly_Model(object):
                                        b["features"], b["normalized_boxes"], b["labels"], class_weight, lr, weight_decay, step)
                 if log_every and it % log_every == 0 and mmdist.rank() == 0:
                     print(f"loss {float(loss):.4f}")
+            self.check_indices()
             for loader, store, fname in ((val_dataloader, res_val, val_filename), (te_dataloader, res_te, te_filename)):
                 if loader is None:
                     continue
@@ -455,5 +461,15 @@ class MMEarly_Model(object):
                 preds.append(out.argmax(1).cpu()); labels.append(b["labels"].argmax(1).cpu())
                 if "data_id" in b:
                     ids_all.append(b["data_id"])
+        self.check_indices()
         return {"data_id": torch.cat(ids_all).numpy() if ids_all else np.zeros(0, dtype=np.int64), "loss": float(np.mean(losses)),
                 "predictions": torch.cat(preds).numpy(), "labels": torch.cat(labels).numpy()}
+
+    def check_indices(self):
+        """the engine clamps token ids / token types into their tables and counts them (include/mmhip.h mmhip_early_set_index_counter): the
+        reference raises IndexError for such an index, so does this -- at the end of an epoch or an evaluation loop (synchronises)"""
+        n, seen = int(self.model._bad_index.item()), getattr(self, "_bad_seen", 0)
+        if n > seen:
+            self._bad_seen = n
+            raise IndexError(f"index out of range in self: {n - seen} token id(s) / token type(s) outside their embedding tables reached the encoder; "
+                             "the engine clamped them to a valid row instead of following them")

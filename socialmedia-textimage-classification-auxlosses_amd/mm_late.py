@@ -210,9 +210,14 @@ class MM_Model(nn.Module):
             self._word_row_state = torch.zeros((self._word_info["shape"][0] + 3) // 4 * 4, dtype=torch.uint8, device=dev)
         _lib.check(lib.mmhip_set_row_state(h, _lib.ptr(self._word_row_state)), "set_row_state")
         if first:
-            self._nonfinite = torch.zeros(2, dtype=torch.int32, device=dev)      # include/mmhip.h mmhip_set_guard: this handle's {counter, void-step flag}
+            # device words of this handle: [0:2] include/mmhip.h mmhip_set_guard {non-finite counter, void-step flag}; [2] mmhip_set_index_counter
+            # (token ids that had to be clamped into the word table: the reference raises IndexError for them)
+            self._guard4 = torch.zeros(4, dtype=torch.int32, device=dev)
+            self._nonfinite = self._guard4[:2]
+            self._bad_index = self._guard4[2:3]
             self._loss_scale = 0.0
         _lib.check(lib.mmhip_set_guard(h, _lib.ptr(self._nonfinite)), "set_guard")
+        _lib.check(lib.mmhip_set_index_counter(h, _lib.ptr(self._bad_index)), "set_index_counter")
         if self._loss_scale > 0:
             _lib.check(lib.mmhip_set_loss_scale(h, self._loss_scale), "set_loss_scale")
         if self.backward_products is not None:
@@ -632,17 +637,40 @@ class MMLate_Model(object):
             buckets = mmdist.ShardedBuckets(m._flat_grad) if sharded else mmdist.StageBuckets(m._flat_grad)
             n_stage = len(m._stage_ranges)
 
+            # per-bucket optimizer (include/mmhip.h MMHIP_CB_BUCKET): a bucket that has just left as a collective is answered with CB_BUCKET; the
+            # engine comes back with CB_WAIT_BUCKET, where ITS side stream is made to wait for that collective (RCCL: a stream-side wait) -- and, with
+            # the sharded optimizer, where the rank's shard of the bucket is updated and gathered on that stream -- so the bucket's layers are
+            # stepped and refreshed beside the backward stages below instead of behind one barrier after the last collective
+            per_bucket = os.environ.get("MMHIP_DP_BUCKET_OPT", "1") != "0"
+            seen = [0, 0]          # buckets.works / buckets.plan entries already answered | already waited for on the side stream
+
+            def started():
+                return len(buckets.plan) if sharded else len(buckets.works)
+
             def on_stage(_user, st):
                 try:
                     if st >= 0:
                         works.extend(mmdist.exchange_stage(m, st, n_stage, self.use_clip_loss, self.use_tim_loss, finishers if st == n_stage - 1 else None,
                                                            buckets=buckets))
+                        if per_bucket and st < n_stage - 1 and started() > seen[0]:
+                            seen[0] = started()
+                            return _lib.CB_BUCKET
+                    elif st == _lib.CB_WAIT_BUCKET:
+                        with torch.cuda.stream(self._engine_side_stream()):
+                            if sharded:
+                                entries = buckets.plan[seen[1]: seen[0]]
+                                seen[1] = seen[0]
+                                self._sharded_dense_update(buckets, lr, weight_decay, step, entries)
+                                return _lib.CB_HANDLED
+                            for w in buckets.works[seen[1]: seen[0]]:
+                                w.wait()
+                            seen[1] = seen[0]
                     elif st == _lib.CB_WAIT_DENSE:
                         for w in works + buckets.works:
                             w.wait()
                         self._share_guard_flag(True)
                         if sharded:
-                            self._sharded_dense_update(buckets, lr, weight_decay, step)
+                            self._sharded_dense_update(buckets, lr, weight_decay, step, buckets.plan[seen[1]:])
                             return _lib.CB_HANDLED
                     elif st == _lib.CB_FINISH_ROWS:
                         for f in finishers:
@@ -676,12 +704,23 @@ class MMLate_Model(object):
         w0 = m._word_info["offset"]
         return tuple(C.c_void_p(t.data_ptr() - w0 * 4) for t in self._opt_rows)
 
-    def _sharded_dense_update(self, buckets, lr, weight_decay, step):
+    def _engine_side_stream(self):
+        """the engine's side stream of the backward as a torch stream (include/mmhip.h mmhip_side_stream)"""
+        if getattr(self, "_side_ext", None) is None:
+            ptr = _lib.lib().mmhip_side_stream(self.model._handle)
+            if not ptr:
+                raise _lib.MMHipError("the engine has no side stream (MMHIP_OVERLAP=0) yet asked for a per-bucket wait")
+            self._side_ext = torch.cuda.ExternalStream(int(ptr), device=self.device)
+        return self._side_ext
+
+    def _sharded_dense_update(self, buckets, lr, weight_decay, step, entries=None):
+        """`entries`: the slice of buckets.plan to update (per-bucket form); None = the whole plan.  Runs on torch's current stream."""
         m, lib = self.model, _lib.lib()
         at = lambda t, el: C.c_void_p(t.data_ptr() + el * 4)
         w0 = m._word_info["offset"]
         active = [(b, min(e, w0)) for b, e in m.active_ranges(self.use_clip_loss, self.use_tim_loss) if b < w0]
-        for ob, oe, _replicated in buckets.own_ranges():
+        plan = buckets.plan if entries is None else entries
+        for ob, oe, _replicated in buckets.own_ranges(plan):
             mo, vo = self._opt_shards.get(ob, oe)
             for ab, ae in active:                       # AdamW touches only parameters that received a gradient (torch skips `grad is None`)
                 b, e = max(ob, ab), min(oe, ae)
@@ -689,9 +728,9 @@ class MMLate_Model(object):
                     _lib.check(lib.mmhip_adamw_guarded(at(m._flat_train, b), at(m._flat_grad, b), at(mo, b - ob), at(vo, b - ob), e - b, lr, 0.9, 0.999, 1e-8,
                                                        weight_decay, step, 1.0 / self.world, 1, _lib.stream_ptr(), _lib.ptr(m._nonfinite)), "adamw shard")
         # the shards of the other ranks hold this rank's unsummed gradient: clear the buckets whole (the entry condition of the next backward)
-        for b, s_, e, _, _ in buckets.plan:
+        for b, s_, e, _, _ in plan:
             m._flat_grad[b:e].zero_()
-        buckets.gather_params(m._flat_train)
+        buckets.gather_params(m._flat_train, plan)
 
     def _adamw(self, lr, weight_decay, step, dense=True, rows=True):
         m, lib = self.model, _lib.lib()
@@ -725,10 +764,12 @@ class MMLate_Model(object):
 
     def _post_guard(self):
         if getattr(self, "_nf_host", None) is None:
-            self._nf_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._nf_host = torch.zeros(4, dtype=torch.int32).pin_memory()
             self._nf_event = torch.cuda.Event()
             self._nf_seen, self._nf_clean, self._nf_pending = 0, 0, False
-        self._nf_host.copy_(self.model._nonfinite, non_blocking=True)
+        if self.world > 1 and self.sharded_optimizer and not mmdist.SKIP_EXCHANGE:
+            mmdist.sync_guard_counter(self.model._nonfinite)          # owner-only AdamW launches: the counter must not stay rank-local
+        self._nf_host.copy_(self.model._guard4, non_blocking=True)
         self._nf_event.record()
         self._nf_pending = True
 
@@ -736,6 +777,7 @@ class MMLate_Model(object):
         if not getattr(self, "_nf_pending", False) or not self._nf_event.query():
             return
         self._nf_pending = False
+        self._raise_on_clamped_indices(int(self._nf_host[2]))
         n = int(self._nf_host[0]) - self._nf_seen
         m = self.model
         if n <= 0:
@@ -757,6 +799,19 @@ class MMLate_Model(object):
         m._loss_scale = max(cur / 2.0, 1.0)
         _lib.check(_lib.lib().mmhip_set_loss_scale(m._handle, m._loss_scale), "set_loss_scale")
         logger.warning("f16 gradient overflow (%d sightings; the steps were skipped on the device): loss scale %g -> %g", n, cur, m._loss_scale)
+
+    def _raise_on_clamped_indices(self, count):
+        """token ids outside [0, vocab) were clamped by the engine (include/mmhip.h mmhip_set_index_counter): the reference's nn.Embedding raises
+        IndexError for them -- so does this, one step late (the count comes from the pinned copy of the guard words) or at the end of a loop"""
+        seen = getattr(self, "_bad_seen", 0)
+        if count > seen:
+            self._bad_seen = count
+            raise IndexError(f"index out of range in self: {count - seen} token id(s) outside [0, {self.model.arch['vocab']}) reached the text tower "
+                             "(a tokenizer that does not match the checkpoint?); the engine clamped them to a valid row instead of following them")
+
+    def check_indices(self):
+        """synchronising form of the check above (end of an evaluation / feature loop)"""
+        self._raise_on_clamped_indices(int(self.model._bad_index.item()))
 
     def check_overflow(self):
         """non-finite gradient elements since the last call (the AdamW kernels skipped and counted them, include/mmhip.h).
@@ -863,4 +918,5 @@ class MMLate_Model(object):
         if shard is not None:
             res["batch_losses"] = batch_losses
             res = mmdist.gather_eval(res)
+        self.check_indices()                   # (the .cpu() copies above synchronised already)
         return res

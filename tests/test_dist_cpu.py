@@ -189,6 +189,10 @@ def _guard_worker(rank, world, port, q):
     mmdist._physical_device = lambda: ("host", 0, 5 + rank, 0)       # a card per rank: 8 queues are the user's business
     out.append(mmdist.check_shared_device())
     mmdist._physical_device = real
+    # sharded optimizer: the non-finite counter of a shard's owner reaches every rank (dist.sync_guard_counter) -- here rank 1 "poisons" its shard
+    words = torch.tensor([5 * rank, 0], dtype=torch.int32)
+    mmdist.sync_guard_counter(words)
+    out.append(words.tolist())
     q.put((rank, out))
     td.destroy_process_group()
 
@@ -205,4 +209,4 @@ def test_shared_device_with_many_hardware_queues_is_refused():
         p.join(timeout=60)
         assert p.exitcode == 0
     for _, out in res:
-        assert out == [2, "refused", 2, 1, 1], out
+        assert out == [2, "refused", 2, 1, 1, [5, 0]], out

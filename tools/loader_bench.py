@@ -54,7 +54,6 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--image_px", default="480x360")
     ap.add_argument("--item_tokenize", action="store_true")
-    ap.add_argument("--split", type=int, default=1, help="sub-batches per batch (MMHIP_LOADER_SPLIT): the workers decode one batch side by side and the prefetcher reassembles it; 1 = whole batches per worker (the default)")
     ap.add_argument("--no_ring", action="store_true", help="A/B: decoded images through the DataLoader's result queue (round 3) instead of the pinned shared-memory ring")
     ap.add_argument("--resident_last", action="store_true", help="A/B: only MMLate_Model.warm_start() runs before the workers fork; the resident step is not timed")
     args = ap.parse_args()
@@ -100,20 +99,18 @@ def main():
             trainer.train_step(s_ids, s_mask, s_px, s_oh, None, lr, wd, step)
         torch.cuda.synchronize()
         res_ps = K * args.batch / (time.time() - t)
-    split = max([d for d in (8, 4, 2, 1) if d <= max(1, min(args.split, args.workers or 1)) and args.batch % d == 0])
     ds = MM_Dataset(df.tweet_id.values, df.text.values, labels, tok, 128, fmt, 224, raw_images=True, batch_tokenize=not args.item_tokenize)
     inner = RawImageCollate(proc)
     ring = None
     if args.workers and not args.no_ring:
         from smtc_amd.image_processing import RingCollate, SharedImageRing
-        ring = SharedImageRing((args.workers * 4 + 6) * split, int(1.1 * args.batch // split * (w * h * 3 + 16)))
+        ring = SharedImageRing(args.workers * 4 + 6, int(1.1 * args.batch * (w * h * 3 + 16)))
         inner = RingCollate(proc, ring)
     collate = inner if args.item_tokenize else BatchTokenizeCollate(tok, 128, inner)
     kw = dict(num_workers=args.workers, collate_fn=collate, drop_last=True)
     if args.workers:
-        kw.update(persistent_workers=True, prefetch_factor=4 * split, worker_init_fn=worker_init)
-    loader = torch.utils.data.DataLoader(ds, batch_size=args.batch // split, shuffle=True, **kw)
-    loader.mmhip_group = split
+        kw.update(persistent_workers=True, prefetch_factor=4, worker_init_fn=worker_init)
+    loader = torch.utils.data.DataLoader(ds, batch_size=args.batch, shuffle=True, **kw)
 
     def epoch_loader_only():
         n = 0
@@ -170,7 +167,7 @@ def main():
 
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     print(json.dumps({"posts": args.posts, "image_px": args.image_px, "workers": args.workers, "host_cores": cores, "batch": args.batch, "layers": args.layers,
-                      "tokenise": "per item" if args.item_tokenize else "per batch (collate)", "image_handoff": "pinned shared-memory ring" if ring is not None else "DataLoader queue", "sub_batches_per_batch": split,
+                      "tokenise": "per item" if args.item_tokenize else "per batch (collate)", "image_handoff": "pinned shared-memory ring" if ring is not None else "DataLoader queue",
                       "ring_pinned": bool(ring is not None and ring.pinned),
                       "loader_only_posts_per_s": round(loader_ps, 1), "loader_to_train_step_posts_per_s": round(e2e_ps, 1),
                       "epoch_fill_ms": round(1e3 * sum(fills) / len(fills), 1), "after_fill_posts_per_s": round(steady_ps, 1),
