@@ -656,8 +656,14 @@ __global__ __launch_bounds__(512) void attn_fwd_x3_long_kernel(AttnArgs a) {
     }
 }
 
-template <int NKT, bool PAIR>
+// NP1 (plane pairs only; AttnBwdArgs::nprod = 1, the engine's one-product backward): the scores S = Q.K^T keep their three products -- the
+// probabilities are RE-computed against the forward's log-sum-exp, and scores off by one bf16 rounding (2e-3) would leave every row of P summing to
+// something else than 1 (measured: the all-one-product kernel took the worst gradient tensor of a 12-layer model from 6e-3 to 1.4e-2) -- while
+// dP = dO.V^T, dV = P^T.dO, dK = dS^T.Q and dQ = dS.K take ONE product of the hi planes, like the backward's GEMMs; d ctx is read from its hi plane only
+// (its producer does not write the other under that policy).
+template <int NKT, bool PAIR, bool NP1 = false>
 __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
+    static_assert(PAIR || !NP1, "the one-product form reads plane pairs");
     typedef X3IO<PAIR> IO;
     typedef typename IO::elem E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -683,7 +689,8 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
     const E* dob = (const E*)a.dctx + row0 * a.ld_ctx + head * HD;
     const E* ob = (const E*)a.ctx + row0 * a.ld_ctx + head * HD;
     IO::stage(Qh, Ql, qb, a.ld_qkv, a.lo_qkv, S, SP, true, tid, 256);
-    IO::stage(dOh, dOl, dob, a.ld_ctx, a.lo_ctx, S, SP, true, tid, 256);
+    if constexpr (NP1) stage_image<bf16_t>(dOh, (const bf16_t*)dob, a.ld_ctx, S, SP, true, tid, 256);
+    else IO::stage(dOh, dOl, dob, a.ld_ctx, a.lo_ctx, S, SP, true, tid, 256);
     IO::stage(Kh, Kl, kb, a.ld_qkv, a.lo_qkv, S, SP, true, tid, 256);
     for (int q = tid; q < SP; q += 256) {
         float d = 0.f, l = 0.f;
@@ -692,7 +699,10 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
             const E* g = dob + (size_t)q * a.ld_ctx;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const f32x4 ov = IO::load4(o + c * 4, a.lo_ctx), gv = IO::load4(g + c * 4, a.lo_ctx);
+                const f32x4 ov = IO::load4(o + c * 4, a.lo_ctx);
+                f32x4 gv;
+                if constexpr (NP1) { const bf16x4 h = *reinterpret_cast<const bf16x4*>((const bf16_t*)g + c * 4); gv = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}; }
+                else gv = IO::load4(g + c * 4, a.lo_ctx);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d += ov[e] * gv[e];
             }
@@ -734,7 +744,8 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
                 for (int s = 0; s < 4; ++s) {
                     const int off = trimg_off(q0 + r, 2 * s + h2);
                     sacc = mma3_32(lds_pair(Qh, Ql, off), kf[s], sacc);       // S[q][key]
-                    pacc = mma3_32(lds_pair(dOh, dOl, off), vf[s], pacc);     // dP[q][key]
+                    if constexpr (NP1) pacc = mfma32(lds_read8<bf16_t>(dOh, off), vf[s].hi, pacc);
+                    else pacc = mma3_32(lds_pair(dOh, dOl, off), vf[s], pacc);     // dP[q][key]
                 }
                 float pdv[16], dsv[16];
 #pragma unroll
@@ -761,7 +772,7 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
                         const int doff = ds_off(drow, key >> 3, SPC) + (key & 7) * 2;
                         const bf16_t dh = (bf16_t)ds;
                         *reinterpret_cast<bf16_t*>(dSh + doff) = dh;
-                        *reinterpret_cast<bf16_t*>(dSl + doff) = (bf16_t)(ds - (float)dh);
+                        if constexpr (!NP1) *reinterpret_cast<bf16_t*>(dSl + doff) = (bf16_t)(ds - (float)dh);
                     }
                 }
 #pragma unroll
@@ -771,11 +782,16 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
                     for (int dt = 0; dt < 2; ++dt) {
                         Frag3 gt, qtf;
                         gt.hi = tr_frag_acc_order<bf16_t>(dOh, q0 + 16 * s2, dt * 32, lane);      // dO^T[d][q]
-                        gt.lo = tr_frag_acc_order<bf16_t>(dOl, q0 + 16 * s2, dt * 32, lane);
-                        dv[dt] = mma3_32(gt, pfrag, dv[dt]);
                         qtf.hi = tr_frag_acc_order<bf16_t>(Qh, q0 + 16 * s2, dt * 32, lane);      // Q^T[d][q]
-                        qtf.lo = tr_frag_acc_order<bf16_t>(Ql, q0 + 16 * s2, dt * 32, lane);
-                        dk[dt] = mma3_32(qtf, dsfrag, dk[dt]);
+                        if constexpr (NP1) {
+                            dv[dt] = mfma32(gt.hi, pfrag.hi, dv[dt]);
+                            dk[dt] = mfma32(qtf.hi, dsfrag.hi, dk[dt]);
+                        } else {
+                            gt.lo = tr_frag_acc_order<bf16_t>(dOl, q0 + 16 * s2, dt * 32, lane);
+                            dv[dt] = mma3_32(gt, pfrag, dv[dt]);
+                            qtf.lo = tr_frag_acc_order<bf16_t>(Ql, q0 + 16 * s2, dt * 32, lane);
+                            dk[dt] = mma3_32(qtf, dsfrag, dk[dt]);
+                        }
                     }
                 }
             }
@@ -790,8 +806,12 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
                 for (int ks = 0; ks < SP / 16; ++ks) {
                     Frag3 ktf;
                     ktf.hi = tr_frag_natural<bf16_t>(Kh, ks * 16, dt * 32, lane);
-                    ktf.lo = tr_frag_natural<bf16_t>(Kl, ks * 16, dt * 32, lane);
-                    dq = mma3_32(lds_pair(dSh, dSl, ds_off(qi * 32 + r, 2 * ks + h2, SPC)), ktf, dq);
+                    if constexpr (NP1) {
+                        dq = mfma32(lds_read8<bf16_t>(dSh, ds_off(qi * 32 + r, 2 * ks + h2, SPC)), ktf.hi, dq);
+                    } else {
+                        ktf.lo = tr_frag_natural<bf16_t>(Kl, ks * 16, dt * 32, lane);
+                        dq = mma3_32(lds_pair(dSh, dSl, ds_off(qi * 32 + r, 2 * ks + h2, SPC)), ktf, dq);
+                    }
                 }
                 E* dqp = (E*)a.dqkv + row0 * a.ld_qkv + head * HD + dt * 32 + r;
 #pragma unroll
@@ -912,16 +932,17 @@ static hipError_t launch_bwd_d(const AttnBwdArgs& a, hipStream_t s) {
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-template <int NKT, bool PAIR>
+template <int NKT, bool PAIR, bool NP1 = false>
 static void launch_bwd_x3_tp(const AttnBwdArgs& a, hipStream_t s) {
     const int lds = 6 * NKT * 32 * 128 + 2 * 64 * NKT * 32 * 2 + 2 * NKT * 32 * 4;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)attn_bwd_x3_kernel<NKT, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
-    hipLaunchKernelGGL((attn_bwd_x3_kernel<NKT, PAIR>), dim3(a.heads, a.posts), dim3(256), lds, s, a);
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn_bwd_x3_kernel<NKT, PAIR, NP1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+    hipLaunchKernelGGL((attn_bwd_x3_kernel<NKT, PAIR, NP1>), dim3(a.heads, a.posts), dim3(256), lds, s, a);
 }
 template <int NKT>
 static void launch_bwd_x3_t(const AttnBwdArgs& a, hipStream_t s) {
-    if (a.pair) launch_bwd_x3_tp<NKT, true>(a, s);
+    if (a.pair && a.nprod == 1) launch_bwd_x3_tp<NKT, true, true>(a, s);
+    else if (a.pair) launch_bwd_x3_tp<NKT, true>(a, s);
     else launch_bwd_x3_tp<NKT, false>(a, s);
 }
 hipError_t launch_attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t s) {

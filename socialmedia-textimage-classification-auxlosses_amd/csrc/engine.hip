@@ -418,7 +418,7 @@ struct G {
     // parity mode with plane pairs: both operands are pairs whose rows hold [hi(W) | lo(W)] -- the leading dimensions given in logical
     // elements double, the lo planes sit K elements behind; px_out: C as a pair, rows [hi(N) | lo(N)]
     G& px_in(bool px, int nprod = 0) { if (px) { a.a_pair = a.b_pair = 1; a.lda *= 2; a.ldb *= 2; a.a_lo = a.b_lo = a.K; a.nprod = nprod; } return *this; }
-    G& px_out(bool px) { if (px) { a.flags |= GEMM_OUT_PAIR; a.ldc *= 2; a.c_lo = a.N; } return *this; }
+    G& px_out(bool px, bool hi_only = false) { if (px) { a.flags |= GEMM_OUT_PAIR | (hi_only ? GEMM_OUT_PAIR_HI : 0); a.ldc *= 2; a.c_lo = a.N; } return *this; }
 };
 // forward GEMM of tower `which` (0 text, 1 image) under the CU partition: persistent 256 x 256 tiles on at most cur_part[which] workgroups
 inline void part_gemm(const mmhip_engine& e, G& g, int which) {
@@ -649,14 +649,14 @@ int text_forward(mmhip_engine& e, hipStream_t s) {
 // (every kernel alone on the chip), and the step takes 11.2 ms against 12.2 ms with the side streams off -- but 10.4 ms with the
 // image tower on its own stream, where kernels of the two towers share CUs.  Hence opt-in: MMHIP_LOCKSTEP=1.
 bool lockstep_ok(const mmhip_engine& e) {
-    // MMHIP_LOCKSTEP: 1 = on, 0 = off; unset = on in the parity mode with plane pairs only.  There every GEMM is three times as long, two towers on
-    // two streams finish together in the SUM of their kernels' times (13.0 ms of forward for 12.4 ms of GEMMs measured alone, round 5) -- the
-    // streams buy nothing -- while the paired launches fill 96 % of their rounds instead of 78 % / 75 % (QKV: 600 + 384 tiles of 256 x 192 =
-    // 3.84 rounds of 256 instead of 2.34 -> 3 and 1.5 -> 2).  In the 16-bit modes the two streams win (above).
+    // MMHIP_LOCKSTEP=1: opt-in, every dtype.  Round 5 tried it as the default of the parity mode with plane pairs, where every GEMM is three times
+    // as long and the towers' own launches fill 78 % / 75 % of their rounds: the paired launches cut the forward's GEMM time by 14 % (12.4 -> 10.7 ms
+    // measured alone) -- and the forward got 0.5 ms LONGER (13.5 vs 13.0 ms, same box, profiles/r05_x3_lockstep.txt), also with the towers' row
+    // kernels forked onto two streams between the pairs: on two streams one tower's attention / LayerNorm kernels hide under the other's
+    // GEMMs for free, in lockstep they are serial work between launches that wait for each other.  Off by default in every mode.
     static int on = -2;
-    if (on == -2) { const char* v = getenv("MMHIP_LOCKSTEP"); on = v ? atoi(v) : -1; }
-    const bool want = on > 0 || (on < 0 && e.dt() == DT_F32 && e.px);
-    return want && (e.dt() == DT_BF16 || e.dt() == DT_F16 || (e.dt() == DT_F32 && e.px)) && !e.clip() && e.Hv() == e.cfg.hidden && e.Iv() == e.cfg.inter &&
+    if (on == -2) { const char* v = getenv("MMHIP_LOCKSTEP"); on = v ? atoi(v) : 0; }
+    return on > 0 && (e.dt() == DT_BF16 || e.dt() == DT_F16 || (e.dt() == DT_F32 && e.px)) && !e.clip() && e.Hv() == e.cfg.hidden && e.Iv() == e.cfg.inter &&
            e.cfg.layers_txt > 0 && e.cfg.layers_img > 0;
 }
 int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s) {
@@ -690,7 +690,12 @@ int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s)
     if (e.cls_only < 0) { const char* v = getenv("MMHIP_CLS_ONLY"); e.cls_only = v ? atoi(v) : 1; }
     e.cls_compact = false;
     const int L = c.layers_txt > c.layers_img ? c.layers_txt : c.layers_img;
-    auto attn = [&](const char* qkv, const float* mb, char* ctx, float* lse, int posts, int S, int heads, const DropCfg* d, int q_tiles) -> int {
+    // Between the paired GEMMs the towers' row kernels are independent: the image tower's attention / LayerNorm go to the side stream, beside the
+    // text tower's on `s` (fork / join by events; 71 + 42 us of attention and 18 + 13 us of LayerNorm per layer, each alone on the chip, round 5)
+    hipStream_t sv = use_side(e) ? e.side_vit[0] : s;
+    auto fork = [&]() -> int { if (sv != s) { CHECK_HIP(hipEventRecord(e.ev_fork, s)); CHECK_HIP(hipStreamWaitEvent(sv, e.ev_fork, 0)); } return 0; };
+    auto join = [&]() -> int { if (sv != s) { CHECK_HIP(hipEventRecord(e.ev_vit, sv)); CHECK_HIP(hipStreamWaitEvent(s, e.ev_vit, 0)); } return 0; };
+    auto attn = [&](hipStream_t st, const char* qkv, const float* mb, char* ctx, float* lse, int posts, int S, int heads, const DropCfg* d, int q_tiles) -> int {
         AttnArgs at;
         memset(&at, 0, sizeof(at));
         at.qkv = qkv; at.maskbias = mb; at.ctx = ctx; at.lse = lse; at.posts = posts; at.S = S; at.heads = heads; at.ld_qkv = 3 * H; at.ld_ctx = H; at.hidden = H;
@@ -698,7 +703,7 @@ int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s)
         at.scale = 1.0f / sqrtf((float)(H / heads));
         if (d) at.drop = *d;
         at.q_tiles = q_tiles;
-        CHECK_HIP(launch_attn_fwd(at, dt, s));
+        CHECK_HIP(launch_attn_fwd(at, dt, st));
         return 0;
     };
     for (int l = 0; l < L; ++l) {
@@ -714,8 +719,8 @@ int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s)
             if (ht && hv) return run_gemm_pair(e, gt, gv, s);
             return run_gemm(e, ht ? gt : gv, s);
         };
-        // ---- QKV (image tower: pre-LN)
-        if (hv) {
+        // ---- QKV (image tower: pre-LN; layer 0's runs here, the later layers' beside the text tower's closing LayerNorm of the layer above)
+        if (hv && l == 0) {
             LNArgs ln{xv, e.ws + e.v_ln, F + ov.ln1_w, F + ov.ln1_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
             ln_to(ln, e.v_ln, H);
             CHECK_HIP(launch_layernorm_fwd(ln, dt, s));
@@ -726,11 +731,15 @@ int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s)
             if (int r = both(gt, gv)) return r;
         }
         // ---- attention
+        if (hv) {
+            if (int r = fork()) return r;
+            if (int r = attn(sv, e.ws + e.v_qkv, nullptr, e.ws + e.v_ctx, nullptr, B, P, e.heads_v(), nullptr, 0)) return r;
+        }
         if (ht) {
             const DropCfg d = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
-            if (int r = attn(e.ws + a.qkv, e.wsp<float>(e.maskbias), e.ws + a.ctx, e.wsp<float>(a.lse), Bt, T, c.heads, &d, compact ? 1 : 0)) return r;
+            if (int r = attn(s, e.ws + a.qkv, e.wsp<float>(e.maskbias), e.ws + a.ctx, e.wsp<float>(a.lse), Bt, T, c.heads, &d, compact ? 1 : 0)) return r;
         }
-        if (hv) if (int r = attn(e.ws + e.v_qkv, nullptr, e.ws + e.v_ctx, nullptr, B, P, e.heads_v(), nullptr, 0)) return r;
+        if (hv) if (int r = join()) return r;
         // ---- attention output (+ residual)
         {
             G gt(e.ws + a.ctx, rs, e.ws + wt.ao, H, e.ws + a.pre1, H, Mr, H, H);
@@ -738,16 +747,18 @@ int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s)
             G gv(e.ws + e.v_ctx, H, e.ws + wv.ao, H, xv, H, Mv, H, H); gv.bias(F + ov.ao_b).residual(xv, H).px_in(px);
             if (int r = both(gt, gv)) return r;
         }
+        if (hv) {
+            if (int r = fork()) return r;
+            LNArgs ln2{xv, e.ws + e.v_ln, F + ov.ln2_w, F + ov.ln2_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+            ln_to(ln2, e.v_ln, H);
+            CHECK_HIP(launch_layernorm_fwd(ln2, dt, sv));
+        }
         if (ht) {
             LNArgs ln1{e.ws + a.pre1, e.ws + a.a1, W + ot.ln1_w, W + ot.ln1_b, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), Mr, H, H, H, c.ln_eps_txt};
             if (px) { ln1.y_pair = e.ws + a.a1p; ln1.ld_pair = 2 * H; ln1.lo_pair = H; }
             CHECK_HIP(launch_layernorm_fwd(ln1, dt, s));
         }
-        if (hv) {
-            LNArgs ln2{xv, e.ws + e.v_ln, F + ov.ln2_w, F + ov.ln2_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
-            ln_to(ln2, e.v_ln, H);
-            CHECK_HIP(launch_layernorm_fwd(ln2, dt, s));
-        }
+        if (hv) if (int r = join()) return r;
         // ---- feed-forward
         {
             G gt(e.ws + (px ? a.a1p : a.a1), H, e.ws + wt.fc1, H, e.ws + a.h, I, Mr, I, H); gt.bias(W + ot.fc1_b).aux(e.ws + a.u, I).gelu().px_in(px).px_out(px);
@@ -760,6 +771,15 @@ int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s)
             G gv(e.ws + e.v_h, I, e.ws + wv.fc2, I, xv, H, Mv, H, I); gv.bias(F + ov.fc2_b).residual(xv, H).px_in(px);
             if (int r = both(gt, gv)) return r;
         }
+        // ---- the text layer's closing LayerNorm beside the image tower's opening one of the next layer
+        const bool vnext = l + 1 < c.layers_img;
+        if (vnext) {
+            if (int r = fork()) return r;
+            const LayerOff& on = e.vit[l + 1];
+            LNArgs ln{xv, e.ws + e.v_ln, F + on.ln1_w, F + on.ln1_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
+            ln_to(ln, e.v_ln, H);
+            CHECK_HIP(launch_layernorm_fwd(ln, dt, sv));
+        }
         if (ht) {
             LNArgs ln2{e.ws + a.pre2, e.ws + a.out, W + ot.ln2_w, W + ot.ln2_b, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), Mr, H, H, H, c.ln_eps_txt};
             if (px) { ln2.y_pair = e.ws + a.outp; ln2.ld_pair = 2 * H; ln2.lo_pair = H; }
@@ -768,6 +788,7 @@ int towers_forward_lockstep(mmhip_engine& e, const float* pixels, hipStream_t s)
             xt = e.ws + a.out;
             xtg = px ? e.ws + a.outp : xt;
         }
+        if (vnext) if (int r = join()) return r;
     }
     LNArgs lnf{xv, e.ws + e.v_out, F + e.v_ln_w, F + e.v_ln_b, nullptr, nullptr, Mv, H, H, H, c.ln_eps_img};
     CHECK_HIP(launch_layernorm_fwd(lnf, dt, s));
@@ -938,6 +959,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     const TextAct& a = e.tact[l];
     const bool px = e.px;
     const int np = e.bwd_np;          // parity mode: MFMA products per k slice of the backward's GEMMs (mmhip_set_backward_products)
+    const bool hi1 = px && np == 1;   // one product everywhere downstream: the lo planes of du / d ctx / d qkv / the dropped LayerNorm gradients are never read -- not written
     const char* x_in = px ? (l ? e.ws + e.tact[l - 1].outp : e.ws + e.x0p) : (l ? e.ws + e.tact[l - 1].out : e.ws + e.x0);      // as the dWqkv product reads it
     const bool tr = e.train_mode;
     // temporaries that the weight-gradient GEMMs read are double-buffered per layer parity so that the side stream may
@@ -960,7 +982,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     // (the second stage of its dgamma / dbeta reduction is not on the dX chain: it runs with the layer's dW on the side stream)
     LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mr, H,
                  e.wsp<float>(e.g_lnp[set][0]), 1.0f / e.gscale(), d_ffn.thresh16 ? ddrop2 : nullptr, nullptr, d_ffn, rmul, 1};
-    if (px) { b2.pair_out = ddrop2; b2.ld_pair = 2 * H; b2.lo_pair = H; }      // parity mode: the GEMMs' operand (dropped or not) as a plane pair in the ddrop buffer
+    if (px) { b2.pair_out = ddrop2; b2.ld_pair = 2 * H; b2.lo_pair = H; b2.pair_hi_only = hi1; }      // parity mode: the GEMMs' operand (dropped or not) as a plane pair in the ddrop buffer
     CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
     const char* df = (px || d_ffn.thresh16) ? ddrop2 : dpre2;
     // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
@@ -970,7 +992,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     auto part_bwd = [&](G& g, int bit) {
         if (e.part_bwd > 0 && (bwd_mask & bit) && side && g.a.M >= 2048 && g.a.N % 256 == 0 && g.a.K % 64 == 0 && (dt == DT_BF16 || dt == DT_F16)) { g.a.tile = 15; g.a.grid = e.part_bwd; }
     };
-    { G g(df, H, e.ws + w.fc2T, H, du, I, Mr, I, H); g.mul_gelu_grad(e.ws + a.u, I).px_in(px, np).px_out(px); part_bwd(g, 1); if (int r = run_gemm(e, g, s)) return r; }
+    { G g(df, H, e.ws + w.fc2T, H, du, I, Mr, I, H); g.mul_gelu_grad(e.ws + a.u, I).px_in(px, np).px_out(px, hi1); part_bwd(g, 1); if (int r = run_gemm(e, g, s)) return r; }
     // the two long-K activation-gradient GEMMs of the layer (768 wide): one role-specialised 256x96 tile per CU when M gives
     // exactly <= 256 of them -- in isolation 7 % faster than the 192 tiles of 256x128, in the step -0.05 ms (same-box A/B; the
     // same tile in the FORWARD costs +0.3 ms: it leaves no CU to the image tower).  MMHIP_BWD_TILE12=0 turns it off.
@@ -982,19 +1004,19 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     const DropCfg d_ao = make_drop(c.p_hidden, e.seed, stream_attn_out(l), tr);
     LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mr, H,
                  e.wsp<float>(e.g_lnp[set][1]), 1.0f / e.gscale(), d_ao.thresh16 ? ddrop1 : nullptr, nullptr, d_ao, rmul, 1};
-    if (px) { b1.pair_out = ddrop1; b1.ld_pair = 2 * H; b1.lo_pair = H; }
+    if (px) { b1.pair_out = ddrop1; b1.ld_pair = 2 * H; b1.lo_pair = H; b1.pair_hi_only = hi1; }
     CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
     const char* dout = (px || d_ao.thresh16) ? ddrop1 : dpre1;
     if (compact) {
         // d ctx for the CLS rows only, spread into an otherwise-zero full tensor for the attention backward (parity mode: pair rows of 2 H 16-bit
         // elements are moved as the H 4-byte words they occupy; an all-zero pair is zero)
-        { G g(dout, H, e.ws + w.aoT, H, dx2, H, Mr, H, H); g.px_in(px, np).px_out(px); if (int r = run_gemm(e, g, s)) return r; }
+        { G g(dout, H, e.ws + w.aoT, H, dx2, H, Mr, H, H); g.px_in(px, np).px_out(px, hi1); if (int r = run_gemm(e, g, s)) return r; }
         CHECK_HIP(hipMemsetAsync(dctx, 0, (size_t)Mt * H * e.esz(), s));
         CHECK_HIP(launch_scatter_rows16(dx2, dctx, Bt, (size_t)T * H, H, 0, dt, s));
         CHECK_HIP(hipMemsetAsync(dqkv, 0, (size_t)Mt * 3 * H * e.esz(), s));      // dQ of the skipped query tiles is zero
     } else {
         G g(dout, H, e.ws + w.aoT, H, dctx, H, Mt, H, H);
-        g.px_in(px, np).px_out(px);
+        g.px_in(px, np).px_out(px, hi1);
         g.a.tile = (bt12 & 2) ? nt : 0;
         part_bwd(g, 4);
         if (int r = run_gemm(e, g, s)) return r;
@@ -1003,7 +1025,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     memset(&ab, 0, sizeof(ab));
     ab.qkv = e.ws + a.qkv; ab.maskbias = e.wsp<float>(e.maskbias); ab.ctx = e.ws + a.ctx; ab.dctx = dctx; ab.lse = e.wsp<float>(a.lse);
     ab.dqkv = dqkv; ab.posts = Bt; ab.S = T; ab.heads = c.heads; ab.ld_qkv = 3 * H; ab.ld_ctx = H; ab.hidden = H;
-    if (px) { ab.pair = 1; ab.ld_qkv = 6 * H; ab.lo_qkv = 3 * H; ab.ld_ctx = 2 * H; ab.lo_ctx = H; }
+    if (px) { ab.pair = 1; ab.ld_qkv = 6 * H; ab.lo_qkv = 3 * H; ab.ld_ctx = 2 * H; ab.lo_ctx = H; ab.nprod = np; }
     ab.scale = 1.0f / sqrtf((float)(H / c.heads));
     ab.drop = make_drop(c.p_attn, e.seed, stream_attn(l), tr);
     ab.q_tiles = compact ? 1 : 0;

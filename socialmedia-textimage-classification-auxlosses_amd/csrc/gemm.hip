@@ -336,8 +336,12 @@ void gemm_tn_kernel(GemmTNGroup g) {
         if (i < g.count && id >= g.p[i].tile_start) pi = i;
     const GemmTNProblem& P = g.p[pi];
     id -= P.tile_start;
-    const int tilesC = P.Nc / BNC;
-    const int n0 = (id / tilesC) * BNN, c0 = (id % tilesC) * BNC;
+    // Tile walk: consecutive ids (one XCD's chunk, running side by side in lockstep along m) share the band of the LARGER operand, so that band
+    // crosses the fabric once instead of once per band of the other operand -- dW2 = df^T . h: B = h is four times A (round 5: its 24 column
+    // bands were each fetched by three XCDs; the other three problems of a layer have the larger operand in A and keep the row-major walk)
+    const int tilesC = P.Nc / BNC, tilesN = P.Nn / BNN;
+    const bool c_major = P.Nc > P.Nn;
+    const int n0 = (c_major ? id % tilesN : id / tilesC) * BNN, c0 = (c_major ? id / tilesN : id % tilesC) * BNC;
     const T* __restrict__ A = (const T*)P.A;
     const T* __restrict__ B = (const T*)P.B;
 

@@ -120,7 +120,7 @@ __device__ __forceinline__ void epilogue8(const GemmNTArgs& a, float* v, int m, 
         const Frag3 f = split8(v);
         bf16_t* c = (bf16_t*)a.C + (size_t)m * a.ldc + n;
         *reinterpret_cast<bf16x8*>(c) = f.hi;
-        *reinterpret_cast<bf16x8*>(c + a.c_lo) = f.lo;
+        if (!(fl & GEMM_OUT_PAIR_HI)) *reinterpret_cast<bf16x8*>(c + a.c_lo) = f.lo;
     } else {
         v8 o;
 #pragma unroll
@@ -618,7 +618,7 @@ static void launch_nt8_e(const GemmNTPair& g, int persistent, hipStream_t s) {
 }
 // epilogue class that covers a flag set (a pair uses the class that covers both)
 static int nt8_class(int f) {
-    f &= ~GEMM_OUT_PAIR;          // where the result goes does not change the class
+    f &= ~(GEMM_OUT_PAIR | GEMM_OUT_PAIR_HI);          // where the result goes does not change the class
     if (f == (GEMM_BIAS | GEMM_GELU) || f == (GEMM_BIAS | GEMM_GELU | GEMM_AUX_PRE) || f == (GEMM_BIAS | GEMM_QGELU)) return EP_GELU;
     if (f == GEMM_MUL_GELU_GRAD || f == (GEMM_MUL_GELU_GRAD | GEMM_RESIDUAL)) return EP_MULG;
     if (!(f & ~(GEMM_BIAS | GEMM_DROPOUT | GEMM_RESIDUAL))) return EP_PLAIN;

@@ -22,6 +22,7 @@ enum {
     GEMM_TANH = 128,
     GEMM_QGELU = 256,         // quick-GELU x * sigmoid(1.702 x)   (HF CLIP hidden_act "quick_gelu")
     GEMM_OUT_PAIR = 512,      // parity mode: C is a plane pair (below) instead of fp32
+    GEMM_OUT_PAIR_HI = 1024,  // ... of which only the hi plane is written: every reader takes one product (GemmNTArgs::nprod = 1), the lo plane is never read
 };
 // Parity mode (bf16x3), round 4: PLANE PAIRS.  A tensor that feeds a matrix product is stored by its PRODUCER as two bf16 planes,
 // hi = bf16(x) and lo = bf16(x - hi), side by side in one row: element (r, c) has hi at base[r * ld + c] and lo at base[r * ld + lo_off + c]
@@ -123,6 +124,8 @@ struct AttnBwdArgs {
     int lo_qkv, lo_ctx;
     int Sq_live, Sk_live; // as in AttnArgs: rows of ctx / dctx past Sq_live are never read (their gradient is taken as zero), dQ rows past Sq_live and
                           // dK / dV rows past Sk_live are not written
+    int nprod;            // plane pairs: 1 = the scores keep three products (they are re-computed against the forward's log-sum-exp), the four other matrix
+                          // products take one, d ctx is read from its hi plane only; 0 / 3: three products throughout (GemmNTArgs::nprod: the engine's policy)
 };
 hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s);
 hipError_t launch_attn_fwd_f32(const AttnArgs& a, hipStream_t s);
@@ -150,6 +153,7 @@ struct LNBwdArgs {
     int defer_reduce;     // 1: only write the per-block partials; the caller runs launch_layernorm_bwd_reduce later
     void* pair_out; int ld_pair, lo_pair;      // parity mode (optional): the tensor the following GEMMs read (dx_drop where dropout is on, else dx) as a
                                                // plane pair; the fp32 dx_drop is then not written
+    int pair_hi_only;                          // ... its hi plane only (every reader takes one product: GemmNTArgs::nprod = 1)
 };
 hipError_t launch_layernorm_bwd_reduce(const LNBwdArgs& a, hipStream_t s);
 hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s);

@@ -46,45 +46,59 @@ __device__ __forceinline__ void store4_pair(bf16_t* p, int lo, const float* v) {
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm forward
+// A wave takes LN_FWD_RPW rows and requests all of them before it uses the first: one row per wave left ~1 KB in flight per wave and the kernel
+// latency-bound at a third of the HBM rate (round 4: 12.7 us for 12608 x 768 bf16 rows, 38 % of 8 TB/s; profiles/r05_rowop_bench.txt)
+static constexpr int LN_FWD_RPW = 2;
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows) return;
+    const int lane = threadIdx.x & 63, row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_FWD_RPW;
+    if (row0 >= a.rows) return;
     const int nch = a.width >> 2;
-    const T* x = (const T*)a.x + (size_t)row * a.ldx;
-    float v[MAXC][4];
-    float s = 0.f;
+    typedef typename Vec<T>::v4 v4;
+    v4 raw[LN_FWD_RPW][MAXC];
 #pragma unroll
-    for (int t = 0; t < MAXC; ++t) {
-        const int c = lane + 64 * t;
-        if (c < nch) {
-            load4<T>(x + c * 4, v[t]);
-            s += v[t][0] + v[t][1] + v[t][2] + v[t][3];
-        }
+    for (int i = 0; i < LN_FWD_RPW; ++i) {
+        const int row = min(row0 + i, a.rows - 1);
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t)
+            if (lane + 64 * t < nch) raw[i][t] = *reinterpret_cast<const v4*>((const T*)a.x + (size_t)row * a.ldx + (lane + 64 * t) * 4);
     }
-    const float mean = wave_sum(s) / a.width;
-    float q = 0.f;
 #pragma unroll
-    for (int t = 0; t < MAXC; ++t)
-        if (lane + 64 * t < nch)
+    for (int i = 0; i < LN_FWD_RPW; ++i) {
+        const int row = row0 + i;
+        if (row >= a.rows) break;
+        float v[MAXC][4];
+        float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { float d = v[t][e] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) / a.width + a.eps);
-    T* y = (T*)a.y + (size_t)row * a.ldy;
+        for (int t = 0; t < MAXC; ++t)
+            if (lane + 64 * t < nch) {
 #pragma unroll
-    for (int t = 0; t < MAXC; ++t) {
-        const int c = lane + 64 * t;
-        if (c < nch) {
-            float g[4], b[4], o[4];
-            load4<float>(a.gamma + c * 4, g);
-            load4<float>(a.beta + c * 4, b);
+                for (int e = 0; e < 4; ++e) { v[t][e] = to_f<T>(raw[i][t][e]); s += v[t][e]; }
+            }
+        const float mean = wave_sum(s) / a.width;
+        float q = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[t][e] - mean) * rstd * g[e] + b[e];
-            if (a.y) store4<T>(y + c * 4, o);
-            if (std::is_same<T, float>::value && a.y_pair) store4_pair((bf16_t*)a.y_pair + (size_t)row * a.ld_pair + c * 4, a.lo_pair, o);
+        for (int t = 0; t < MAXC; ++t)
+            if (lane + 64 * t < nch)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float d = v[t][e] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / a.width + a.eps);
+        T* y = (T*)a.y + (size_t)row * a.ldy;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            if (c < nch) {
+                float g[4], b[4], o[4];
+                load4<float>(a.gamma + c * 4, g);
+                load4<float>(a.beta + c * 4, b);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[t][e] - mean) * rstd * g[e] + b[e];
+                if (a.y) store4<T>(y + c * 4, o);
+                if (std::is_same<T, float>::value && a.y_pair) store4_pair((bf16_t*)a.y_pair + (size_t)row * a.ld_pair + c * 4, a.lo_pair, o);
+            }
         }
+        if (lane == 0 && a.mean) { a.mean[row] = mean; a.rstd[row] = rstd; }
     }
-    if (lane == 0 && a.mean) { a.mean[row] = mean; a.rstd[row] = rstd; }
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm backward
@@ -177,7 +191,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
                     if (!(std::is_same<T, float>::value && a.pair_out)) store4<T>((T*)a.dx_drop + (size_t)row * a.width + c * 4, o);
                 }
                 // parity mode: what the following matrix products read (the dropped gradient where dropout is on) as a plane pair
-                if (std::is_same<T, float>::value && a.pair_out) store4_pair((bf16_t*)a.pair_out + (size_t)row * a.ld_pair + c * 4, a.lo_pair, o);
+                if (std::is_same<T, float>::value && a.pair_out) {
+                    bf16_t* pp = (bf16_t*)a.pair_out + (size_t)row * a.ld_pair + c * 4;
+                    if (a.pair_hi_only) { bf16x4 h; h[0] = (bf16_t)o[0]; h[1] = (bf16_t)o[1]; h[2] = (bf16_t)o[2]; h[3] = (bf16_t)o[3]; *reinterpret_cast<bf16x4*>(pp) = h; }
+                    else store4_pair(pp, a.lo_pair, o);
+                }
                 if (a.colsum_out) {      // sums of the values as the bias-gradient consumer sees them (16-bit rounded)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dc[t][e] += to_f<T>(from_f<T>(o[e]));
@@ -812,9 +830,9 @@ static inline int cap_grid(size_t work_items) {
 hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
     if (a.width % 4 || a.width > 1024 || a.ldx % 4 || a.ldy % 4) return hipErrorInvalidValue;
-    if (dtype == DT_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(ln_fwd_kernel<f16_t>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3((a.rows + 4 * LN_FWD_RPW - 1) / (4 * LN_FWD_RPW)), dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(ln_fwd_kernel<f16_t>, dim3((a.rows + 4 * LN_FWD_RPW - 1) / (4 * LN_FWD_RPW)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3((a.rows + 4 * LN_FWD_RPW - 1) / (4 * LN_FWD_RPW)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 size_t partial_floats_rows(int rows, int width, int nvec) {   // LN backward may use 3 vectors

@@ -20,20 +20,26 @@ __device__ __forceinline__ f32x4 mma3(const Frag3& a, const Frag3& b, f32x4 c) {
 
 // operand fragment of 8 consecutive k of one row: an fp32 row split in registers, or the two planes of a plane pair as they are
 // (mmhip_kernels.h: hi at base[row * ld + k], lo `lo` elements behind; ld, lo in 16-bit elements)
-__device__ __forceinline__ Frag3 frag_any(const void* base, size_t row, int ld, int k, int pair, int lo) {
+// hi_only (GemmNTArgs::nprod = 1): the lo plane is not read -- under the one-product backward its producers do not write it
+__device__ __forceinline__ Frag3 frag_any(const void* base, size_t row, int ld, int k, int pair, int lo, int hi_only = 0) {
     if (pair) {
         const bf16_t* p = (const bf16_t*)base + row * (size_t)ld + k;
         Frag3 f;
         f.hi = *reinterpret_cast<const bf16x8*>(p);
-        f.lo = *reinterpret_cast<const bf16x8*>(p + lo);
+        if (hi_only) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f.lo[e] = (bf16_t)0.0f;
+        } else {
+            f.lo = *reinterpret_cast<const bf16x8*>(p + lo);
+        }
         return f;
     }
     float v[8];
     load8((const float*)base + row * (size_t)ld + k, v);
     return split8(v);
 }
-__device__ __forceinline__ float value_any(const void* base, size_t row, int ld, int k, int pair, int lo) {
-    if (pair) { const bf16_t* p = (const bf16_t*)base + row * (size_t)ld + k; return (float)p[0] + (float)p[lo]; }
+__device__ __forceinline__ float value_any(const void* base, size_t row, int ld, int k, int pair, int lo, int hi_only = 0) {
+    if (pair) { const bf16_t* p = (const bf16_t*)base + row * (size_t)ld + k; return hi_only ? (float)p[0] : (float)p[0] + (float)p[lo]; }
     return ((const float*)base)[row * (size_t)ld + k];
 }
 // C row store of 4 consecutive columns: fp32, or a plane pair (GEMM_OUT_PAIR)
@@ -44,7 +50,7 @@ __device__ __forceinline__ void store4_any(const GemmNTArgs& a, int m, int n, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) { h[e] = (bf16_t)v[e]; l[e] = (bf16_t)(v[e] - (float)h[e]); }
         *reinterpret_cast<bf16x4*>(c) = h;
-        *reinterpret_cast<bf16x4*>(c + a.c_lo) = l;
+        if (!(a.flags & GEMM_OUT_PAIR_HI)) *reinterpret_cast<bf16x4*>(c + a.c_lo) = l;
     } else {
         *reinterpret_cast<f32x4*>((float*)a.C + (size_t)m * a.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
     }
@@ -68,8 +74,9 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     Frag3 na[4], nb[4];
+    const int h1 = a.nprod == 1;          // one product: hi planes only (the small terms multiply zeros)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { na[i] = frag_any(a.A, arow[i], a.lda, kc * 8, a.a_pair, a.a_lo); nb[i] = frag_any(a.B, brow[i], a.ldb, kc * 8, a.b_pair, a.b_lo); }
+    for (int i = 0; i < 4; ++i) { na[i] = frag_any(a.A, arow[i], a.lda, kc * 8, a.a_pair, a.a_lo, h1); nb[i] = frag_any(a.B, brow[i], a.ldb, kc * 8, a.b_pair, a.b_lo, h1); }
 #pragma unroll 1
     for (int k0 = 0; k0 < a.K; k0 += 32) {
         Frag3 af[4], bf[4];
@@ -78,8 +85,8 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmNTArgs a) {
         if (k0 + 32 < a.K) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                na[i] = frag_any(a.A, arow[i], a.lda, k0 + 32 + kc * 8, a.a_pair, a.a_lo);
-                nb[i] = frag_any(a.B, brow[i], a.ldb, k0 + 32 + kc * 8, a.b_pair, a.b_lo);
+                na[i] = frag_any(a.A, arow[i], a.lda, k0 + 32 + kc * 8, a.a_pair, a.a_lo, h1);
+                nb[i] = frag_any(a.B, brow[i], a.ldb, k0 + 32 + kc * 8, a.b_pair, a.b_lo, h1);
             }
         }
 #pragma unroll
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) void slow_nt_f32_kernel(GemmNTArgs a) {
     const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
     if (n >= a.N) return;
     float v = 0.f;
-    for (int k = 0; k < a.K; ++k) v = fmaf(value_any(a.A, m, a.lda, k, a.a_pair, a.a_lo), value_any(a.B, n, a.ldb, k, a.b_pair, a.b_lo), v);
+    for (int k = 0; k < a.K; ++k) v = fmaf(value_any(a.A, m, a.lda, k, a.a_pair, a.a_lo, a.nprod == 1), value_any(a.B, n, a.ldb, k, a.b_pair, a.b_lo, a.nprod == 1), v);
     const int fl = a.flags;
     if (fl & GEMM_BIAS) v += a.bias[n];
     if (fl & GEMM_AUX_PRE) ((float*)a.aux)[(size_t)m * a.ldaux + n] = v;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(GemmTNProblem P, int ac
                 const int m = mb + 8 * kc + e;
                 const bool in = m < P.M;
                 const int mr = in ? m : P.M - 1;
-                const float y = value_any(P.A, mr, P.lda, ncol[i], P.pair, P.a_lo), x = value_any(P.B, mr, P.ldb, ccol[i], P.pair, P.b_lo);
+                const float y = value_any(P.A, mr, P.lda, ncol[i], P.pair, P.a_lo, P.nprod == 1), x = value_any(P.B, mr, P.ldb, ccol[i], P.pair, P.b_lo, P.nprod == 1);
                 ry[e] = in ? y : 0.f;
                 rx[e] = in ? x : 0.f;
             }

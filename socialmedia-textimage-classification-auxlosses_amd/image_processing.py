@@ -334,12 +334,21 @@ class DevicePrefetcher:
         c = getattr(c, "inner", c)                 # BatchTokenizeCollate wraps the image collate
         return getattr(c, "owner", 0)
 
+    def prime(self):
+        """ask the loader for its next epoch's iterator NOW: its workers start on the epoch's first batches while the caller is still busy with
+        something else (the tail of the previous epoch on another loader: MMLate_Model.train, MMHIP_EPOCH_PREFETCH).  The sampler's shuffle is
+        drawn here.  The following __iter__ continues with this iterator."""
+        if getattr(self, "_primed", None) is None:
+            if self.ring is not None:
+                self.ring.begin_epoch(self._ring_owner())
+            self._primed = iter(self.loader)
+            if self.ring is not None:              # slots named by batches of an abandoned epoch (dropped by the loader's reset) come back
+                self.ring.recover(self._ring_owner(), {slot for slot, _ in self._held})
+        return self
+
     def __iter__(self):
-        if self.ring is not None:
-            self.ring.begin_epoch(self._ring_owner())
-        it = iter(self.loader)
-        if self.ring is not None:                  # slots named by batches of an abandoned epoch (dropped by the loader's reset) come back
-            self.ring.recover(self._ring_owner(), {slot for slot, _ in self._held})
+        self.prime()
+        it, self._primed = self._primed, None
         queue = []
 
         def fetch():

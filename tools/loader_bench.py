@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--image_px", default="480x360")
     ap.add_argument("--item_tokenize", action="store_true")
     ap.add_argument("--no_ring", action="store_true", help="A/B: decoded images through the DataLoader's result queue (round 3) instead of the pinned shared-memory ring")
+    ap.add_argument("--epoch_prefetch", action="store_true", help="MMHIP_EPOCH_PREFETCH: a twin loader on which the next epoch is primed while this epoch's tail is trained on")
     ap.add_argument("--resident_last", action="store_true", help="A/B: only MMLate_Model.warm_start() runs before the workers fork; the resident step is not timed")
     args = ap.parse_args()
     import pandas as pd
@@ -104,7 +105,7 @@ def main():
     ring = None
     if args.workers and not args.no_ring:
         from smtc_amd.image_processing import RingCollate, SharedImageRing
-        ring = SharedImageRing(args.workers * 4 + 6, int(1.1 * args.batch * (w * h * 3 + 16)))
+        ring = SharedImageRing(args.workers * 4 * (2 if args.epoch_prefetch else 1) + 6, int(1.1 * args.batch * (w * h * 3 + 16)))
         inner = RingCollate(proc, ring)
     collate = inner if args.item_tokenize else BatchTokenizeCollate(tok, 128, inner)
     kw = dict(num_workers=args.workers, collate_fn=collate, drop_last=True)
@@ -123,11 +124,27 @@ def main():
     epoch_loader_only()                                   # start the workers, warm the page cache
     t = time.time(); n = epoch_loader_only(); loader_ps = n / (time.time() - t)
 
+    feeds, turn = [DevicePrefetcher(loader, dev, proc, depth=3, trim_padding=False, ring=ring)], [0]
+    if args.epoch_prefetch and args.workers:
+        twin_collate = RingCollate(proc, ring, owner=3) if ring is not None else RawImageCollate(proc)
+        kw2 = dict(kw, collate_fn=twin_collate if args.item_tokenize else BatchTokenizeCollate(tok, 128, twin_collate))
+        twin = torch.utils.data.DataLoader(ds, batch_size=args.batch, shuffle=True, **kw2)
+        feeds.append(DevicePrefetcher(twin, dev, proc, depth=3, trim_padding=False, ring=ring))
+        for b_ in twin:                                   # start the twin's workers as well
+            if "image_slot" in b_:
+                ring.release(int(b_["image_slot"]))
+    lead = args.workers * 4
+
     def epoch_train():
         nonlocal step
         n = 0
         t_start = time.time()
-        for b in DevicePrefetcher(loader, dev, proc, depth=3, trim_padding=False, ring=ring):
+        cur = turn[0] % len(feeds)
+        turn[0] += 1
+        nb = len(feeds[cur])
+        for it, b in enumerate(feeds[cur]):
+            if len(feeds) > 1 and it == max(0, nb - 1 - lead):
+                feeds[1 - cur].prime()                    # the next epoch's workers start while this epoch's tail is trained on
             if n == 0:
                 fills.append(time.time() - t_start)          # epoch start: the workers decode their first batches while the GPU waits
             ids, mask, px = trainer._unpack(b)
@@ -168,7 +185,7 @@ def main():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     print(json.dumps({"posts": args.posts, "image_px": args.image_px, "workers": args.workers, "host_cores": cores, "batch": args.batch, "layers": args.layers,
                       "tokenise": "per item" if args.item_tokenize else "per batch (collate)", "image_handoff": "pinned shared-memory ring" if ring is not None else "DataLoader queue",
-                      "ring_pinned": bool(ring is not None and ring.pinned),
+                      "ring_pinned": bool(ring is not None and ring.pinned), "epoch_prefetch": bool(args.epoch_prefetch),
                       "loader_only_posts_per_s": round(loader_ps, 1), "loader_to_train_step_posts_per_s": round(e2e_ps, 1),
                       "epoch_fill_ms": round(1e3 * sum(fills) / len(fills), 1), "after_fill_posts_per_s": round(steady_ps, 1),
                       "resident_batch_train_step_posts_per_s": round(res_ps, 1), "end_to_end_over_resident": round(e2e_ps / res_ps, 3) if res_ps == res_ps else None,
