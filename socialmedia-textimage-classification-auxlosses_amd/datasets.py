@@ -235,9 +235,8 @@ def loaders_from_data_key(cfg, args, trainer):
         kw.update(persistent_workers=True, prefetch_factor=4, worker_init_fn=worker_init)
     # MMHIP_EPOCH_PREFETCH=1 (opt-in): a second training loader (its own workers) on which MMLate_Model.train starts epoch N + 1 while epoch N's
     # last batches are still being trained on -- the GPU no longer waits ~60 ms at every epoch start for the workers' first decoded batches
-    # (0.90 -> 0.96 of the resident rate over 4 096-post epochs).  Opt-in because the next epoch's shuffle is then drawn from
-    # torch's global generator BEFORE the validation / test loaders draw their seeds instead of after: a seeded run visits the posts in another
-    # order than without the flag (and than the reference).
+    # (DESIGN.md 8 f2).  Opt-in because the next epoch's shuffle is then drawn from torch's global generator BEFORE the validation / test loaders
+    # draw their seeds instead of after: a seeded run visits the posts in another order than without the flag (and than the reference).
     twin_wanted = kw["num_workers"] > 0 and os.environ.get("MMHIP_EPOCH_PREFETCH", "0") == "1"
     inner, ring_collates = None, None
     if gpu:
@@ -260,9 +259,9 @@ def loaders_from_data_key(cfg, args, trainer):
             if slots * slot_mb > room_mb:
                 fit = int(room_mb / slot_mb)
                 logger.warning("image ring: %d slots of %.0f MB do not fit /dev/shm (%.0f MB usable): %s", slots, slot_mb, room_mb,
-                               f"ring cut to {fit} slots" if fit >= 3 + kw["num_workers"] else "decoded images go through the DataLoader queue instead")
+                               f"ring cut to {fit} slots" if fit >= 3 + kw["num_workers"] * n_live else "decoded images go through the DataLoader queue instead")
                 slots = fit
-            # every batch the loader can have outstanding needs a slot, beside the 3 the prefetcher holds (SharedImageRing: why)
+            # every batch the loaders can have outstanding needs a slot, beside the 3 the prefetcher holds (SharedImageRing: why)
             pf = min(4, (slots - 3) // (kw["num_workers"] * n_live))
             if pf >= 1:
                 kw["prefetch_factor"] = pf
@@ -279,113 +278,6 @@ def loaders_from_data_key(cfg, args, trainer):
             n_made[0] += owner is None
             kw["collate_fn"] = BatchTokenizeCollate(tok, cfg.max_length, rc) if batch_tok else rc
         return torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sh if sampler is None else None, sampler=sampler, **kw)
-    train_ds = mk(tr, ytr)
-    if multi:
-        sampler = torch.utils.data.distributed.DistributedSampler(train_ds, shuffle=True, seed=int(args.seed), drop_last=False)
-        train_loader = torch.utils.data.DataLoader(train_ds, batch_size=cfg.batch_size, sampler=sampler, **kw)
-    else:
-        train_loader = dl(train_ds, True)
-    return train_loader, dl(mk(va, yva), False), dl(mk(te, yte), False), w
-
-
-def worker_init(_worker_id):
-    """DataLoader worker: one thread per worker.  The GPU box grants a CPU share (16 cores), not the host's 256: a Rust tokenizer pool or an
-    OpenMP team sized by the host's core count inside each of 8+ workers oversubscribes that share and throttles the process that enqueues
-    the GPU step (tools/loader_bench.py)."""
-    os.environ["TOKENIZERS_PARALLELISM"] = "false"
-    os.environ["OMP_NUM_THREADS"] = "1"
-    torch.set_num_threads(1)
-
-
-class BatchTokenizeCollate:
-    """collate_fn: the batch's normalised texts -> input_ids / attention_mask [B, max_length] in ONE tokenizer call (the fast tokenizers'
-    encode_batch: Rust, all cores of the worker) instead of one Python-level call per item (reference models/datasets.py:141-146 encodes per
-    item and the default collate stacks [B, 1, T]; same ids, same padding='max_length' / truncation).  The remaining fields go to `inner`
-    (RawImageCollate for decoded images) or to the default collate."""
-
-    def __init__(self, tokenizer, max_length, inner=None):
-        self.tok, self.max_length, self.inner = tokenizer, max_length, inner
-
-    def __call__(self, items):
-        from torch.utils.data import default_collate
-        enc = self.tok([it["text"] for it in items], padding="max_length", truncation=True, max_length=self.max_length, return_tensors="pt")
-        rest = [{k: v for k, v in it.items() if k != "text"} for it in items]
-        batch = self.inner(rest) if self.inner is not None else default_collate(rest)
-        batch["input_ids"], batch["attention_mask"] = enc["input_ids"], enc["attention_mask"]
-        return batch
-
-
-def loaders_from_data_key(cfg, args, trainer):
-    from transformers import AutoTokenizer
-    tdir = MODEL_DIR_DICT[args.txt_model_name]
-    if not os.path.isdir(tdir):
-        raise FileNotFoundError(f"tokenizer directory {tdir!r} (config.MODEL_DIR_DICT) not found: use --synthetic, or place the model there")
-    tok = AutoTokenizer.from_pretrained(tdir)
-    # single process: numpy's global stream, exactly like the reference (run_mm_late.py:49 seeded it; the ITM sampling then
-    # continues from the reference's state).  Data parallel: every rank must draw the SAME subsample, and each rank's global
-    # stream is seeded seed + rank for its own ITM draws -- so an explicit RandomState(seed), which picks the same rows.
-    multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
-    tr, ytr, va, yva, te, yte, w = prepare_data(cfg.data, cfg.num_labels, args.testing, args.nsamples, args.seed if multi else None)
-    # image resize + normalize run on the GPU per batch (image_processing.py) unless --cpu_preprocess asks for the host form
-    gpu = not getattr(args, "cpu_preprocess", False) and trainer.device.type == "cuda"
-    size = trainer.model.arch["image"]
-    # texts are encoded per batch in the collate (one encode_batch call) unless --item_tokenize keeps the reference's per-item calls
-    batch_tok = not getattr(args, "item_tokenize", False) and getattr(tok, "is_fast", False)
-    mk = lambda df, y: MM_Dataset(df.tweet_id.values, df.text.values, y, tok, cfg.max_length, cfg.img_fmt, size, raw_images=gpu, batch_tokenize=batch_tok)
-    kw = dict(num_workers=int(getattr(args, "num_workers", 0) or 0))
-    # MMHIP_LOADER_SPLIT=s (opt-in): the workers decode one training batch side by side -- the DataLoader cuts the sampler's order into
-    # sub-batches of batch_size / s posts and the device prefetcher puts s consecutive ones back together (same posts, same order as one
-    # BatchSampler of the full size; tests/test_gpu_cli_dp.py).  With whole batches per worker the first batch of every epoch takes one
-    # worker's 64 JPEG decodes with the GPU idle (64 ms); s = 8 brings that to 36 ms but costs 3 % of the steady rate (eight times the
-    # items through the result queue, eight preprocess launches per batch): +0.7 % over a 4 096-post epoch, a loss on long epochs
-    # (profiles/r04_loader_bench.txt) -- hence off by default.
-    split = 1
-    if gpu and kw["num_workers"] > 1:
-        want = int(os.environ.get("MMHIP_LOADER_SPLIT", "1"))
-        split = max([d for d in (8, 4, 2, 1) if d <= max(1, min(want, kw["num_workers"])) and cfg.batch_size % d == 0])
-    if kw["num_workers"] > 0:
-        kw.update(persistent_workers=True, prefetch_factor=4 * split, worker_init_fn=worker_init)
-    inner, ring_collates = None, None
-    if gpu:
-        from .image_processing import GpuImageProcessor, RawImageCollate, RingCollate, SharedImageRing
-        trainer.image_processor = GpuImageProcessor(size=size, device=trainer.device)
-        inner = RawImageCollate(trainer.image_processor)
-        if kw["num_workers"] > 0 and os.environ.get("MMHIP_IMAGE_RING", "1") != "0":
-            # decoded images reach the training process through a pinned shared-memory ring instead of the DataLoader's result queue
-            # (image_processing.SharedImageRing); a batch that does not fit its slot falls back to the queue
-            slot_mb = float(os.environ.get("MMHIP_RING_SLOT_MB", str(1.5 * cfg.batch_size))) / split      # per (sub-)batch
-            slots = min((kw["num_workers"] * 4 + 6) * split, max(4, int(4096 / slot_mb)))                  # at most 4 GB of pinned shared memory
-            # every batch the loader can have outstanding needs a slot, beside the 3 * split the prefetcher holds (SharedImageRing: why)
-            pf = min(4 * split, (slots - 3 * split) // kw["num_workers"])
-            # the ring lives in /dev/shm: pages that do not fit there are a SIGBUS when a worker first touches them (a container with a small
-            # /dev/shm) -- shrink the ring to 80 % of what is free, or go without it
-            try:
-                vfs = os.statvfs("/dev/shm")
-                room_mb = vfs.f_bavail * vfs.f_frsize / (1 << 20) * 0.8
-            except OSError:
-                room_mb = float("inf")
-            if slots * slot_mb > room_mb:
-                fit = int(room_mb / slot_mb)
-                logger.warning("image ring: %d slots of %.0f MB do not fit /dev/shm (%.0f MB usable): %s", slots, slot_mb, room_mb,
-                               f"ring cut to {fit} slots" if fit >= 3 * split + kw["num_workers"] else "decoded images go through the DataLoader queue instead")
-                slots = fit
-            pf = min(4 * split, (slots - 3 * split) // kw["num_workers"])
-            if pf >= 1:
-                kw["prefetch_factor"] = pf
-                trainer.image_ring = SharedImageRing(slots, int(slot_mb * (1 << 20)))
-                ring_collates = [RingCollate(trainer.image_processor, trainer.image_ring, owner=o) for o in range(3)]      # train / val / test: one lease owner each
-        kw["collate_fn"] = inner
-    if batch_tok:
-        kw["collate_fn"] = BatchTokenizeCollate(tok, cfg.max_length, inner)
-    n_made = [0]
-    def dl(ds, sh, sampler=None):
-        if ring_collates is not None:
-            rc = ring_collates[min(n_made[0], 2)]
-            n_made[0] += 1
-            kw["collate_fn"] = BatchTokenizeCollate(tok, cfg.max_length, rc) if batch_tok else rc
-        loader = torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size // split, shuffle=sh if sampler is None else None, sampler=sampler, **kw)
-        loader.mmhip_group = split              # image_processing.DevicePrefetcher reassembles the batches
-        return loader
     train_ds = mk(tr, ytr)
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         # data parallel: every rank trains on its own shard (equal length on all ranks, so the per-stage all-reduces pair up);
