@@ -71,13 +71,6 @@ struct mmhip_engine {
                                            // process-wide registration of mmhip_set_step_guard, if any
     size_t g_set[2][6];      // double-buffered backward temporaries read by the side stream: dpre2, ddrop2, du, dpre1, ddrop1, dqkv
     size_t g_dx, g_dx2, g_dpre, g_ddrop, g_dpre1, g_ddrop1, g_dqkv, g_dctx, g_du;                               // backward temporaries
-    // the gradient of a layer's output (dx) and of its first LayerNorm's output (dx2) in TWO buffers each, alternating per layer: the column sums
-    // of the LayerNorm backward (dgamma, dbeta) read them on the side stream while the layer below is already running (text_layer_backward)
-    size_t g_dxb[2] = {0, 0}, g_dx2b[2] = {0, 0};
-    hipEvent_t ev_cols = nullptr; bool cols_pending = false;
-    int ln_split = -1;         // -1 = read MMHIP_LN_BWD_SPLIT on first use (default 1)
-    char* grad_in(int l) const { return ws + g_dxb[(cfg.layers_txt - 1 - l) & 1]; }      // layer l reads its output's gradient here ...
-    char* grad_out(int l) const { return ws + g_dxb[(cfg.layers_txt - l) & 1]; }        // ... and writes its input's gradient here (= grad_in(l - 1))
     // heads (fp32) ----------------------------------------------------------------------
     size_t h_vpool, h_tpool, h_txt_e, h_img_e, h_txt_n, h_img_n, h_txt_inv, h_img_inv, h_logits;
     size_t h_q, h_qk, h_prob, h_xbar, h_z, h_feats, h_featd, h_out_cls, h_out_tim;
@@ -350,7 +343,6 @@ void build_workspace(mmhip_engine& e) {
     e.g_dx = w.take(Mt * H * Z); e.g_dx2 = w.take(Mt * H * Z); e.g_dpre = w.take(Mt * H * Z); e.g_ddrop = w.take(Mt * H * Z); e.g_dpre1 = w.take(Mt * H * Z); e.g_ddrop1 = w.take(Mt * H * Z);
     e.g_dqkv = w.take(Mt * 3 * H * Z); e.g_dctx = w.take(Mt * H * Z); e.g_du = w.take(Mt * I * Z);
     e.g_det_rows = w.take(Mt * H * 4);       // per-slot embedding gradient rows of the deterministic mode (MMHIP_DETERMINISTIC=1)
-    e.g_dxb[0] = e.g_dx; e.g_dxb[1] = w.take(Mt * H * Z); e.g_dx2b[0] = e.g_dx2; e.g_dx2b[1] = w.take(Mt * H * Z);
     e.g_set[0][0] = e.g_dpre; e.g_set[0][1] = e.g_ddrop; e.g_set[0][2] = e.g_du; e.g_set[0][3] = e.g_dpre1; e.g_set[0][4] = e.g_ddrop1; e.g_set[0][5] = e.g_dqkv;
     e.g_set[1][0] = w.take(Mt * H * Z); e.g_set[1][1] = w.take(Mt * H * Z); e.g_set[1][2] = w.take(Mt * I * Z);
     e.g_set[1][3] = w.take(Mt * H * Z); e.g_set[1][4] = w.take(Mt * H * Z); e.g_set[1][5] = w.take(Mt * 3 * H * Z);
@@ -952,11 +944,11 @@ int heads_backward(mmhip_engine& e, hipStream_t s) {
     }
     // gradient of the last hidden state: CLS rows only
     // gradient of the last hidden state: CLS rows only (compact [Bt, H] when the last layer ran on CLS rows)
-    CHECK_HIP(launch_scatter_cls_rows(dxcls, c.layers_txt ? e.grad_in(c.layers_txt - 1) : e.grad_out(0), Bt, e.cls_compact ? 1 : T, H, dt, s, e.gscale()));
+    CHECK_HIP(launch_scatter_cls_rows(dxcls, e.ws + e.g_dx, Bt, e.cls_compact ? 1 : T, H, dt, s, e.gscale()));
     return 0;
 }
 
-// one text layer; on entry grad_in(l) holds the gradient of the layer's output, on exit grad_out(l) that of its input
+// one text layer; on entry g_dx holds the gradient of the layer's output, on exit of its input
 int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     const mmhip_config& c = e.cfg;
     const int H = c.hidden, I = c.inter, T = e.T, Bt = e.Bt, Mt = Bt * T, dt = e.dt();
@@ -977,11 +969,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     // last layer in CLS-only mode: its gradient arrives as compact [Bt, H] rows; everything up to d ctx runs on Bt rows
     const bool compact = e.cls_compact && l == c.layers_txt - 1;
     const int Mr = compact ? Bt : Mt, rs = compact ? T * H : H, rmul = compact ? T : 1;
-    char *dx = e.grad_in(l), *dx_out = e.grad_out(l), *dx2 = e.ws + e.g_dx2b[set], *dctx = e.ws + e.g_dctx;
-    // LayerNorm backward in two launches (rowops.hip ln_bwd_dx_kernel: why): dx by a light kernel that fits beside the weight-gradient workgroups
-    // of the layer above, the column partials of dgamma / dbeta on the side stream.  Not for the compact last layer (a handful of rows).
-    if (e.ln_split < 0) { const char* v = getenv("MMHIP_LN_BWD_SPLIT"); e.ln_split = v ? atoi(v) : 1; }
-    const bool ln_split = e.ln_split > 0 && side && !compact;
+    char *dx = e.ws + e.g_dx, *dx2 = e.ws + e.g_dx2, *dctx = e.ws + e.g_dctx;
     char *dpre2 = e.ws + e.g_set[set][0], *ddrop2 = e.ws + e.g_set[set][1], *du = e.ws + e.g_set[set][2];
     char *dpre1 = e.ws + e.g_set[set][3], *ddrop1 = e.ws + e.g_set[set][4], *dqkv = e.ws + e.g_set[set][5];
     if (side && e.tn_pending[set]) {           // the set was last read by layer l+2's side work
@@ -995,8 +983,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     LNBwdArgs b2{dx, e.ws + a.pre2, W + o.ln2_w, e.wsp<float>(a.mean2), e.wsp<float>(a.rstd2), dpre2, nullptr, Gd + o.ln2_w, Gd + o.ln2_b, Mr, H,
                  e.wsp<float>(e.g_lnp[set][0]), 1.0f / e.gscale(), d_ffn.thresh16 ? ddrop2 : nullptr, nullptr, d_ffn, rmul, 1};
     if (px) { b2.pair_out = ddrop2; b2.ld_pair = 2 * H; b2.lo_pair = H; b2.pair_hi_only = hi1; }      // parity mode: the GEMMs' operand (dropped or not) as a plane pair in the ddrop buffer
-    if (ln_split) CHECK_HIP(launch_layernorm_bwd_dx(b2, dt, s));
-    else CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
+    CHECK_HIP(launch_layernorm_bwd(b2, dt, s));
     const char* df = (px || d_ffn.thresh16) ? ddrop2 : dpre2;
     // du = (df . W2) * gelu'(u);  d_a1 = du . W1 + dpre2
     if (e.part_bwd < 0) { const char* v = getenv("MMHIP_PART_BWD"); e.part_bwd = v ? atoi(v) : 0; }
@@ -1018,8 +1005,7 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
     LNBwdArgs b1{dx2, e.ws + a.pre1, W + o.ln1_w, e.wsp<float>(a.mean1), e.wsp<float>(a.rstd1), dpre1, nullptr, Gd + o.ln1_w, Gd + o.ln1_b, Mr, H,
                  e.wsp<float>(e.g_lnp[set][1]), 1.0f / e.gscale(), d_ao.thresh16 ? ddrop1 : nullptr, nullptr, d_ao, rmul, 1};
     if (px) { b1.pair_out = ddrop1; b1.ld_pair = 2 * H; b1.lo_pair = H; b1.pair_hi_only = hi1; }
-    if (ln_split) CHECK_HIP(launch_layernorm_bwd_dx(b1, dt, s));
-    else CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
+    CHECK_HIP(launch_layernorm_bwd(b1, dt, s));
     const char* dout = (px || d_ao.thresh16) ? ddrop1 : dpre1;
     if (compact) {
         // d ctx for the CLS rows only, spread into an otherwise-zero full tensor for the attention backward (parity mode: pair rows of 2 H 16-bit
@@ -1052,29 +1038,18 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
         CHECK_HIP(hipStreamWaitEvent(e.side, e.ev_ready[set], 0));
         ps = e.side;
     }
-    if (e.cols_pending) {          // the layer above's column sums read its incoming gradient -- the buffer this layer's last GEMM writes
-        CHECK_HIP(hipStreamWaitEvent(s, e.ev_cols, 0));
-        e.cols_pending = false;
-    }
     if (compact) {
         // dx_in = dqkv . Wqkv, plus d pre1 on the CLS rows (the residual branch of the CLS rows)
-        { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx_out, H, Mt, H, 3 * H); g.px_in(px, np); if (int r = run_gemm(e, g, s)) return r; }
-        CHECK_HIP(launch_scatter_rows16(dpre1, dx_out, Bt, (size_t)T * H, H, 1, dt, s));
+        { G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H); g.px_in(px, np); if (int r = run_gemm(e, g, s)) return r; }
+        CHECK_HIP(launch_scatter_rows16(dpre1, dx, Bt, (size_t)T * H, H, 1, dt, s));
     } else {
-        G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx_out, H, Mt, H, 3 * H);
+        G g(dqkv, 3 * H, e.ws + w.qkvT, 3 * H, dx, H, Mt, H, 3 * H);
         g.residual(dpre1, H).px_in(px, np);
         g.a.tile = nt;
         part_bwd(g, 8);
         if (int r = run_gemm(e, g, s)) return r;
     }
     GemmTNProblem pr[4];
-    if (ln_split) {
-        CHECK_HIP(launch_layernorm_bwd_cols(b2, dt, ps));
-        CHECK_HIP(launch_layernorm_bwd_cols(b1, dt, ps));
-        if (!e.ev_cols) CHECK_HIP(hipEventCreateWithFlags(&e.ev_cols, hipEventDisableTiming));
-        CHECK_HIP(hipEventRecord(e.ev_cols, ps));
-        e.cols_pending = true;
-    }
     CHECK_HIP(launch_layernorm_bwd_reduce(b2, ps));
     CHECK_HIP(launch_layernorm_bwd_reduce(b1, ps));
     // each problem also yields its Linear's bias gradient (column sums of the dY operand) from the same tiles
@@ -1099,7 +1074,6 @@ int text_layer_backward(mmhip_engine& e, int l, hipStream_t s) {
 
 // join the side stream: after this, every gradient is final in the caller's stream order
 int backward_finish(mmhip_engine& e, hipStream_t s) {
-    e.cols_pending = false;          // (the column kernels precede the weight-gradient GEMMs joined below on the side stream)
     for (int set = 0; set < 2; ++set)
         if (e.tn_pending[set]) {
             CHECK_HIP(hipStreamWaitEvent(s, e.ev_tn[set], 0));
@@ -1122,7 +1096,7 @@ int embed_backward(mmhip_engine& e, hipStream_t s) {
     float* Gd = e.grad;
     EmbedBwdArgs b;
     memset(&b, 0, sizeof(b));
-    b.dx = e.grad_out(0); b.xhat = e.ws + e.xhat_emb; b.rstd = e.wsp<float>(e.rstd_emb); b.gamma = W + e.t_eln_w;
+    b.dx = e.ws + e.g_dx; b.xhat = e.ws + e.xhat_emb; b.rstd = e.wsp<float>(e.rstd_emb); b.gamma = W + e.t_eln_w;
     b.ids = e.wsp<int64_t>(e.ids_all); b.pos_ids = e.wsp<int>(e.pos_ids);
     b.dword = Gd + e.t_word; b.dpos = Gd + e.t_pos; b.dtype = Gd + e.t_type; b.dgamma = Gd + e.t_eln_w; b.dbeta = Gd + e.t_eln_b;
     b.posts = e.Bt; b.T = e.T; b.H = c.hidden; b.pad_id = c.pad_id;
@@ -1181,7 +1155,6 @@ void mmhip_destroy(mmhip_handle h) {
             if (ev) (void)hipEventDestroy(ev);
         for (auto sv : h->side_vit) if (sv) (void)hipStreamSynchronize(sv);      // pooled streams: drained, not destroyed
         for (auto ev : h->span_ev) if (ev) (void)hipEventDestroy(ev);
-        if (h->ev_cols) (void)hipEventDestroy(h->ev_cols);
     }
     for (auto& ev : h->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     delete h;

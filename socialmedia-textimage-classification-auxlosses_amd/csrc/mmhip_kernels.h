@@ -154,13 +154,8 @@ struct LNBwdArgs {
     void* pair_out; int ld_pair, lo_pair;      // parity mode (optional): the tensor the following GEMMs read (dx_drop where dropout is on, else dx) as a
                                                // plane pair; the fp32 dx_drop is then not written
     int pair_hi_only;                          // ... its hi plane only (every reader takes one product: GemmNTArgs::nprod = 1)
-    int cols_only;                             // ln_bwd_kernel: only the per-block column partials (dx was written by launch_layernorm_bwd_dx)
 };
 hipError_t launch_layernorm_bwd_reduce(const LNBwdArgs& a, hipStream_t s);
-// the backward in two launches: dx (+ dropped copy / plane pair) by a light kernel without LDS, the column partials of dgamma / dbeta by the fused
-// kernel in its cols_only form (rowops.hip ln_bwd_dx_kernel: why)
-hipError_t launch_layernorm_bwd_dx(const LNBwdArgs& a, int dtype, hipStream_t s);
-hipError_t launch_layernorm_bwd_cols(const LNBwdArgs& a, int dtype, hipStream_t s);
 hipError_t launch_layernorm_fwd(const LNArgs& a, int dtype, hipStream_t s);
 hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s);
 

@@ -165,7 +165,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
                 }
             }
         }
-        if (a.cols_only) continue;          // column partials only: dx was written by ln_bwd_dx_kernel
         const float c1 = wave_sum(s1) / a.width, c2 = wave_sum(s2) / a.width;
         T* dx = (T*)a.dx + (size_t)row * a.width;
 #pragma unroll
@@ -221,77 +220,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
             if (a.partial) a.partial[((size_t)v * gridDim.x + blockIdx.x) * a.width + c] = sres;   // [nvec][grid][width]
             else atomicAdd(outs[v] + c, sres * (a.alpha == 0.f ? 1.f : a.alpha));
         }
-}
-// The dx half of the LayerNorm backward alone: one wave per row, NO LDS, few registers (the row stays in its packed input form between the two
-// passes; gamma is re-read from the L1).  Why it exists (round 5): the fused kernel above needs 48 KB of LDS and ~220 VGPRs, and in the training step
-// it runs while the grouped weight-gradient GEMM of the layer above holds 216 CUs (144 KB of LDS, 456 of 512 VGPRs per SIMD each): its 512 blocks
-// queued for the 40 CUs that launch leaves -- 39 us in the step against 14 alone, twice per layer, on the critical path.  This kernel fits beside
-// a weight-gradient workgroup; the column sums (dgamma, dbeta) are taken by the fused kernel with LNBwdArgs::cols_only on the side stream.
-// Registers: a SIMD has 56 VGPRs left beside three weight-gradient waves of 152, so nothing of the row is kept between the two passes -- the second
-// pass reads dy and x again (from the L1 / L2: the first pass has just fetched them; HBM sees them once).
-template <typename T>
-__global__ __launch_bounds__(256, 8) void ln_bwd_dx_kernel(LNBwdArgs a) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows) return;
-    const int nch = a.width >> 2;
-    const float mean = a.mean[row], rstd = a.rstd[row];
-    const T* __restrict__ xrow = (const T*)a.x + (size_t)row * a.width;
-    const T* __restrict__ drow = (const T*)a.dy + (size_t)row * a.width;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < MAXC; ++t) {
-        const int c = lane + 64 * t;
-        if (c < nch) {
-            float xv[4], dv[4];
-            load4<T>(xrow + c * 4, xv);
-            load4<T>(drow + c * 4, dv);
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float g = dv[e] * gm[e];
-                s1 += g;
-                s2 += g * ((xv[e] - mean) * rstd);
-            }
-        }
-    }
-    const float c1 = wave_sum(s1) / a.width, c2 = wave_sum(s2) / a.width;
-    const bool dropping = a.dx_drop != nullptr && a.drop.thresh16 != 0;
-    const bool pair = std::is_same<T, float>::value && a.pair_out != nullptr;
-#pragma unroll
-    for (int t = 0; t < MAXC; ++t) {
-        const int c = lane + 64 * t;
-        if (c < nch) {
-            float xv[4], o[4];
-            load4<T>(xrow + c * 4, xv);
-            load4<T>(drow + c * 4, o);
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = rstd * (o[e] * gm[e] - c1 - ((xv[e] - mean) * rstd) * c2);
-            if (a.dres) {
-                load4<T>((const T*)a.dres + (size_t)row * a.width + c * 4, xv);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += xv[e];
-            }
-            store4<T>((T*)a.dx + (size_t)row * a.width + c * 4, o);
-            if (dropping) {
-                const uint32_t e0 = (uint32_t)row * (uint32_t)(a.drop_row_mul ? a.drop_row_mul : 1) * (uint32_t)a.width + (uint32_t)c * 4u;
-                bool k0, k1, k2, k3;
-                mm_keep2(e0, a.drop, k0, k1);
-                mm_keep2(e0 + 2, a.drop, k2, k3);
-                o[0] = k0 ? o[0] * a.drop.keep_scale : 0.f;
-                o[1] = k1 ? o[1] * a.drop.keep_scale : 0.f;
-                o[2] = k2 ? o[2] * a.drop.keep_scale : 0.f;
-                o[3] = k3 ? o[3] * a.drop.keep_scale : 0.f;
-                if (!pair) store4<T>((T*)a.dx_drop + (size_t)row * a.width + c * 4, o);
-            }
-            if (pair) {
-                bf16_t* pp = (bf16_t*)a.pair_out + (size_t)row * a.ld_pair + c * 4;
-                if (a.pair_hi_only) { bf16x4 h; h[0] = (bf16_t)o[0]; h[1] = (bf16_t)o[1]; h[2] = (bf16_t)o[2]; h[3] = (bf16_t)o[3]; *reinterpret_cast<bf16x4*>(pp) = h; }
-                else store4_pair(pp, a.lo_pair, o);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);          // one chunk at a time: the next chunk's loads are not hoisted above this one's stores
-    }
 }
 // out[c] += sum_i partial[i][c]   (i < n).  Block = 64 columns x 4 waves; grid.y splits the partial rows; each wave
 // walks its rows with 4 independent accumulators; the 4 waves combine through LDS and one atomic per column per
@@ -921,28 +849,6 @@ hipError_t launch_layernorm_bwd(const LNBwdArgs& a, int dtype, hipStream_t s) {
     else if (dtype == DT_F16) hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, a);
     if (a.partial && !a.defer_reduce) return launch_layernorm_bwd_reduce(a, s);
-    return hipGetLastError();
-}
-// the two halves of the backward as separate launches (ln_bwd_dx_kernel: why): dx [+ dropped copy / plane pair] here ...
-hipError_t launch_layernorm_bwd_dx(const LNBwdArgs& a, int dtype, hipStream_t s) {
-    if (a.rows <= 0) return hipSuccess;
-    if (a.width % 4 || a.width > 1024 || a.colsum_out) return hipErrorInvalidValue;
-    const int grid = (a.rows + 3) / 4;
-    if (dtype == DT_BF16) hipLaunchKernelGGL(ln_bwd_dx_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(ln_bwd_dx_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(ln_bwd_dx_kernel<float>, dim3(grid), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-// ... and the per-block column partials of dgamma / dbeta here (the caller reduces them: launch_layernorm_bwd_reduce); a.partial is required
-hipError_t launch_layernorm_bwd_cols(const LNBwdArgs& a0, int dtype, hipStream_t s) {
-    if (a0.rows <= 0) return hipSuccess;
-    if (a0.width % 4 || a0.width > 1024 || !a0.partial) return hipErrorInvalidValue;
-    LNBwdArgs a = a0;
-    a.cols_only = 1; a.colsum_out = nullptr;
-    const int grid = (a.rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
-    if (dtype == DT_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 // second stage of the column reductions (dgamma, dbeta[, colsum]); with LNBwdArgs::defer_reduce the caller issues it itself,
