@@ -164,6 +164,22 @@ def bench_early(args):
         tr.train_step(ids, mask, tt, feats, boxes, onehot, None, 1e-5, 0.00025, step)
     host_ms = (time.perf_counter() - th) / 2 * 1e3
     sync()
+    # roofline of the dominant kernel family (NT GEMMs): HIP events around every launch on the stream it goes to (mmhip_early_gemm_timing),
+    # two steps, the engine's three streams on -- the conditions of the timed step
+    import ctypes as Ct
+    from smtc_amd import _lib
+    lib = _lib.lib()
+    gemm = None
+    if world == 1 and hasattr(lib, "mmhip_early_gemm_timing"):
+        _lib.check(lib.mmhip_early_gemm_timing(tr.model._handle, 1, 1, None, None, None))
+        for _ in range(2):
+            step += 1
+            tr.train_step(ids, mask, tt, feats, boxes, onehot, None, 1e-5, 0.00025, step)
+        gms, gl, gf = Ct.c_double(), Ct.c_uint64(), Ct.c_double()
+        _lib.check(lib.mmhip_early_gemm_timing(tr.model._handle, 0, 1, Ct.byref(gms), Ct.byref(gl), Ct.byref(gf)))
+        if gms.value > 0:
+            gemm = {"tflops": gf.value / (gms.value * 1e-3) / 1e12, "ms_per_step": gms.value / 2, "launches_per_step": int(gl.value) // 2,
+                    "flops_per_launch": gf.value / max(1, gl.value)}
     layer = 2.0 * (4 * H * H + 2 * H * I)                       # Linear FLOPs per token of a BERT-shaped layer
     xlayer = 2.0 * (8 * H * H + 2 * H * I)                      # cross-modality layer: cross + self attention blocks, feed-forward
     fwd = (9 * layer + 5 * xlayer) * T + (5 * layer + 5 * xlayer) * NB + 2.0 * NB * (2048 + 4) * H
@@ -198,8 +214,16 @@ def bench_early(args):
                       "implementation": "native engine (csrc/early.hip: one C call per step; language / vision / weight-gradient streams; per-layer AdamW beside the backward; ITM pass batched with the main pass)",
                       "gf_per_post": round(gf_post, 1), "posts_per_gpu": B, "text_tokens": T, "boxes": NB, "parallelism": f"dp{world}", "weights": "random-init at true shapes"},
            "final_loss": round(float(loss), 5), "host_enqueue_ms_per_step": round(host_ms, 3),
-           "roofline": {"bound": "mfma", "kernel": "whole step: algorithmic Linear FLOPs / step time (per-kernel durations: profiles/r04_cfg5_kernel_stats.csv, rocprofv3 of this command)",
-                        "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS, 4), "traffic": None},
+           "roofline": ({"bound": "mfma", "kernel": "NT GEMM family (gemm_nt_kernel 128x128 tiles on 2- / 3-deep LDS rings, MFMA 16x16x32, LDS-DMA staged)",
+                         "achieved": round(gemm["tflops"], 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm["tflops"] / PEAK_TFLOPS, 4),
+                         "conditions": "HIP events around every NT launch on its own stream, the engine's three streams on (as in the timed step): launches of the language, "
+                                       "vision and weight-gradient streams share the chip, so the durations add up to more than the step",
+                         "gemm_ms_per_step": round(gemm["ms_per_step"], 3), "launches_per_step": gemm["launches_per_step"],
+                         "algorithmic_flops_per_launch": round(gemm["flops_per_launch"]), "traffic": None,
+                         "traffic_note": "no PMC pass of this command in profiles/ for these kernel sources",
+                         "whole_step_tflops": round(tf, 1), "whole_step_frac": round(tf / PEAK_TFLOPS, 4)} if gemm else
+                        {"bound": "mfma", "kernel": "whole step: algorithmic Linear FLOPs / step time", "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_TFLOPS, 4), "traffic": None}),
            "cpu_baseline": cpu}
     if world > 1:
         out["multi_gpu"] = "staged exchange: the engine calls back per backward stage, ranges leave as bucketed all-reduces beside the stages below (unmeasured on hardware: the development box has one GPU)"

@@ -401,6 +401,9 @@ int mmhip_early_bind(mmhip_early_handle h, float* params, float* grads, void* wo
 /* 16-bit (parity mode: fp32) operand copies of the weights + transposed copies; call after the parameters changed */
 int mmhip_early_refresh_weights(mmhip_early_handle h, void* stream);
 int mmhip_early_set_index_counter(mmhip_early_handle h, uint32_t* device_word);      /* see mmhip_set_index_counter */
+/* Measurement only, as mmhip_gemm_timing: HIP events around every NT GEMM launch of the following mmhip_early_train_step calls, on the stream each
+ * launch goes to; sums over the launches timed since the last reset (synchronises).  No reference counterpart. */
+int mmhip_early_gemm_timing(mmhip_early_handle h, int enable, int reset, double* ms, uint64_t* launches, double* flops);
 /* Lxmert.forward.  ids / mask / token_type_ids (may be NULL = zeros): int64 [B, T]; feats fp32 [B, Nb, feat_dim]; boxes fp32 [B, Nb, pos_dim];
  * tim_*: the swapped texts of the ITM pass (NULL = no ITM) -- both passes run as ONE encoder pass of 2B posts.  Outputs (may be NULL) fp32:
  * out [B, num_labels], emb_t [B, H] (masked max over tokens, detached), emb_v [B, H] (max over boxes), out_tim [B, 2]. */

@@ -90,6 +90,7 @@ _SIGS = {
     "mmhip_side_stream": (P, [P]),
     "mmhip_set_index_counter": (I, [P, P]),
     "mmhip_early_set_index_counter": (I, [P, P]),
+    "mmhip_early_gemm_timing": (I, [P, I, I, C.POINTER(C.c_double), C.POINTER(U64), C.POINTER(C.c_double)]),
     "mmhip_train_step": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P]),
     "mmhip_train_step_dp": (I, [P, P, P, P, P, P, P, P, P, I, I, U64, I, I, F, F, F, P, P, F, F, F, F, F, I, F, P, P, P, P, P]),
     "mmhip_image_plan_words": (U64, [I, P, P, I]),

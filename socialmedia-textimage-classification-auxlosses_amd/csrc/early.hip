@@ -204,6 +204,8 @@ DropCfg drop_cfg(float p, uint64_t seed, uint32_t stream, bool on) {
 }  // namespace
 
 struct mmhip_early {
+    // mmhip_early_gemm_timing: events around every NT GEMM launch of the handle's steps while enabled
+    std::vector<GemmTimingSink::Ev> timing_evs; GemmTimingSink timing{nullptr, 0, 0}; int timing_on = 0;
     unsigned* bad_index = nullptr;      // caller-owned device word: indices (token ids, token types, ITM source rows) that had to be clamped (mmhip_early_set_index_counter)
     mmhip_early_config cfg;
     std::vector<mmhip_param_info> params;
@@ -877,6 +879,7 @@ int mmhip_early_create(const mmhip_early_config* cfg, mmhip_early_handle* out) {
 }
 void mmhip_early_destroy(mmhip_early_handle h) {
     if (!h) return;
+    for (auto& ev : h->timing_evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->side) {
         (void)hipStreamSynchronize(h->side);
         for (hipEvent_t ev : {h->ev_fork, h->ev_join, h->ev_l, h->ev_v, h->ev_l2, h->ev_v2, h->ev_lw, h->ev_vw, h->ev_w})
@@ -906,6 +909,33 @@ int mmhip_early_bind(mmhip_early_handle h, float* params, float* grads, void* wo
 int mmhip_early_set_index_counter(mmhip_early_handle h, uint32_t* device_word) {
     if (!h || ((uintptr_t)device_word & 3)) return MMHIP_E_INVALID;
     h->bad_index = device_word;
+    return 0;
+}
+// Measurement only (the early-fusion counterpart of mmhip_gemm_timing): enable != 0 arms HIP events around every NT GEMM launch of the following
+// mmhip_early_train_step calls (on the stream each launch goes to); ms / launches / flops (may be NULL) return the sums over the launches timed
+// since the last reset -- synchronises.  Algorithmic FLOPs 2 M N K per launch.
+int mmhip_early_gemm_timing(mmhip_early_handle h, int enable, int reset, double* ms, uint64_t* launches, double* flops) {
+    if (!h) return MMHIP_E_INVALID;
+    mmhip_early& e = *h;
+    if (ms || launches || flops) {
+        double tms = 0, tf = 0;
+        for (size_t i = 0; i < e.timing.used; ++i) {
+            CHECK_HIP(hipEventSynchronize(e.timing_evs[i].b));
+            float t = 0;
+            CHECK_HIP(hipEventElapsedTime(&t, e.timing_evs[i].a, e.timing_evs[i].b));
+            tms += t; tf += e.timing_evs[i].flops;
+        }
+        if (ms) *ms = tms;
+        if (launches) *launches = e.timing.used;
+        if (flops) *flops = tf;
+    }
+    if (reset) e.timing.used = 0;
+    if (enable && e.timing_evs.empty()) {
+        e.timing_evs.resize(2048);
+        for (auto& ev : e.timing_evs) { CHECK_HIP(hipEventCreate(&ev.a)); CHECK_HIP(hipEventCreate(&ev.b)); }
+        e.timing.evs = e.timing_evs.data(); e.timing.capacity = e.timing_evs.size(); e.timing.used = 0;
+    }
+    e.timing_on = enable != 0;
     return 0;
 }
 int mmhip_early_refresh_weights(mmhip_early_handle h, void* stream) {
@@ -1067,6 +1097,8 @@ int mmhip_early_train_step(mmhip_early_handle h, const int64_t* ids, const int64
     if (use_itm && (!itm_src || !lbl_tim)) return MMHIP_E_INVALID;
     mmhip_early& e = *h;
     hipStream_t s = (hipStream_t)stream;
+    struct SinkScope { bool on; explicit SinkScope(GemmTimingSink* k) : on(k != nullptr) { if (on) gemm_timing_sink(k); } ~SinkScope() { if (on) gemm_timing_sink(nullptr); } };
+    SinkScope sink_scope(e.timing_on ? &e.timing : nullptr);
     CHECK_RC(forward_impl(h, ids, mask, token_type_ids, feats, boxes, nullptr, nullptr, nullptr, use_itm ? itm_src : nullptr, B, T, Nb, 1, seed, nullptr, nullptr, nullptr,
                           nullptr, stream));
     CHECK_RC(mmhip_early_loss(h, onehot, class_w, use_itm ? lbl_tim : nullptr, w_cls, use_itc ? w_itc : 0.f, use_itm ? w_itm : 0.f, loss, nullptr, stream));

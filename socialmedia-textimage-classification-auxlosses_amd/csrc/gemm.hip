@@ -739,7 +739,23 @@ static bool debug_force_slow() {
     return v != 0;
 }
 
+static thread_local GemmTimingSink* g_timing_sink = nullptr;
+void gemm_timing_sink(GemmTimingSink* sink) { g_timing_sink = sink; }
+static hipError_t launch_gemm_nt_untimed(const GemmNTArgs& a, int dtype, hipStream_t s);
 hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s) {
+    GemmTimingSink* k = g_timing_sink;
+    if (!k || k->used >= k->capacity || a.M <= 0 || a.N <= 0) return launch_gemm_nt_untimed(a, dtype, s);
+    GemmTimingSink::Ev& ev = k->evs[k->used];
+    ev.flops = 2.0 * a.M * (double)a.N * a.K;
+    hipError_t r = hipEventRecord(ev.a, s);
+    if (r != hipSuccess) return r;
+    r = launch_gemm_nt_untimed(a, dtype, s);
+    if (r != hipSuccess) return r;
+    r = hipEventRecord(ev.b, s);
+    if (r == hipSuccess) k->used++;
+    return r;
+}
+static hipError_t launch_gemm_nt_untimed(const GemmNTArgs& a, int dtype, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if (a.c_rps > 0 && (dtype == DT_F32 || !nt_fast_ok(a) || a.force_slow || debug_force_slow() || a.c_rps_stride < a.c_rps || (a.flags & GEMM_OUT_PAIR)))
         return hipErrorInvalidValue;          // the row remap lives in gemm_nt_kernel's epilogue only

@@ -80,6 +80,13 @@ struct SmallGemmArgs {
     int sam, sak, sbk, sbn;   // element strides of A(m,k) and B(k,n); filled by the launch_small_* wrappers
 };
 hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s);
+// Measurement hook (round 5): while a sink is set on the calling thread, launch_gemm_nt brackets every launch with HIP events recorded on the
+// launch's own stream (the early-fusion engine enqueues its NT GEMMs from composite blocks on three streams: there is no single call site to wrap)
+struct GemmTimingSink {
+    struct Ev { hipEvent_t a, b; double flops; };
+    Ev* evs; size_t capacity, used;
+};
+void gemm_timing_sink(GemmTimingSink* sink);      // nullptr = off
 // deep-pipelined 256 x bn tiles (gemm8.hip); false = shape rules not met, nothing launched
 bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hipStream_t s);
 // two problems of equal N and K in one persistent launch (the two towers' GEMMs of one layer); bn = 0: best-filling tile
