@@ -258,7 +258,7 @@ void gemm_nt_kernel(GemmNTArgs a) {
             }
             if (fl & GEMM_GELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = mm_gelu(v[e]);
+                for (int e = 0; e < 8; e += 2) mm_gelu2(v[e], v[e + 1]);
             }
             if (fl & GEMM_TANH) {
 #pragma unroll
@@ -272,7 +272,7 @@ void gemm_nt_kernel(GemmNTArgs a) {
                 v8 u = pre[ch][p];
                 if (!pre_mul) u = *reinterpret_cast<const v8*>((const T*)a.mul_in + (size_t)m * a.ldmul + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= mm_gelu_grad(to_f<T>(u[e]));
+                for (int e = 0; e < 8; e += 2) { const f32x2_t gg = mm_gelu_grad2(to_f<T>(u[e]), to_f<T>(u[e + 1])); v[e] *= gg[0]; v[e + 1] *= gg[1]; }
             }
             if ((fl & GEMM_DROPOUT) && a.drop.thresh16) {
                 const uint32_t e0 = (uint32_t)m * (uint32_t)(a.drop_row_mul ? a.drop_row_mul : 1) * (uint32_t)a.N + (uint32_t)n;

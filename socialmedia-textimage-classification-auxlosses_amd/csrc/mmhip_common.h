@@ -119,7 +119,61 @@ __device__ __forceinline__ float mm_erf(float x) {
     float r = 1.0f - y * __expf(-ax * ax);
     return copysignf(r, x);
 }
-__device__ __forceinline__ float mm_gelu(float x) { return 0.5f * x * (1.0f + mm_erf(x * 0.70710678118654752f)); }
+// exact (erf) GELU without the division: GELU(x) = max(x, 0) - |x| Phi(-|x|), and the normal tail is smooth in the log domain --
+// Phi(-a) = 2^-(1 + P(a)) with P of degree 8 on [0, 5.5] (beyond it |x| Phi(-|x|) < 1.1e-7).  |error| <= 4.8e-7 absolute over all x
+// (tools/gelu_fit.py: fit and check against erfc in double), the fp32 floor of the form; one v_exp_f32 and ten plain VALU operations per value
+// instead of v_rcp_f32 + v_exp_f32 + fifteen (the Abramowitz-Stegun erf above): in the FC1 epilogue of the encoder GEMMs the activation was
+// a fifth of the launch (profiles/r05_gemm_epilogue_cost.txt).
+__device__ __forceinline__ float mm_gelu(float x) {
+    const float a = __builtin_amdgcn_fmed3f(fabsf(x), 0.f, 5.5f);          // one v_med3_f32 (fminf / fmaxf also quiet their operands: two instructions each)
+    float p = 9.896420750e-08f;
+    p = fmaf(p, a, -2.559779944e-07f);
+    p = fmaf(p, a, -4.382965926e-05f);
+    p = fmaf(p, a, 8.528624312e-04f);
+    p = fmaf(p, a, -8.322801441e-03f);
+    p = fmaf(p, a, 5.372542515e-02f);
+    p = fmaf(p, a, 4.586065114e-01f);
+    p = fmaf(p, a, 1.151219487e+00f);
+    p = fmaf(p, a, 9.999963641e-01f);
+    return __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f) - a * __builtin_amdgcn_exp2f(-p);
+}
+// two values at a time: the polynomial as v_pk_fma_f32 (hipcc does not pack the scalar form -- its constants are 32-bit literals of v_fmaak_f32)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mm_gelu2(float& x0, float& x1) {
+    const f32x2_t a = {__builtin_amdgcn_fmed3f(fabsf(x0), 0.f, 5.5f), __builtin_amdgcn_fmed3f(fabsf(x1), 0.f, 5.5f)};
+    f32x2_t p = {9.896420750e-08f, 9.896420750e-08f};
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){-2.559779944e-07f, -2.559779944e-07f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){-4.382965926e-05f, -4.382965926e-05f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){8.528624312e-04f, 8.528624312e-04f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){-8.322801441e-03f, -8.322801441e-03f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){5.372542515e-02f, 5.372542515e-02f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){4.586065114e-01f, 4.586065114e-01f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){1.151219487e+00f, 1.151219487e+00f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){9.999963641e-01f, 9.999963641e-01f});
+    const f32x2_t t = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};
+    const f32x2_t r = {__builtin_amdgcn_fmed3f(x0, 0.f, 3.0e38f), __builtin_amdgcn_fmed3f(x1, 0.f, 3.0e38f)};
+    const f32x2_t o = __builtin_elementwise_fma(-a, t, r);
+    x0 = o[0];
+    x1 = o[1];
+}
+// gelu'(x) = Phi(x) + x phi(x) from the same tail polynomial: r = Phi(-a) - a phi(a), gelu' = 1 - r for x >= 0, r below; |error| <= 1.3e-6
+__device__ __forceinline__ f32x2_t mm_gelu_grad2(float x0, float x1) {
+    const f32x2_t a = {__builtin_amdgcn_fmed3f(fabsf(x0), 0.f, 5.5f), __builtin_amdgcn_fmed3f(fabsf(x1), 0.f, 5.5f)};
+    f32x2_t p = {9.896420750e-08f, 9.896420750e-08f};
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){-2.559779944e-07f, -2.559779944e-07f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){-4.382965926e-05f, -4.382965926e-05f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){8.528624312e-04f, 8.528624312e-04f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){-8.322801441e-03f, -8.322801441e-03f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){5.372542515e-02f, 5.372542515e-02f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){4.586065114e-01f, 4.586065114e-01f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){1.151219487e+00f, 1.151219487e+00f});
+    p = __builtin_elementwise_fma(p, a, (f32x2_t){9.999963641e-01f, 9.999963641e-01f});
+    const f32x2_t e = __builtin_elementwise_fma(a * a, (f32x2_t){-0.72134752044f, -0.72134752044f}, (f32x2_t){-1.32574806473f, -1.32574806473f});   // log2 phi(a)
+    const f32x2_t T = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};
+    const f32x2_t ph = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+    const f32x2_t h = (f32x2_t){0.5f, 0.5f} - __builtin_elementwise_fma(-a, ph, T);
+    return (f32x2_t){0.5f + copysignf(h[0], x0), 0.5f + copysignf(h[1], x1)};
+}
 __device__ __forceinline__ float mm_qgelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float mm_gelu_grad(float x) {
     // cdf(x) + x pdf(x).  erf(x / sqrt2) = 1 - poly(t) exp(-x^2 / 2) and pdf(x) = exp(-x^2 / 2) / sqrt(2 pi) share ONE exponential

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmNTArgs a) {
             if (fl & GEMM_AUX_PRE) *reinterpret_cast<f32x4*>((float*)a.aux + (size_t)m * a.ldaux + n) = f32x4{v[0], v[1], v[2], v[3]};
             if (fl & GEMM_GELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = mm_gelu(v[e]);
+                for (int e = 0; e < 4; e += 2) mm_gelu2(v[e], v[e + 1]);
             }
             if (fl & GEMM_TANH) {
 #pragma unroll
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmNTArgs a) {
             if (fl & GEMM_MUL_GELU_GRAD) {
                 const f32x4 u = *reinterpret_cast<const f32x4*>((const float*)a.mul_in + (size_t)m * a.ldmul + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= mm_gelu_grad(u[e]);
+                for (int e = 0; e < 4; e += 2) { const f32x2_t gg = mm_gelu_grad2(u[e], u[e + 1]); v[e] *= gg[0]; v[e + 1] *= gg[1]; }
             }
             if ((fl & GEMM_DROPOUT) && a.drop.thresh16) {
                 const uint32_t e0 = (uint32_t)m * (uint32_t)(a.drop_row_mul ? a.drop_row_mul : 1) * (uint32_t)a.N + (uint32_t)n;

@@ -118,6 +118,46 @@ def test_gemm_nt_epilogues(dt, M, N, K, slow):
             assert (z == ~keep).float().mean() > 0.99      # kept values below half an output ulp of the residual also read as "dropped"
 
 
+@pytest.mark.parametrize("dt,slow", [("bf16", 0), ("bf16", 16), ("bf16", 224), ("f16", 256), ("x3", 0)])
+def test_gelu_epilogue_is_the_erf_gelu(dt, slow):
+    """the activation of the FC1 epilogue alone: with B = I the accumulator IS the (16-bit exact) input, so the fp32 output is mm_gelu(x) --
+    checked against x Phi(x) in double over [-9, 9].  mm_gelu is the division-free tail form (csrc/mmhip_common.h; tools/gelu_fit.py):
+    |error| <= 4.8e-7 by construction; the bound below adds fp32 rounding of the result."""
+    code, tdt = DT[dt]
+    M, N = 512, 128
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = ((torch.rand(M, N, generator=g) * 18 - 9).to(torch.bfloat16 if dt == "x3" else tdt)).to(tdt)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1e-4, -1e-4, 5.5, -5.5, 30.0, -30.0]).to(tdt)
+    A, B = x.to(dev()), torch.eye(N, dtype=tdt, device=dev())
+    C_ = torch.zeros(M, N, dtype=torch.float32, device=dev())
+    call("mmhip_op_gemm_nt", code, ptr(A), N, ptr(B), N, ptr(C_), N, M, N, N, None, 1, None, 0, None, 0, 0.0, 0, 0, None, 0, 0 if dt == "x3" else 1, slow, stream())
+    torch.cuda.synchronize()
+    xd = x.double()
+    ref = xd * 0.5 * torch.erfc(-xd / math.sqrt(2.0))
+    err = (C_.double().cpu() - ref).abs()
+    assert (err <= 6e-7 + 1.2e-7 * ref.abs()).all(), err.max().item()
+
+
+@pytest.mark.parametrize("dt,slow", [("bf16", 0), ("bf16", 16), ("bf16", 224), ("f16", 256), ("x3", 0)])
+def test_gelu_grad_epilogue_is_the_erf_gelu_derivative(dt, slow):
+    """the dFC2 epilogue alone: B = I and A = 1 make the fp32 output mm_gelu_grad2(u) -- against Phi(u) + u phi(u) in double over [-9, 9]
+    (|error| <= 1.3e-6 by construction, csrc/mmhip_common.h)"""
+    code, tdt = DT[dt]
+    M, N = 512, 128
+    g = torch.Generator(device="cpu").manual_seed(6)
+    u = ((torch.rand(M, N, generator=g) * 18 - 9).to(torch.bfloat16 if dt == "x3" else tdt)).to(tdt)
+    u[0, :8] = torch.tensor([0.0, -0.0, 1e-4, -1e-4, 5.5, -5.5, 30.0, -30.0]).to(tdt)
+    B, U = torch.eye(N, dtype=tdt, device=dev()), u.to(dev())
+    A = torch.ones(M, N, dtype=tdt, device=dev())          # A . I^T: the accumulator is exactly 1 everywhere
+    C_ = torch.zeros(M, N, dtype=torch.float32, device=dev())
+    call("mmhip_op_gemm_nt", code, ptr(A), N, ptr(B), N, ptr(C_), N, M, N, N, None, 0, None, 0, ptr(U), N, 0.0, 0, 0, None, 0, 0 if dt == "x3" else 1, slow, stream())
+    torch.cuda.synchronize()
+    ud = u.double()
+    ref = 0.5 * torch.erfc(-ud / math.sqrt(2.0)) + ud * torch.exp(-ud * ud / 2) / math.sqrt(2 * math.pi)
+    err = (C_.double().cpu() - ref).abs()
+    assert err.max().item() <= 2e-6, err.max().item()
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,Nn,Nc,slow", [(64, 128, 128, 0), (256, 256, 384, 0), (8192, 768, 768, 0), (1024, 2304, 768, 0),
                                           (96, 40, 72, 1), (64, 128, 128, 16), (256, 256, 384, 16),])

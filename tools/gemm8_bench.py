@@ -48,6 +48,10 @@ def main():
                 continue
             if epi == "gelu":
                 fns.append(lambda tile=tile: lib.mmhip_op_gemm_nt(0, p(A), K, p(B), K, p(Cm), N, M, N, K, p(bias), 1, p(aux), N, None, 0, 0.0, 0, 0, None, 0, 0, tile << 4, st()))
+            elif epi == "gelunoaux":
+                fns.append(lambda tile=tile: lib.mmhip_op_gemm_nt(0, p(A), K, p(B), K, p(Cm), N, M, N, K, p(bias), 1, None, 0, None, 0, 0.0, 0, 0, None, 0, 0, tile << 4, st()))
+            elif epi == "gelugrad":
+                fns.append(lambda tile=tile: lib.mmhip_op_gemm_nt(0, p(A), K, p(B), K, p(Cm), N, M, N, K, None, 0, None, 0, p(aux), N, 0.0, 0, 0, None, 0, 0, tile << 4, st()))
             elif epi == "resid":
                 fns.append(lambda tile=tile: lib.mmhip_op_gemm_nt(0, p(A), K, p(B), K, p(Cm), N, M, N, K, p(bias), 0, None, 0, None, 0, 0.1, 5, 7, p(resid), N, 0, tile << 4, st()))
             else:
