@@ -664,7 +664,7 @@ static int tile_map_lookup(const GemmNTArgs& a) {
 }
 // tile choice: explicit (a.tile / MMHIP_NT_TILE / MMHIP_TILE_MAP) or measured rules.  Tiles: 1 = 128x128 (two blocks per CU), 6 = 128x192,
 // 9 = role-specialised 256x128, 10 = 128x96, 12 = role-specialised 256x96, 20 / 21 = 128x128 on a 4- / 3-deep ring (gemm.hip); 13-18 = the deep-pipelined kernel of gemm8.hip
-// (13 / 15 = 256x256 one-shot / persistent, 14 / 16 = 256x128, 17 / 18 = 256x192); 22 = 256x128 tiles by four-wave workgroups, two per CU (gemm8.hip)
+// (13 / 15 = 256x256 one-shot / persistent, 14 / 16 = 256x128, 17 / 18 = 256x192)
 static int choose_nt_tile(const GemmNTArgs& a) {
     { const int m = tile_map_lookup(a); if (m) return m; }
     static int env = -1;
@@ -675,9 +675,8 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     if ((t == 17 || t == 18 || t == 6) && a.N % 192) t = 0;
     if ((t == 14 || t == 16 || t == 1 || t == 9) && a.N % 128) t = 0;
     if ((t == 10 || t == 12) && a.N % 96) t = 0;
-    if ((t == 20 || t == 21 || t == 22) && a.N % 128) t = 0;
-    if (a.c_rps && t == 22) t = 0;
-    if (t == 1 || t == 6 || t == 9 || t == 10 || t == 12 || (t >= 13 && t <= 18) || t == 20 || t == 21 || t == 22) return t;
+    if ((t == 20 || t == 21) && a.N % 128) t = 0;
+    if (t == 1 || t == 6 || t == 9 || t == 10 || t == 12 || (t >= 13 && t <= 18) || t == 20 || t == 21) return t;
     // Rules measured inside the training step (same-box A/B of bench.py, profiles/r02_step_ab*.txt, r03_*): the image-tower-sized GEMMs
     // (M >= 12000 rows) take the deep-pipelined persistent tile that fills the rounds of 256 workgroups best; the 8192-row text GEMMs
     // outside the forward's CU partition (i.e. the backward's) keep 128 x 128 at two blocks per CU, and the long-K 768-wide ones the
@@ -722,11 +721,7 @@ static void launch_nt_d(const GemmNTArgs& a, hipStream_t s) {
         const int bn = tile >= 17 ? 192 : ((tile == 13 || tile == 15) ? 256 : 128);
         if (launch_gemm_nt8(a, dt, bn, tile == 15 || tile == 16 || tile == 18, s)) return;
     }
-    if (tile == 22) {      // two workgroups per CU, 256 x 128 tiles, one tile per workgroup (gemm8.hip: gemm_nt4_kernel)
-        const int dt = sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16;
-        if (launch_gemm_nt4(a, dt, s)) return;
-    }
-    switch (((tile >= 13 && tile <= 18) || tile == 22) ? 1 : tile) {
+    switch ((tile >= 13 && tile <= 18) ? 1 : tile) {
         case 20: launch_nt_t<T, 128, 128, 2, 2, 4>(a, s); break;      // 128 x 128 on a 4-deep LDS ring (one block per CU): grids of <= 256 tiles, where
                                                                       // nothing else on the CU hides the load latency of the 2-stage variant
         case 21: launch_nt_t<T, 128, 128, 2, 2, 3>(a, s); break;      // ... 3-deep

@@ -641,175 +641,9 @@ static int nt8_class(int f) {
     if (!(f & ~(GEMM_BIAS | GEMM_DROPOUT | GEMM_RESIDUAL))) return EP_PLAIN;
     return EP_ANY;
 }
-// ---------------------------------------------------------------------------------------------------------------------------
-// Two workgroups per CU (round 5).  gemm_nt8_kernel owns its CU: all eight waves reach the epilogue together, the matrix cores idle
-// while 128 KB of results drain, and with every CU of a persistent launch in the same phase the chip alternates between a K-loop
-// phase that leaves HBM idle and a 32 MB store burst (profiles/r05_gemm_epilogue_cost.txt: the stores are 7-14 us of an 80 us
-// launch, the GELU arithmetic of FC1 15-20 us, a late start of half the workgroups costs what it gains).  Here a workgroup is FOUR
-// waves on a 256 x 128 tile (each wave the same 64 x 128 sub-tile as in the 256 x 256 kernel, so the register epilogue is shared),
-// 72 KB of LDS, two workgroups per CU, one tile per workgroup (no persistence: the dispatcher hands a CU its next tile when one
-// finishes, and the two residents drift apart by themselves -- while one stores, the other multiplies at the full rate of the CU).
-//   * BK = 32: a stage is 24 KB (A 256 rows x 64 B, B 128 rows x 64 B), three stages.  A stage is 24 fragment images of 1 KB: lane
-//     L of a piece holds row (L & 15), k-chunk (L >> 4) of a 16-row fragment, i.e. exactly what lane L of the ds_read_b128 wants --
-//     the read is linear (lane x 16 B: conflict-free by construction) and the swizzle lives in the LDS-DMA's per-lane source address.
-//   * one barrier per stage (32 MFMAs per wave), placed before the stage's last quarter: [wait: next stage landed] [barrier]
-//     [last 8 MFMAs + the next stage's first fragments + LDS-DMA of stage s+3 into the buffer just released].
-//   * RAW: counted vmcnt (the wave's own pieces of stage s+1) -> barrier -> read.  WAR: a buffer's last reads (B fragments of
-//     quarter 3, requested in quarter 2) are back (lgkmcnt 0) before the barrier behind which it is restaged.
-template <typename T, int EPI, typename ET = T>
-__global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmNTArgs a, int gw) {
-    constexpr int STG = 24 * 1024, BOFF = 16 * 1024;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename Vec<T>::v8 v8;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tilesN = a.N / 128, tilesM = (a.M + 255) / 256;
-    int m0, n0;
-    {
-        const int id = xcd_remap(blockIdx.x, gridDim.x);
-        const int GW = gw > 0 ? gw : 8, per_group = tilesM * GW;
-        const int cg = id / per_group, rem = id - cg * per_group, g = min(GW, tilesN - cg * GW);
-        m0 = (rem / g) * 256;
-        n0 = (cg * GW + rem % g) * 128;
-    }
-#ifdef MMHIP_DIAG_FULLLINE
-    const int nst = a.K >> 6;          // (WRONG results: every piece fetches 8 rows x 128 B -- whole cache lines -- instead of 16 rows x 64 B; half the stages)
-#else
-    const int nst = a.K >> 5;
-#endif
-    const int l15 = lane & 15, kc = lane >> 4;
-    // LDS-DMA sources: this wave stages its own four A fragments and B fragments 2w, 2w+1 (fragment j = 2p + h: columns 32p .. 32p+31, half h,
-    // rows permuted as in gemm_nt8_kernel so that a lane ends up with 8 consecutive output columns)
-    unsigned voA[4], voB[2];
-#pragma unroll
-#ifdef MMHIP_DIAG_FULLLINE
-    for (int i = 0; i < 4; ++i) voA[i] = ((unsigned)min(m0 + w * 64 + i * 16 + (lane >> 3), a.M - 1) * (unsigned)a.lda + (unsigned)((lane & 7) * 8)) * 2u;
-#else
-    for (int i = 0; i < 4; ++i) voA[i] = ((unsigned)min(m0 + w * 64 + i * 16 + l15, a.M - 1) * (unsigned)a.lda + (unsigned)(kc * 8)) * 2u;
-#endif
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int j = 2 * w + q, row = n0 + 32 * (j >> 1) + 8 * (l15 >> 2) + 4 * (j & 1) + (lane & 3);
-        voB[q] = ((unsigned)row * (unsigned)a.ldb + (unsigned)(kc * 8)) * 2u;
-#ifdef MMHIP_DIAG_FULLLINE
-        voB[q] = ((unsigned)(n0 + 16 * j + (lane >> 3)) * (unsigned)a.ldb + (unsigned)((lane & 7) * 8)) * 2u;
-#endif
-    }
-    const char* gA = (const char*)a.A;
-    const char* gB = (const char*)a.B;
-    auto issue = [&](int boff) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(MM_GLB(gA + voA[i]), MM_LDS(smem + boff + (w * 4 + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) __builtin_amdgcn_global_load_lds(MM_GLB(gB + voB[q]), MM_LDS(smem + boff + BOFF + (2 * w + q) * 1024), 16, 0, 0);
-#ifdef MMHIP_DIAG_FULLLINE
-        gA += 128;
-        gB += 128;
-#else
-        gA += 64;
-        gB += 64;
-#endif
-    };
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto lgkm0 = [&]() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };
-    const int lofs = lane * 16;
-    v8 af[4], bf[2][2];
-    auto read_a = [&](int i, int boff) { af[i] = lds_read8<T>(smem, boff + (w * 4 + i) * 1024 + lofs); };
-    auto read_b = [&](auto set_, int boff, int p) {
-        constexpr int set = decltype(set_)::value;
-        bf[set][0] = lds_read8<T>(smem, boff + BOFF + (2 * p) * 1024 + lofs);
-        bf[set][1] = lds_read8<T>(smem, boff + BOFF + (2 * p + 1) * 1024 + lofs);
-    };
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
-    auto quarter = [&](auto set_, auto p_) {
-        constexpr int set = decltype(set_)::value, p = decltype(p_)::value;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) acc[i][2 * p + h] = mfma16(bf[set][h], af[i], acc[i][2 * p + h]);
-    };
-    // prologue: stages 0, 1, 2
-    issue(0);
-    issue(STG);
-    issue(2 * STG);
-    wait_vm<12>();
-    raw_barrier();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) read_a(i, 0);
-    read_b(I0{}, 0, 0);
-    lgkm0();
-    int cb = 0;
-    for (int s = 0; s < nst; ++s) {
-        const int nb = cb == 2 * STG ? 0 : cb + STG;
-        read_b(I1{}, cb, 1);
-        quarter(I0{}, std::integral_constant<int, 0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        lgkm0();
-        read_b(I0{}, cb, 2);
-        quarter(I1{}, std::integral_constant<int, 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        lgkm0();
-        read_b(I1{}, cb, 3);
-        quarter(I0{}, std::integral_constant<int, 2>{});
-        __builtin_amdgcn_sched_barrier(0);
-        lgkm0();                                   // every read of buffer cb is back
-        if (s + 2 < nst) wait_vm<6>(); else wait_vm<0>();          // this wave's pieces of stage s+1 have landed (behind them: stage s+2's six)
-        raw_barrier();
-        if (s + 1 < nst) {
-            read_b(I0{}, nb, 0);
-            if (s + 3 < nst) issue(cb);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) acc[i][6 + h] = mfma16(bf[1][h], af[i], acc[i][6 + h]);
-                read_a(i, nb);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            lgkm0();
-        } else {
-            quarter(I1{}, std::integral_constant<int, 3>{});
-        }
-        cb = nb;
-    }
-    tile_epilogue8<ET, 8, 128, EPI, 4, false>(a, acc, m0, n0, w, 0, l15, kc);
-}
-
-static bool nt4_ok(const GemmNTArgs& a) {
-    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    if (a.a_pair || a.b_pair || (a.flags & GEMM_OUT_PAIR) || a.c_rps) return false;
-    return a.N % 128 == 0 && a.K % 32 == 0 && a.K >= 96 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && al(a.A) && al(a.B) && al(a.C) &&
-           (!(a.flags & GEMM_RESIDUAL) || (a.ldres % 8 == 0 && al(a.residual))) && (!(a.flags & GEMM_AUX_PRE) || (a.ldaux % 8 == 0 && al(a.aux))) &&
-           (!(a.flags & GEMM_MUL_GELU_GRAD) || (a.ldmul % 8 == 0 && al(a.mul_in))) && (!(a.flags & GEMM_BIAS) || al(a.bias)) && a.M > 0 &&
-           (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldb * 2 < (1ull << 32);
-}
-template <typename T, int EPI>
-static void launch_nt4_e(const GemmNTArgs& a, hipStream_t s) {
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt4_kernel<T, EPI, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); done = true; }
-    const int tn = a.N / 128, ng = (tn + 7) / 8, ntiles = ((a.M + 255) / 256) * tn;
-    hipLaunchKernelGGL((gemm_nt4_kernel<T, EPI, T>), dim3(ntiles), dim3(256), 72 * 1024, s, a, (tn + ng - 1) / ng);
-}
-template <typename T>
-static void launch_nt4_t(const GemmNTArgs& a, hipStream_t s) {
-    const int c = nt8_class(a.flags);
-    if (c == EP_GELU) launch_nt4_e<T, EP_GELU>(a, s);
-    else if (c == EP_MULG) launch_nt4_e<T, EP_MULG>(a, s);
-    else if (c == EP_PLAIN) launch_nt4_e<T, EP_PLAIN>(a, s);
-    else launch_nt4_e<T, EP_ANY>(a, s);
-}
-// 16-bit operands only.  false = the shape rules do not hold (caller falls back)
-bool launch_gemm_nt4(const GemmNTArgs& a, int dtype, hipStream_t s) {
-    if ((dtype != DT_BF16 && dtype != DT_F16) || !nt4_ok(a)) return false;
-    if (dtype == DT_BF16) launch_nt4_t<bf16_t>(a, s);
-    else launch_nt4_t<f16_t>(a, s);
-    return true;
-}
-
+// (Round 5 built the variant the round-4 review asked for -- four-wave workgroups on 256 x 128 tiles, two per CU, so that one tile's epilogue overlaps
+// the other's K loop -- and measured it 25-45 % behind this kernel: profiles/r05_two_wg_gemm.txt.  The overlap worked; the feed did not: 1.5 x the operand
+// bytes per MFMA through the 64 B/clk L1 path of the CU, and no room in 160 KB for two BK = 64 rings.  Removed; the history has gemm_nt4_kernel.)
 template <typename T, int BN, typename ET = T, int SEG = 0>
 static void launch_nt8_t(const GemmNTPair& g, int persistent, hipStream_t s) {
     int c = nt8_class(g.p[0].flags);

@@ -89,7 +89,6 @@ struct GemmTimingSink {
 void gemm_timing_sink(GemmTimingSink* sink);      // nullptr = off
 // deep-pipelined 256 x bn tiles (gemm8.hip); false = shape rules not met, nothing launched
 bool launch_gemm_nt8(const GemmNTArgs& a, int dtype, int bn, int persistent, hipStream_t s);
-bool launch_gemm_nt4(const GemmNTArgs& a, int dtype, hipStream_t s);          // two workgroups per CU, 256 x 128 tiles (gemm8.hip)
 // two problems of equal N and K in one persistent launch (the two towers' GEMMs of one layer); bn = 0: best-filling tile
 // split-K finish: C = epilogue(sum over `slices` partial products in a.splitk_ws), same flags as the fused epilogue
 hipError_t launch_splitk_finish(const GemmNTArgs& a, int dtype, int slices, hipStream_t s);

@@ -16,7 +16,7 @@ dev = torch.device("cuda:0")
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 
-VARIANTS = [("r1 auto", 0), ("128x128", 1), ("role 256x128", 9), ("role 256x96", 12), ("dp 256x256", 13), ("dp 256x256 P", 15), ("dp 256x128 P", 16), ("dp 256x192 P", 18), ("2wg 256x128", 22)]
+VARIANTS = [("r1 auto", 0), ("128x128", 1), ("role 256x128", 9), ("role 256x96", 12), ("dp 256x256", 13), ("dp 256x256 P", 15), ("dp 256x128 P", 16), ("dp 256x192 P", 18)]
 if os.environ.get("VARIANTS"):
     VARIANTS = [v for v in VARIANTS if str(v[1]) in os.environ["VARIANTS"].split(",")]
 
