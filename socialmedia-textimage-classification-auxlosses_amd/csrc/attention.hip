@@ -70,11 +70,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int head = blockIdx.x, post = blockIdx.y;
     const int S = a.S;
-    const int Sq = a.Sq_live > 0 ? a.Sq_live : S, Sk = a.Sk_live > 0 ? a.Sk_live : S;      // live rows of the post's S-row block (cross attention)
-    const T* base = (const T*)a.qkv + (size_t)post * S * a.ld_qkv + head * HD;
-    stage_image<T>(Kimg, base + a.hidden, a.ld_qkv, Sk, SP, false, tid, NW * 64);
-    stage_image<T>(Vimg, base + 2 * a.hidden, a.ld_qkv, Sk, SP, true, tid, NW * 64);
-    for (int k = tid; k < SP; k += NW * 64) {
+    const int Sq = a.Sq_live > 0 ? a.Sq_live : S, Sk = a.Sk_live > 0 ? a.Sk_live : S;      // the post's queries and keys (cross attention: Sq != Sk)
+    const int qr = a.q_rps > 0 ? a.q_rps : S, kr = a.kv_rps > 0 ? a.kv_rps : S, cr = a.ctx_rps > 0 ? a.ctx_rps : S;      // rows per post of Q | K, V | ctx
+    const T* base = (const T*)a.qkv + (size_t)post * qr * a.ld_qkv + head * HD;                  // the post's query rows
+    const T* kvb = (const T*)a.qkv + (size_t)post * kr * a.ld_qkv + a.hidden + head * HD;        // ... its key rows (values a.hidden columns on)
+    const int nkt = min(NKT, (Sk + 31) / 32);          // key tiles that hold a key: the others are neither staged nor multiplied
+    stage_image<T>(Kimg, kvb, a.ld_qkv, Sk, nkt * 32, false, tid, NW * 64);
+    stage_image<T>(Vimg, kvb + a.hidden, a.ld_qkv, Sk, nkt * 32, true, tid, NW * 64);
+    for (int k = tid; k < nkt * 32; k += NW * 64) {
         float b = (k < Sk) ? (a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f) : -INFINITY;
         mb[k] = b * LOG2E;
     }
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(AttnArgs a) {
         float m_run = -INFINITY, l_run = 0.f;
         f32x16 oacc[2] = {f32x16{}, f32x16{}};
 #pragma unroll 1
-        for (int kt = 0; kt < NKT; ++kt) {
+        for (int kt = 0; kt < nkt; ++kt) {
             // S^T tile: acc[reg] = score(key = kt*32 + (reg&3) + 8*(reg>>2) + 4*h2, query q)
             f32x16 acc = f32x16{};
 #pragma unroll
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(AttnArgs a) {
         const float inv = 1.0f / l_run;
         // oacc[dt][reg] = O(query q, d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h2), still to be divided by the soft-max sum
         if (q < Sq) {
-            T* op = (T*)a.ctx + ((size_t)post * S + q) * a.ld_ctx + head * HD;
+            T* op = (T*)a.ctx + ((size_t)post * cr + q) * a.ld_ctx + head * HD;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -195,13 +198,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int head = blockIdx.x, post = blockIdx.y;
     const int S = a.S;
-    const int Sq = a.Sq_live > 0 ? a.Sq_live : S, Sk = a.Sk_live > 0 ? a.Sk_live : S;      // live rows of the post's S-row block (cross attention)
-    const size_t row0 = (size_t)post * S;
-    const T* qb = (const T*)a.qkv + row0 * a.ld_qkv + head * HD;
-    const T* kb = qb + a.hidden;
-    const T* vb = qb + 2 * a.hidden;
-    const T* dob = (const T*)a.dctx + row0 * a.ld_ctx + head * HD;
-    const T* ob = (const T*)a.ctx + row0 * a.ld_ctx + head * HD;
+    const int Sq = a.Sq_live > 0 ? a.Sq_live : S, Sk = a.Sk_live > 0 ? a.Sk_live : S;      // the post's queries and keys (cross attention: Sq != Sk)
+    const size_t qrow0 = (size_t)post * (a.q_rps > 0 ? a.q_rps : S), krow0 = (size_t)post * (a.kv_rps > 0 ? a.kv_rps : S), crow0 = (size_t)post * (a.ctx_rps > 0 ? a.ctx_rps : S);
+    const int nkt = min(NKT, (Sk + 31) / 32);          // key tiles that hold a key
+    const T* qb = (const T*)a.qkv + qrow0 * a.ld_qkv + head * HD;
+    const T* kb = (const T*)a.qkv + krow0 * a.ld_qkv + a.hidden + head * HD;
+    const T* vb = kb + a.hidden;
+    const T* dob = (const T*)a.dctx + crow0 * a.ld_ctx + head * HD;
+    const T* ob = (const T*)a.ctx + crow0 * a.ld_ctx + head * HD;
     stage_image<T>(Qtr, qb, a.ld_qkv, Sq, SP, true, tid, 256);
     stage_image<T>(dOtr, dob, a.ld_ctx, Sq, SP, true, tid, 256);
     stage_image<T>(Ktr, kb, a.ld_qkv, Sk, SP, true, tid, 256);
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
         lse2[q] = l;
     }
     const int r = lane & 31, h2 = lane >> 5;
-    const bool has_keys = w < NKT;              // wave w owns keys 32w .. 32w+31
+    const bool has_keys = w < nkt;              // wave w owns keys 32w .. 32w+31 (a wave without a live key only takes part in the dQ products)
     const int key = w * 32 + r;
     const int krow = min(key, Sk - 1);
     v8 kf[4], vf[4];
@@ -310,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
                 f32x16 dq = f32x16{};
 #pragma unroll
                 for (int ks = 0; ks < SP / 16; ++ks) {
+                    if (ks >= nkt * 2) break;          // columns of dS past the last live key tile were never written
                     v8 dsf = lds_read8<T>(dSimg, ds_off(qi * 32 + r, 2 * ks + h2, SPC));
                     v8 ktf = tr_frag_natural<T>(Ktr, ks * 16, dt * 32, lane);
                     dq = mfma32(ktf, dsf, dq);          // dQ^T = K^T . dS^T: the same two fragments with the roles swapped, so the lane owns a query row
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
                 // dq[reg] = dQ(query qt*32 + r, d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h2): four consecutive d per register quad -> 8-byte stores
                 const int q = qt * 32 + r;
                 if (q < Sq) {
-                    T* dqp = (T*)a.dqkv + (row0 + q) * a.ld_qkv + head * HD + dt * 32 + 4 * h2;
+                    T* dqp = (T*)a.dqkv + (qrow0 + q) * a.ld_qkv + head * HD + dt * 32 + 4 * h2;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         v4 o;
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs a) {
     }
     if (has_keys && key < Sk) {
         // dk[dt][reg] = dK(key, d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h2)
-        T* dkp = (T*)a.dqkv + (row0 + key) * a.ld_qkv + a.hidden + head * HD;
+        T* dkp = (T*)a.dqkv + (krow0 + key) * a.ld_qkv + a.hidden + head * HD;
         T* dvp = dkp + a.hidden;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -434,21 +439,25 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int head = blockIdx.x, post = blockIdx.y;
     const int S = a.S;
-    const E* base = (const E*)a.qkv + (size_t)post * S * a.ld_qkv + head * HD;
-    IO::stage(Kh, Kl, base + a.hidden, a.ld_qkv, a.lo_qkv, S, SP, false, tid, NW * 64);
-    IO::stage(Vh, Vl, base + 2 * a.hidden, a.ld_qkv, a.lo_qkv, S, SP, true, tid, NW * 64);
-    for (int k = tid; k < SP; k += NW * 64) {
-        float b = (k < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f) : -INFINITY;
+    const int Sq = a.Sq_live > 0 ? a.Sq_live : S, Sk = a.Sk_live > 0 ? a.Sk_live : S;      // as in attn_fwd_kernel: queries / keys of a post, rows per post, live key tiles
+    const int qr = a.q_rps > 0 ? a.q_rps : S, kr = a.kv_rps > 0 ? a.kv_rps : S, cr = a.ctx_rps > 0 ? a.ctx_rps : S;
+    const E* base = (const E*)a.qkv + (size_t)post * qr * a.ld_qkv + head * HD;
+    const E* kvb = (const E*)a.qkv + (size_t)post * kr * a.ld_qkv + a.hidden + head * HD;
+    const int nkt = min(NKT, (Sk + 31) / 32);
+    IO::stage(Kh, Kl, kvb, a.ld_qkv, a.lo_qkv, Sk, nkt * 32, false, tid, NW * 64);
+    IO::stage(Vh, Vl, kvb + a.hidden, a.ld_qkv, a.lo_qkv, Sk, nkt * 32, true, tid, NW * 64);
+    for (int k = tid; k < nkt * 32; k += NW * 64) {
+        float b = (k < Sk) ? (a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f) : -INFINITY;
         mb[k] = b * LOG2E;
     }
     __syncthreads();
     const int r = lane & 31, h2 = lane >> 5;
     const float sc = a.scale * LOG2E;
-    const int nqt = a.q_tiles > 0 ? min((S + 31) / 32, a.q_tiles) : (S + 31) / 32;
+    const int nqt = a.q_tiles > 0 ? min((Sq + 31) / 32, a.q_tiles) : (Sq + 31) / 32;
     const bool dropping = a.drop.thresh16 != 0;
     for (int qt = w; qt < nqt; qt += NW) {
         const int q = qt * 32 + r;
-        const int qrow = min(q, S - 1);
+        const int qrow = min(q, Sq - 1);
         const E* qp = base + (size_t)qrow * a.ld_qkv + 8 * h2;
         Frag3 qf[4];
 #pragma unroll
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(AttnArgs a) {
         float m_run = -INFINITY, l_run = 0.f;
         f32x16 oacc[2] = {f32x16{}, f32x16{}};
 #pragma unroll 1
-        for (int kt = 0; kt < NKT; ++kt) {
+        for (int kt = 0; kt < nkt; ++kt) {
             f32x16 acc = f32x16{};
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = mma3_32(lds_pair(Kh, Kl, rowimg_off(kt * 32 + r, 2 * s + h2)), qf[s], acc);
@@ -513,10 +522,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(AttnArgs a) {
                 }
             }
         }
-        if (a.lse && h2 == 0 && q < S) a.lse[((size_t)post * a.heads + head) * S + q] = (m_run + log2f(l_run)) * (1.0f / LOG2E);
+        if (a.lse && h2 == 0 && q < Sq) a.lse[((size_t)post * a.heads + head) * S + q] = (m_run + log2f(l_run)) * (1.0f / LOG2E);
         const float inv = 1.0f / l_run;
-        if (q < S) {
-            E* op = (E*)a.ctx + ((size_t)post * S + q) * a.ld_ctx + head * HD;
+        if (q < Sq) {
+            E* op = (E*)a.ctx + ((size_t)post * cr + q) * a.ld_ctx + head * HD;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -682,19 +691,21 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int head = blockIdx.x, post = blockIdx.y;
     const int S = a.S;
-    const size_t row0 = (size_t)post * S;
-    const E* qb = (const E*)a.qkv + row0 * a.ld_qkv + head * HD;
-    const E* kb = qb + a.hidden;
-    const E* vb = qb + 2 * a.hidden;
-    const E* dob = (const E*)a.dctx + row0 * a.ld_ctx + head * HD;
-    const E* ob = (const E*)a.ctx + row0 * a.ld_ctx + head * HD;
-    IO::stage(Qh, Ql, qb, a.ld_qkv, a.lo_qkv, S, SP, true, tid, 256);
-    if constexpr (NP1) stage_image<bf16_t>(dOh, (const bf16_t*)dob, a.ld_ctx, S, SP, true, tid, 256);
-    else IO::stage(dOh, dOl, dob, a.ld_ctx, a.lo_ctx, S, SP, true, tid, 256);
-    IO::stage(Kh, Kl, kb, a.ld_qkv, a.lo_qkv, S, SP, true, tid, 256);
+    const int Sq = a.Sq_live > 0 ? a.Sq_live : S, Sk = a.Sk_live > 0 ? a.Sk_live : S;      // as in attn_bwd_kernel
+    const size_t qrow0 = (size_t)post * (a.q_rps > 0 ? a.q_rps : S), krow0 = (size_t)post * (a.kv_rps > 0 ? a.kv_rps : S), crow0 = (size_t)post * (a.ctx_rps > 0 ? a.ctx_rps : S);
+    const int nkt = min(NKT, (Sk + 31) / 32);
+    const E* qb = (const E*)a.qkv + qrow0 * a.ld_qkv + head * HD;
+    const E* kb = (const E*)a.qkv + krow0 * a.ld_qkv + a.hidden + head * HD;
+    const E* vb = kb + a.hidden;
+    const E* dob = (const E*)a.dctx + crow0 * a.ld_ctx + head * HD;
+    const E* ob = (const E*)a.ctx + crow0 * a.ld_ctx + head * HD;
+    IO::stage(Qh, Ql, qb, a.ld_qkv, a.lo_qkv, Sq, SP, true, tid, 256);
+    if constexpr (NP1) stage_image<bf16_t>(dOh, (const bf16_t*)dob, a.ld_ctx, Sq, SP, true, tid, 256);
+    else IO::stage(dOh, dOl, dob, a.ld_ctx, a.lo_ctx, Sq, SP, true, tid, 256);
+    IO::stage(Kh, Kl, kb, a.ld_qkv, a.lo_qkv, Sk, SP, true, tid, 256);
     for (int q = tid; q < SP; q += 256) {
         float d = 0.f, l = 0.f;
-        if (q < S) {
+        if (q < Sq) {
             const E* o = ob + (size_t)q * a.ld_ctx;
             const E* g = dob + (size_t)q * a.ld_ctx;
 #pragma unroll
@@ -712,9 +723,9 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
         lse2[q] = l;
     }
     const int r = lane & 31, h2 = lane >> 5;
-    const bool has_keys = w < NKT;
+    const bool has_keys = w < nkt;
     const int key = w * 32 + r;
-    const int krow = min(key, S - 1);
+    const int krow = min(key, Sk - 1);
     Frag3 kf[4], vf[4];
     float mbk = 0.f;
     if (has_keys) {
@@ -723,7 +734,7 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
             kf[s] = IO::frag(kb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2, a.lo_qkv);
             vf[s] = IO::frag(vb + (size_t)krow * a.ld_qkv + 16 * s + 8 * h2, a.lo_qkv);
         }
-        mbk = (key < S) ? (a.maskbias ? a.maskbias[(size_t)post * S + key] : 0.f) : -INFINITY;
+        mbk = (key < Sk) ? (a.maskbias ? a.maskbias[(size_t)post * S + key] : 0.f) : -INFINITY;
         mbk *= LOG2E;
     }
     __syncthreads();
@@ -731,7 +742,7 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
     const bool dropping = a.drop.thresh16 != 0;
     f32x16 dk[2] = {f32x16{}, f32x16{}}, dv[2] = {f32x16{}, f32x16{}};
     constexpr int NQT = NKT;
-    const int qlim = a.q_tiles > 0 ? min(NQT, a.q_tiles) : NQT;
+    const int qlim = min(a.q_tiles > 0 ? min(NQT, a.q_tiles) : NQT, (Sq + 31) / 32);
     for (int pair = 0; pair < (qlim + 1) / 2; ++pair) {
         if (has_keys) {
 #pragma unroll
@@ -757,7 +768,7 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
                         const int reg = 4 * g + e;
                         const int q = q0 + 8 * g + 4 * h2 + e;
                         float p = fast_exp2(sacc[reg] * sc + mbk - l4[e]);
-                        if (q >= S) p = 0.f;
+                        if (q >= Sq) p = 0.f;
                         float pd = p, dpd = pacc[reg];
                         if (dropping) {
                             const uint32_t eidx = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)min(q, S - 1)) * (uint32_t)S + (uint32_t)min(key, S - 1);
@@ -804,6 +815,7 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
                 f32x16 dq = f32x16{};
 #pragma unroll
                 for (int ks = 0; ks < SP / 16; ++ks) {
+                    if (ks >= nkt * 2) break;          // columns of dS past the last live key tile were never written
                     Frag3 ktf;
                     ktf.hi = tr_frag_natural<bf16_t>(Kh, ks * 16, dt * 32, lane);
                     if constexpr (NP1) {
@@ -813,18 +825,18 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
                         dq = mma3_32(lds_pair(dSh, dSl, ds_off(qi * 32 + r, 2 * ks + h2, SPC)), ktf, dq);
                     }
                 }
-                E* dqp = (E*)a.dqkv + row0 * a.ld_qkv + head * HD + dt * 32 + r;
+                E* dqp = (E*)a.dqkv + qrow0 * a.ld_qkv + head * HD + dt * 32 + r;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int q = qt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-                    if (q < S) IO::store1(dqp + (size_t)q * a.ld_qkv, a.lo_qkv, dq[reg]);
+                    if (q < Sq) IO::store1(dqp + (size_t)q * a.ld_qkv, a.lo_qkv, dq[reg]);
                 }
             }
         }
         __syncthreads();
     }
-    if (has_keys && key < S) {
-        E* dkp = (E*)a.dqkv + (row0 + key) * a.ld_qkv + a.hidden + head * HD;
+    if (has_keys && key < Sk) {
+        E* dkp = (E*)a.dqkv + (krow0 + key) * a.ld_qkv + a.hidden + head * HD;
         E* dvp = dkp + a.hidden;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -840,6 +852,11 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(AttnBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+// rows per post must hold the post's live rows
+static bool attn_rows_ok(int S, int Sq_live, int Sk_live, int q_rps, int kv_rps, int ctx_rps) {
+    const int Sq = Sq_live > 0 ? Sq_live : S, Sk = Sk_live > 0 ? Sk_live : S;
+    return q_rps >= 0 && kv_rps >= 0 && ctx_rps >= 0 && (q_rps == 0 || q_rps >= Sq) && (kv_rps == 0 || kv_rps >= Sk) && (ctx_rps == 0 || ctx_rps >= Sq);
+}
 template <typename T, int NKT, int NW, int DROP>
 static void launch_fwd_td(const AttnArgs& a, hipStream_t s) {
     const int lds = 2 * NKT * 32 * 128 + NKT * 32 * 4;
@@ -883,7 +900,8 @@ static bool x3_mfma_attention() {
 }
 hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s) {
     if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1 || a.Sq_live > a.S || a.Sk_live > a.S) return hipErrorInvalidValue;
-    if (dtype == DT_F32 && (a.Sq_live > 0 || a.Sk_live > 0)) return hipErrorInvalidValue;      // live-row counts: 16-bit kernels only
+    if (!attn_rows_ok(a.S, a.Sq_live, a.Sk_live, a.q_rps, a.kv_rps, a.ctx_rps)) return hipErrorInvalidValue;
+    const bool cross = a.Sq_live > 0 || a.Sk_live > 0 || a.q_rps > 0 || a.kv_rps > 0 || a.ctx_rps > 0;      // live counts / compact rows: the MFMA kernels only
     if (dtype == DT_F32) {
         // parity mode: split operands on the matrix cores; two 16-bit images per tensor fit the CU's LDS up to S = 288 (148 KB), longer
         // sequences (up to 768) walk the keys in LDS-sized chunks (attn_fwd_x3_long_kernel); MMHIP_X3_FAST=0: fp32 on the vector ALUs
@@ -892,6 +910,7 @@ hipError_t launch_attn_fwd(const AttnArgs& a, int dtype, hipStream_t s) {
             return launch_attn_fwd_f32(a, s);
         }
         if (a.S > 288) {
+            if (cross) return hipErrorInvalidValue;          // (the chunked kernel of the 577-token image tower: self-attention only)
             const int lds = 4 * 9 * 32 * 128 + 768 * 4;
             static bool done[2] = {false, false};
             if (a.pair) {
@@ -947,7 +966,7 @@ static void launch_bwd_x3_t(const AttnBwdArgs& a, hipStream_t s) {
 }
 hipError_t launch_attn_bwd(const AttnBwdArgs& a, int dtype, hipStream_t s) {
     if (a.hidden != a.heads * HD || a.ld_qkv % 8 || a.ld_ctx % 8 || a.S < 1 || a.Sq_live > a.S || a.Sk_live > a.S) return hipErrorInvalidValue;
-    if (dtype == DT_F32 && (a.Sq_live > 0 || a.Sk_live > 0)) return hipErrorInvalidValue;      // live-row counts: 16-bit kernels only
+    if (!attn_rows_ok(a.S, a.Sq_live, a.Sk_live, a.q_rps, a.kv_rps, a.ctx_rps)) return hipErrorInvalidValue;
     if (dtype == DT_F32) {
         auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
         if (!x3_mfma_attention() || a.S > 128 || !al(a.qkv) || !al(a.ctx) || !al(a.dctx) || !al(a.dqkv)) {

@@ -116,9 +116,12 @@ struct AttnArgs {
     int q_tiles;          // > 0: only the first q_tiles 32-row query tiles are computed / written (last layer: CLS row only)
     int pair;             // parity mode: qkv and ctx are plane pairs (ld_qkv / ld_ctx in 16-bit elements), lo planes lo_qkv / lo_ctx elements behind
     int lo_qkv, lo_ctx;
-    int Sq_live, Sk_live; // > 0 (16-bit kernels): only the first Sq_live query rows / Sk_live key rows of each post's S-row block exist -- the other rows
-                          // of qkv are never read (keys past Sk_live are masked, whatever maskbias holds there) and the other rows of ctx / lse never
-                          // written.  Layout strides and the dropout element index stay those of S.  (Cross attention, Sq != Sk, without padding passes.)
+    int Sq_live, Sk_live; // > 0: a post has Sq_live queries and Sk_live keys (cross attention, Sq != Sk; 0 = S).  Nothing past them is read or written, key tiles
+                          // past Sk_live are not computed.  The dropout element index, the lse row and the maskbias row stay those of the S x S layout
+                          // (S = the larger of the two), so padded and compact callers drop the same probabilities.
+    int q_rps, kv_rps, ctx_rps;   // rows per post of the Q columns / of the K and V columns of qkv / of ctx (0 = S): round 5 -- cross attention on COMPACT tensors:
+                          // query row q of post p is row p * q_rps + q, key row k is row p * kv_rps + k; the two projections write Mq and Mc rows and nothing is
+                          // remapped, cleared or copied
 };
 struct AttnBwdArgs {
     const void* qkv; const float* maskbias; const void* ctx; const void* dctx; const float* lse;
@@ -130,7 +133,8 @@ struct AttnBwdArgs {
     int pair;             // parity mode: qkv, ctx, dctx, dqkv are plane pairs (qkv and dqkv share ld_qkv / lo_qkv; ctx and dctx ld_ctx / lo_ctx)
     int lo_qkv, lo_ctx;
     int Sq_live, Sk_live; // as in AttnArgs: rows of ctx / dctx past Sq_live are never read (their gradient is taken as zero), dQ rows past Sq_live and
-                          // dK / dV rows past Sk_live are not written
+                          // dK / dV rows past Sk_live never written
+    int q_rps, kv_rps, ctx_rps;   // as in AttnArgs (qkv and dqkv share q_rps / kv_rps; ctx and dctx share ctx_rps)
     int nprod;            // plane pairs: 1 = the scores keep three products (they are re-computed against the forward's log-sum-exp), the four other matrix
                           // products take one, d ctx is read from its hi plane only; 0 / 3: three products throughout (GemmNTArgs::nprod: the engine's policy)
 };

@@ -396,12 +396,15 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnArgs a) {
     float* Ks = sm;
     float* Vs = sm + (size_t)S * HD;
     float* mb = sm + (size_t)2 * S * HD;
-    const float* base = (const float*)a.qkv + (size_t)post * S * a.ld_qkv + head * HD;
-    stage_rows(Ks, base + a.hidden, a.ld_qkv, S, tid, 256);
-    stage_rows(Vs, base + 2 * a.hidden, a.ld_qkv, S, tid, 256);
-    for (int k = tid; k < S; k += 256) mb[k] = a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f;
+    const int Sq = a.Sq_live > 0 ? a.Sq_live : S, Sk = a.Sk_live > 0 ? a.Sk_live : S;      // queries / keys of a post and rows per post, as in attn_fwd_kernel
+    const int qr = a.q_rps > 0 ? a.q_rps : S, kr = a.kv_rps > 0 ? a.kv_rps : S, cr = a.ctx_rps > 0 ? a.ctx_rps : S;
+    const float* base = (const float*)a.qkv + (size_t)post * qr * a.ld_qkv + head * HD;
+    const float* kvb = (const float*)a.qkv + (size_t)post * kr * a.ld_qkv + a.hidden + head * HD;
+    stage_rows(Ks, kvb, a.ld_qkv, Sk, tid, 256);
+    stage_rows(Vs, kvb + a.hidden, a.ld_qkv, Sk, tid, 256);
+    for (int k = tid; k < Sk; k += 256) mb[k] = a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f;
     __syncthreads();
-    const int qlim = a.q_tiles > 0 ? min(S, a.q_tiles * 32) : S;
+    const int qlim = a.q_tiles > 0 ? min(Sq, a.q_tiles * 32) : Sq;
     const bool dropping = a.drop.thresh16 != 0;
     for (int q = tid; q < qlim; q += 256) {
         float qv[HD];
@@ -411,14 +414,14 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnArgs a) {
             qv[d] = x[0]; qv[d + 1] = x[1]; qv[d + 2] = x[2]; qv[d + 3] = x[3];
         }
         float mx = -INFINITY;
-        for (int key = 0; key < S; ++key) mx = fmaxf(mx, dot64(qv, Ks + key * HD) * a.scale + mb[key]);
+        for (int key = 0; key < Sk; ++key) mx = fmaxf(mx, dot64(qv, Ks + key * HD) * a.scale + mb[key]);
         const float msafe = (mx == -INFINITY) ? 0.f : mx;
         float o[HD];
 #pragma unroll
         for (int d = 0; d < HD; ++d) o[d] = 0.f;
         float l = 0.f;
         const uint32_t ebase = (uint32_t)(((size_t)post * a.heads + head) * S + (uint32_t)q) * (uint32_t)S;
-        for (int key = 0; key < S; ++key) {
+        for (int key = 0; key < Sk; ++key) {
             const float p = __expf(dot64(qv, Ks + key * HD) * a.scale + mb[key] - msafe);
             l += p;
             float pd = p;
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnArgs a) {
         }
         if (a.lse) a.lse[((size_t)post * a.heads + head) * S + q] = msafe + __logf(l);
         const float inv = 1.0f / l;
-        float* op = (float*)a.ctx + ((size_t)post * S + q) * a.ld_ctx + head * HD;
+        float* op = (float*)a.ctx + ((size_t)post * cr + q) * a.ld_ctx + head * HD;
 #pragma unroll
         for (int d = 0; d < HD; d += 4) *reinterpret_cast<f32x4*>(op + d) = f32x4{o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
     }
@@ -451,15 +454,18 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs a) {
     float* lse = Vs + (size_t)S * HD;
     float* Dv = lse + S;
     float* mb = Dv + S;
-    const size_t row0 = (size_t)post * S;
-    const float* qb = (const float*)a.qkv + row0 * a.ld_qkv + head * HD;
-    const float* dob = (const float*)a.dctx + row0 * a.ld_ctx + head * HD;
-    const float* ob = (const float*)a.ctx + row0 * a.ld_ctx + head * HD;
-    stage_rows(Qs, qb, a.ld_qkv, S, tid, 256);
-    stage_rows(Ks, qb + a.hidden, a.ld_qkv, S, tid, 256);
-    stage_rows(Vs, qb + 2 * a.hidden, a.ld_qkv, S, tid, 256);
-    stage_rows(Gs, dob, a.ld_ctx, S, tid, 256);
-    for (int q = tid; q < S; q += 256) {
+    const int Sq = a.Sq_live > 0 ? a.Sq_live : S, Sk = a.Sk_live > 0 ? a.Sk_live : S;      // as in attn_bwd_kernel
+    const size_t qrow0 = (size_t)post * (a.q_rps > 0 ? a.q_rps : S), krow0 = (size_t)post * (a.kv_rps > 0 ? a.kv_rps : S), crow0 = (size_t)post * (a.ctx_rps > 0 ? a.ctx_rps : S);
+    const float* qb = (const float*)a.qkv + qrow0 * a.ld_qkv + head * HD;
+    const float* kb = (const float*)a.qkv + krow0 * a.ld_qkv + a.hidden + head * HD;
+    const float* dob = (const float*)a.dctx + crow0 * a.ld_ctx + head * HD;
+    const float* ob = (const float*)a.ctx + crow0 * a.ld_ctx + head * HD;
+    stage_rows(Qs, qb, a.ld_qkv, Sq, tid, 256);
+    stage_rows(Ks, kb, a.ld_qkv, Sk, tid, 256);
+    stage_rows(Vs, kb + a.hidden, a.ld_qkv, Sk, tid, 256);
+    stage_rows(Gs, dob, a.ld_ctx, Sq, tid, 256);
+    for (int k = tid; k < Sk; k += 256) mb[k] = a.maskbias ? a.maskbias[(size_t)post * S + k] : 0.f;
+    for (int q = tid; q < Sq; q += 256) {
         float d = 0.f;
 #pragma unroll
         for (int c = 0; c < HD; c += 4) {
@@ -468,19 +474,18 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs a) {
         }
         Dv[q] = d;
         lse[q] = a.lse[((size_t)post * a.heads + head) * S + q];
-        mb[q] = a.maskbias ? a.maskbias[(size_t)post * S + q] : 0.f;
     }
     __syncthreads();
-    const int qlim = a.q_tiles > 0 ? min(S, a.q_tiles * 32) : S;      // later queries carry a zero d ctx
+    const int qlim = a.q_tiles > 0 ? min(Sq, a.q_tiles * 32) : Sq;      // later queries carry a zero d ctx
     const bool dropping = a.drop.thresh16 != 0;
     const uint32_t hbase = (uint32_t)(((size_t)post * a.heads + head) * S);
     const int role = tid >> 7, key = tid & 127;        // role 0: dK, role 1: dV
-    if (key < S) {
+    if (key < Sk) {
         float kr[HD], acc[HD];
 #pragma unroll
         for (int d = 0; d < HD; ++d) { kr[d] = Ks[key * HD + d]; acc[d] = 0.f; }
         const float mbk = mb[key];
-        float* outp = (float*)a.dqkv + (row0 + key) * a.ld_qkv + (role == 0 ? 1 : 2) * a.hidden + head * HD;
+        float* outp = (float*)a.dqkv + (krow0 + key) * a.ld_qkv + (role == 0 ? 1 : 2) * a.hidden + head * HD;
         if (role == 0) {
             float vr[HD];
 #pragma unroll
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs a) {
 #pragma unroll
         for (int d = 0; d < HD; ++d) { qr[d] = Qs[q * HD + d]; gr[d] = Gs[q * HD + d]; acc[d] = 0.f; }
         const float lq = lse[q], dq = Dv[q];
-        for (int k = 0; k < S; ++k) {
+        for (int k = 0; k < Sk; ++k) {
             const float p = __expf(dot64(qr, Ks + k * HD) * a.scale + mb[k] - lq);
             float dpd = dot64(gr, Vs + k * HD);
             if (dropping) dpd = mm_keep((hbase + (uint32_t)q) * (uint32_t)S + (uint32_t)k, a.drop) ? dpd * a.drop.keep_scale : 0.f;
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs a) {
                 acc[d] = fmaf(ds, x[0], acc[d]); acc[d + 1] = fmaf(ds, x[1], acc[d + 1]); acc[d + 2] = fmaf(ds, x[2], acc[d + 2]); acc[d + 3] = fmaf(ds, x[3], acc[d + 3]);
             }
         }
-        float* outp = (float*)a.dqkv + (row0 + q) * a.ld_qkv + head * HD;
+        float* outp = (float*)a.dqkv + (qrow0 + q) * a.ld_qkv + head * HD;
 #pragma unroll
         for (int d = 0; d < HD; d += 4) *reinterpret_cast<f32x4*>(outp + d) = f32x4{acc[d], acc[d + 1], acc[d + 2], acc[d + 3]};
     }
