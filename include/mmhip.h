@@ -329,13 +329,14 @@ int mmhip_op_self_att_block_bwd(int dtype, const void* dy, const float* maskbias
                                 void* stream);
 /* cross-attention block (LXMERT cross-modality layers, reference models/mm_early.py:121-127 via HF LxmertCrossAttentionLayer): queries from
  * xq [posts*Sq, H], keys / values from xc [posts*Sk, H];  y = LayerNorm(dropout(att Wo^T + bo) + xq).  wqkv / bqkv = the fused [Wq; Wk; Wv]
- * [3H, H] copy and bias; keybias [posts, S] additive key mask padded with -inf past Sk, S = max(Sq, Sk).  qkv [posts*S, 3H] and att
- * [posts*S, H] are the packed tensors the attention kernels work on (saved for the backward with lse, pre, mean, rstd); tq / attq
- * [posts*Sq, H] (needed when Sq < S) and tkv [posts*Sk, 2H] (when Sk < S) are scratch.  Backward: dxq (incl. the residual branch), dxc;
- * weight-gradient operands: dd / attq-or-att (Wo), dq-or-dqkv[:, :H] / xq (Wq), dkv-or-dqkv[:, H:] / xc (Wk, Wv).
- * Round 4: with a 16-bit dtype (and H a multiple of 128) nothing is padded -- the projections write their rows into the posts' S-row blocks
- * directly and the attention kernels are given the live row counts, so rows of qkv / att / datt / dqkv past Sq (queries) or Sk (keys) are
- * neither read nor written and need no initialisation; tq, tkv and dattq are then unused and may be NULL.  MMHIP_F32 keeps the padded form. */
+ * [3H, H] copy and bias; keybias [posts, S] additive key mask, S = max(Sq, Sk) (entries past Sk are not read).
+ * Round 5 -- compact tensors, every dtype: qkv is [max(Mq, Mc), 3H] with Mq = posts*Sq, Mc = posts*Sk: the query projection fills rows [0, Mq) of
+ * columns [0, H), the key / value projection rows [0, Mc) of columns [H, 3H) (row p*Sq + q = query q of post p, row p*Sk + k = its key k); att is
+ * [Mq, H]; lse [posts, heads, S].  The attention kernels take the two row pitches and lengths, skip key tiles past Sk, and nothing is padded,
+ * cleared, remapped or copied (rounds 3-4 did: tq, tkv, attq, dattq, dq, dkv were their scratch -- now unused, may be NULL).  The dropout masks keep
+ * the element indices of the S x S layout.  Saved for the backward: qkv, att, lse, pre, mean, rstd.  Backward: dxq (incl. the residual branch), dxc;
+ * datt [Mq, H]; dqkv laid out like qkv.  Weight-gradient operands, as the block leaves them: dd / att (Wo), dqkv[:Mq, :H] / xq (Wq),
+ * dqkv[:Mc, H:] / xc (Wk, Wv) -- leading dimension 3H. */
 int mmhip_op_cross_att_block_fwd(int dtype, const void* xq, const void* xc, const float* keybias, const void* wqkv, const float* bqkv, const void* wo,
                                  const float* bo, const float* gamma, const float* beta, float eps, int posts, int Sq, int Sk, int heads, float p_att,
                                  float p_hid, uint64_t seed, void* qkv, void* att, float* lse, void* tq, void* tkv, void* attq, void* pre, float* mean,

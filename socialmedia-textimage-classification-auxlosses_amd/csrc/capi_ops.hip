@@ -228,33 +228,10 @@ int mmhip_op_self_att_block_bwd(int dtype, const void* dy, const float* maskbias
     return 0;
 }
 
-// ---- cross-attention block (LXMERT's cross-modality layers: queries from one stream, keys / values from the other).  The attention kernels
-// take ONE packed [posts * S, 3H] tensor with S = max(Sq, Sk): row (post, i) carries query i | key i | value i.  A stream whose length is S
-// is projected straight into its columns of the packed tensor; the shorter one goes through a dense temporary and a row copy; rows past a
-// stream's length stay zero, keys past Sk are masked by the (padded) key bias, query rows past Sq are dropped.
+// ---- cross-attention block (LXMERT's cross-modality layers: queries from one stream, keys / values from the other).  Rounds 3-4 packed both
+// streams into S-row blocks of one tensor (S = max(Sq, Sk)) with clears and row copies, then with a row remap in the projections' epilogue; since
+// round 5 the attention kernels take the two streams' rows where the projections put them (compact tensors, two row pitches): see the forward below.
 namespace {
-// dst[(b * rps_dst + i) * ld_dst + c] = src[(b * rps_src + i) * ld_src + c], i < L, c < W  (16-byte chunks; W * esz % 16 == 0)
-__global__ __launch_bounds__(256) void copy_post_rows_kernel(const char* __restrict__ src, size_t ld_src, int rps_src, char* __restrict__ dst, size_t ld_dst,
-                                                             int rps_dst, int posts, int L, int chunks) {
-    const size_t total = (size_t)posts * L * chunks;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int c = (int)(idx % chunks);
-        const size_t r = idx / chunks;
-        const int i = (int)(r % L), b = (int)(r / L);
-        *reinterpret_cast<u32x4*>(dst + ((size_t)b * rps_dst + i) * ld_dst + (size_t)c * 16) =
-            *reinterpret_cast<const u32x4*>(src + ((size_t)b * rps_src + i) * ld_src + (size_t)c * 16);
-    }
-}
-hipError_t copy_post_rows(const void* src, size_t ld_src_bytes, int rps_src, void* dst, size_t ld_dst_bytes, int rps_dst, int posts, int L, size_t row_bytes,
-                          hipStream_t s) {
-    if (posts <= 0 || L <= 0) return hipSuccess;
-    if (row_bytes % 16 || ld_src_bytes % 16 || ld_dst_bytes % 16 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return hipErrorInvalidValue;
-    const int chunks = (int)(row_bytes / 16);
-    const size_t total = (size_t)posts * L * chunks;
-    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(copy_post_rows_kernel, dim3(grid), dim3(256), 0, s, (const char*)src, ld_src_bytes, rps_src, (char*)dst, ld_dst_bytes, rps_dst, posts, L, chunks);
-    return hipGetLastError();
-}
 inline size_t esz_of(int dtype) { return dtype == MMHIP_F32 ? 4 : 2; }
 }  // namespace
 
@@ -262,45 +239,35 @@ int mmhip_op_cross_att_block_fwd(int dtype, const void* xq, const void* xc, cons
                                  const float* bo, const float* gamma, const float* beta, float eps, int posts, int Sq, int Sk, int heads, float p_att,
                                  float p_hid, uint64_t seed, void* qkv, void* att, float* lse, void* tq, void* tkv, void* attq, void* pre, float* mean,
                                  float* rstd, void* y, void* stream) {
+    (void)tq; (void)tkv; (void)attq;          // scratch of the padded forms of rounds 3-4: unused since round 5
     if (!xq || !xc || !keybias || !wqkv || !bqkv || !wo || !bo || !gamma || !beta || !qkv || !att || !lse || !pre || !mean || !rstd || !y || posts < 1 ||
         Sq < 1 || Sk < 1 || heads < 1)
         return MMHIP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    const int H = heads * 64, S = Sq > Sk ? Sq : Sk, Mq = posts * Sq, Mc = posts * Sk, M = posts * S;
+    const int H = heads * 64, S = Sq > Sk ? Sq : Sk, Mq = posts * Sq, Mc = posts * Sk;
     const size_t Z = esz_of(dtype);
-    // 16-bit dtypes: no padding passes.  The two projections write their rows straight into the posts' S-row blocks of the packed buffer
-    // (GemmNTArgs::c_rps) and the attention kernel is told how many query / key rows of a block exist (AttnArgs::Sq_live / Sk_live): the
-    // other rows are never read, so nothing has to be cleared or copied.  fp32 (parity mode): the padded form -- clear, project into
-    // compact scratch, copy the rows in -- which the parity kernels take as an ordinary self-attention over S rows.
-    const bool direct = dtype != MMHIP_F32 && H % 128 == 0;
-    if (!direct && ((Sq < S && !tq) || (Sk < S && !tkv))) return MMHIP_E_INVALID;
-    if (Sq < S && !attq) return MMHIP_E_INVALID;
+    // Round 5, every dtype: COMPACT tensors.  The query projection writes Mq rows into columns [0, H) of qkv, the key / value projection Mc rows into
+    // columns [H, 3H) -- row p * Sq + q is query q of post p, row p * Sk + k its key k -- and the attention kernels are told the two row pitches
+    // (AttnArgs::q_rps / kv_rps / ctx_rps) and the two lengths.  Nothing is padded, cleared, remapped or copied; key tiles past Sk are not computed;
+    // att is [Mq, H], the operand of the output projection as it is.  The dropout masks, the lse rows and keybias keep the indices of the S x S layout.
     const char* w = (const char*)wqkv;
-    if (!direct && (Sq < S || Sk < S)) CHECK_HIP(hipMemsetAsync(qkv, 0, (size_t)M * 3 * H * Z, s));
-    {   // Q = xq Wq^T + bq  -> columns [0, H)
-        GemmNTArgs a = (Sq == S || direct) ? nt(xq, H, w, H, qkv, 3 * H, Mq, H, H) : nt(xq, H, w, H, tq, H, Mq, H, H);
+    {   // Q = xq Wq^T + bq
+        GemmNTArgs a = nt(xq, H, w, H, qkv, 3 * H, Mq, H, H);
         a.bias = bqkv; a.flags = GEMM_BIAS;
-        if (direct && Sq < S) { a.c_rps = Sq; a.c_rps_stride = S; }
         CHECK_HIP(launch_gemm_nt(a, dtype, s));
-        if (!direct && Sq < S) CHECK_HIP(copy_post_rows(tq, (size_t)H * Z, Sq, qkv, (size_t)3 * H * Z, S, posts, Sq, (size_t)H * Z, s));
     }
-    {   // [K | V] = xc [Wk; Wv]^T + [bk; bv]  -> columns [H, 3H)
-        char* dst = (char*)qkv + (size_t)H * Z;
-        GemmNTArgs a = (Sk == S || direct) ? nt(xc, H, w + (size_t)H * H * Z, H, dst, 3 * H, Mc, 2 * H, H) : nt(xc, H, w + (size_t)H * H * Z, H, tkv, 2 * H, Mc, 2 * H, H);
+    {   // [K | V] = xc [Wk; Wv]^T + [bk; bv]
+        GemmNTArgs a = nt(xc, H, w + (size_t)H * H * Z, H, (char*)qkv + (size_t)H * Z, 3 * H, Mc, 2 * H, H);
         a.bias = bqkv + H; a.flags = GEMM_BIAS;
-        if (direct && Sk < S) { a.c_rps = Sk; a.c_rps_stride = S; }
         CHECK_HIP(launch_gemm_nt(a, dtype, s));
-        if (!direct && Sk < S) CHECK_HIP(copy_post_rows(tkv, (size_t)2 * H * Z, Sk, dst, (size_t)3 * H * Z, S, posts, Sk, (size_t)2 * H * Z, s));
     }
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.qkv = qkv; at.maskbias = keybias; at.ctx = att; at.lse = lse; at.posts = posts; at.S = S; at.heads = heads;
     at.hidden = H; at.ld_qkv = 3 * H; at.ld_ctx = H; at.scale = 0.125f; at.drop = drop_of(p_att, seed, 7);
-    if (direct) { at.Sq_live = Sq; at.Sk_live = Sk; }
+    at.Sq_live = Sq; at.Sk_live = Sk; at.q_rps = Sq; at.kv_rps = Sk; at.ctx_rps = Sq;
     CHECK_HIP(launch_attn_fwd(at, dtype, s));
-    const void* aq = att;
-    if (Sq < S) { CHECK_HIP(copy_post_rows(att, (size_t)H * Z, S, attq, (size_t)H * Z, Sq, posts, Sq, (size_t)H * Z, s)); aq = attq; }
-    { GemmNTArgs a = nt(aq, H, wo, H, pre, H, Mq, H, H); a.bias = bo; a.residual = xq; a.ldres = H; a.flags = GEMM_BIAS | GEMM_RESIDUAL;
+    { GemmNTArgs a = nt(att, H, wo, H, pre, H, Mq, H, H); a.bias = bo; a.residual = xq; a.ldres = H; a.flags = GEMM_BIAS | GEMM_RESIDUAL;
       if (p_hid > 0.f) { a.drop = drop_of(p_hid, seed, 8); a.flags |= GEMM_DROPOUT; }
       CHECK_HIP(launch_gemm_nt(a, dtype, s)); }
     LNArgs ln{pre, y, gamma, beta, mean, rstd, Mq, H, H, H, eps};
@@ -312,14 +279,13 @@ int mmhip_op_cross_att_block_bwd(int dtype, const void* dy, const float* keybias
                                  int Sk, int heads, float p_att, float p_hid, uint64_t seed, const void* qkv, const void* att, const float* lse,
                                  const void* pre, const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dpre, void* dd, void* dattq,
                                  void* datt, void* dqkv, void* dq, void* dkv, void* dxq, void* dxc, void* stream) {
+    (void)dattq; (void)dq; (void)dkv;          // scratch of the padded forms of rounds 3-4: unused since round 5
     if (!dy || !keybias || !wqkvT || !woT || !gamma || !qkv || !att || !lse || !pre || !mean || !rstd || !dgamma || !dbeta || !dpre || !dd || !datt || !dqkv ||
         !dxq || !dxc || posts < 1 || Sq < 1 || Sk < 1 || heads < 1)
         return MMHIP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    const int H = heads * 64, S = Sq > Sk ? Sq : Sk, Mq = posts * Sq, Mc = posts * Sk, M = posts * S;
+    const int H = heads * 64, S = Sq > Sk ? Sq : Sk, Mq = posts * Sq, Mc = posts * Sk;
     const size_t Z = esz_of(dtype);
-    const bool direct = dtype != MMHIP_F32 && H % 128 == 0;      // as in the forward
-    if ((Sq < S && ((!direct && !dattq) || !dq)) || (Sk < S && !dkv)) return MMHIP_E_INVALID;
     LNBwdArgs b;
     memset(&b, 0, sizeof(b));
     b.dy = dy; b.x = pre; b.gamma = gamma; b.mean = mean; b.rstd = rstd; b.dx = dpre; b.dgamma = dgamma; b.dbeta = dbeta; b.rows = Mq; b.width = H; b.alpha = 1.0f;
@@ -327,37 +293,23 @@ int mmhip_op_cross_att_block_bwd(int dtype, const void* dy, const float* keybias
     if (dropping) { b.dx_drop = dd; b.drop = drop_of(p_hid, seed, 8); b.drop_row_mul = 1; }
     CHECK_HIP(launch_layernorm_bwd(b, dtype, s));
     const void* dsrc = dropping ? dd : dpre;
-    if (Sq == S) {
-        GemmNTArgs a = nt(dsrc, H, woT, H, datt, H, Mq, H, H);
-        CHECK_HIP(launch_gemm_nt(a, dtype, s));
-    } else if (direct) {      // rows written in place; the attention backward takes the rows past Sq as absent (AttnBwdArgs::Sq_live)
-        GemmNTArgs a = nt(dsrc, H, woT, H, datt, H, Mq, H, H);
-        a.c_rps = Sq; a.c_rps_stride = S;
-        CHECK_HIP(launch_gemm_nt(a, dtype, s));
-    } else {          // the gradient of the dropped query rows is zero
-        GemmNTArgs a = nt(dsrc, H, woT, H, dattq, H, Mq, H, H);
-        CHECK_HIP(launch_gemm_nt(a, dtype, s));
-        CHECK_HIP(hipMemsetAsync(datt, 0, (size_t)M * H * Z, s));
-        CHECK_HIP(copy_post_rows(dattq, (size_t)H * Z, Sq, datt, (size_t)H * Z, S, posts, Sq, (size_t)H * Z, s));
-    }
+    { GemmNTArgs a = nt(dsrc, H, woT, H, datt, H, Mq, H, H); CHECK_HIP(launch_gemm_nt(a, dtype, s)); }          // d att, compact [Mq, H] like att
     AttnBwdArgs ab;
     memset(&ab, 0, sizeof(ab));
     ab.qkv = qkv; ab.maskbias = keybias; ab.ctx = att; ab.dctx = datt; ab.lse = lse; ab.dqkv = dqkv; ab.posts = posts; ab.S = S; ab.heads = heads;
     ab.hidden = H; ab.ld_qkv = 3 * H; ab.ld_ctx = H; ab.scale = 0.125f; ab.drop = drop_of(p_att, seed, 7);
-    if (direct) { ab.Sq_live = Sq; ab.Sk_live = Sk; }
+    ab.Sq_live = Sq; ab.Sk_live = Sk; ab.q_rps = Sq; ab.kv_rps = Sk; ab.ctx_rps = Sq;
     CHECK_HIP(launch_attn_bwd(ab, dtype, s));
+    // dqkv as qkv: dQ in rows [0, Mq) of columns [0, H), [dK | dV] in rows [0, Mc) of columns [H, 3H) -- the operands of the two input-gradient products
+    // below and of the caller's weight-gradient products (leading dimension 3H), as they are
     const char* wt = (const char*)wqkvT;              // [H, 3H]: columns [0,H) = Wq^T, [H,3H) = [Wk; Wv]^T
     {   // d xq = dQ Wq + d pre (residual branch)
-        const void* src = dqkv; int ld = 3 * H;
-        if (Sq < S) { CHECK_HIP(copy_post_rows(dqkv, (size_t)3 * H * Z, S, dq, (size_t)H * Z, Sq, posts, Sq, (size_t)H * Z, s)); src = dq; ld = H; }
-        GemmNTArgs a = nt(src, ld, wt, 3 * H, dxq, H, Mq, H, H);
+        GemmNTArgs a = nt(dqkv, 3 * H, wt, 3 * H, dxq, H, Mq, H, H);
         a.residual = dpre; a.ldres = H; a.flags = GEMM_RESIDUAL;
         CHECK_HIP(launch_gemm_nt(a, dtype, s));
     }
     {   // d xc = [dK | dV] [Wk; Wv]
-        const void* src = (const char*)dqkv + (size_t)H * Z; int ld = 3 * H;
-        if (Sk < S) { CHECK_HIP(copy_post_rows(src, (size_t)3 * H * Z, S, dkv, (size_t)2 * H * Z, Sk, posts, Sk, (size_t)2 * H * Z, s)); src = dkv; ld = 2 * H; }
-        GemmNTArgs a = nt(src, ld, wt + (size_t)H * Z, 3 * H, dxc, H, Mc, H, 2 * H);
+        GemmNTArgs a = nt((const char*)dqkv + (size_t)H * Z, 3 * H, wt + (size_t)H * Z, 3 * H, dxc, H, Mc, H, 2 * H);
         CHECK_HIP(launch_gemm_nt(a, dtype, s));
     }
     return 0;

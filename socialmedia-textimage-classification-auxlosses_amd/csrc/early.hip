@@ -45,7 +45,7 @@ struct Copy { size_t w, wT; };                                      // byte offs
 struct AttW { Copy qkv, o; };
 struct FfnW { Copy w1, w2; };
 struct SelfAct { size_t qkv, att, lse, pre, mean, rstd, y, dpre, dd, datt, dqkv, dx; };
-struct CrossAct { size_t qkv, att, lse, tq, tkv, attq, pre, mean, rstd, y, dpre, dd, dattq, datt, dqkv, dq, dkv, dxq, dxc; };
+struct CrossAct { size_t qkv, att, lse, pre, mean, rstd, y, dpre, dd, datt, dqkv, dxq, dxc; };
 struct FfnAct { size_t h, u, pre, mean, rstd, y, dpre, dd, du, dx; };
 struct PlainLayer { AttOff att; FfnOff ffn; AttW aw; FfnW fw; SelfAct sa; FfnAct fa; size_t begin, end; };
 struct XLayer {
@@ -387,10 +387,11 @@ void build_workspace(mmhip_early& e) {
         a.dpre = w.take(M * H * Z); a.dd = w.take(M * H * Z); a.du = w.take(M * I * Z); a.dx = w.take(M * H * Z);
     };
     auto cross_act = [&](CrossAct& a, size_t Mq, size_t Mc) {
-        a.qkv = w.take(MS * 3 * H * Z); a.att = w.take(MS * H * Z); a.lse = w.take(Pm * heads * Sm * 4); a.tq = w.take(Mq * H * Z); a.tkv = w.take(Mc * 2 * H * Z);
-        a.attq = w.take(Mq * H * Z); a.pre = w.take(Mq * H * Z); a.mean = w.take(Mq * 4); a.rstd = w.take(Mq * 4); a.y = w.take(Mq * H * Z);
-        a.dpre = w.take(Mq * H * Z); a.dd = w.take(Mq * H * Z); a.dattq = w.take(Mq * H * Z); a.datt = w.take(MS * H * Z); a.dqkv = w.take(MS * 3 * H * Z);
-        a.dq = w.take(Mq * H * Z); a.dkv = w.take(Mc * 2 * H * Z); a.dxq = w.take(Mq * H * Z); a.dxc = w.take(Mc * H * Z);
+        // compact tensors (round 5): qkv / dqkv hold Mq rows of Q columns and Mc rows of K | V columns, att / datt Mq rows; no padded blocks, no scratch copies
+        a.qkv = w.take(MS * 3 * H * Z); a.att = w.take(Mq * H * Z); a.lse = w.take(Pm * heads * Sm * 4);
+        a.pre = w.take(Mq * H * Z); a.mean = w.take(Mq * 4); a.rstd = w.take(Mq * 4); a.y = w.take(Mq * H * Z);
+        a.dpre = w.take(Mq * H * Z); a.dd = w.take(Mq * H * Z); a.datt = w.take(Mq * H * Z); a.dqkv = w.take(MS * 3 * H * Z);
+        a.dxq = w.take(Mq * H * Z); a.dxc = w.take(Mc * H * Z);
     };
     for (auto& l : e.lang) { attw(l.aw); ffnw(l.fw); self_act(l.sa, ML, Pm, Tm); ffn_act(l.fa, ML); }
     for (auto& l : e.rel) { attw(l.aw); ffnw(l.fw); self_act(l.sa, MV, Pm, Nm); ffn_act(l.fa, MV); }
@@ -482,8 +483,8 @@ int cross_fwd(mmhip_early& e, const AttOff& o, const AttW& w, CrossAct& a, const
               hipStream_t s) {
     const float p_att = e.train ? e.cfg.p_attn : 0.f, p_hid = e.train ? e.cfg.p_hidden : 0.f;
     return mmhip_op_cross_att_block_fwd(e.dt(), xq, xc, keybias, e.ws + w.qkv.w, e.P + o.qkv_b, e.ws + w.o.w, e.P + o.o_b, e.P + o.ln_w, e.P + o.ln_b, e.cfg.ln_eps, posts,
-                                        Sq, Sk, e.cfg.heads, p_att, p_hid, block_seed(e, blk), e.ws + a.qkv, e.ws + a.att, e.wsp<float>(a.lse), e.ws + a.tq, e.ws + a.tkv,
-                                        e.ws + a.attq, e.ws + a.pre, e.wsp<float>(a.mean), e.wsp<float>(a.rstd), e.ws + a.y, s);
+                                        Sq, Sk, e.cfg.heads, p_att, p_hid, block_seed(e, blk), e.ws + a.qkv, e.ws + a.att, e.wsp<float>(a.lse), nullptr, nullptr,
+                                        nullptr, e.ws + a.pre, e.wsp<float>(a.mean), e.wsp<float>(a.rstd), e.ws + a.y, s);
 }
 
 // weight-gradient products of a group of blocks: queued while the blocks' backward is enqueued, launched grouped (<= 8 problems per launch)
@@ -529,18 +530,17 @@ int ffn_bwd(mmhip_early& e, const FfnOff& o, const FfnW& w, FfnAct& a, const voi
 }
 int cross_bwd(mmhip_early& e, const AttOff& o, const AttW& w, CrossAct& a, const void* dy, const void* xq, const void* xc, const float* keybias, int posts, int Sq, int Sk,
               int blk, TNQueue& tn, hipStream_t s) {
-    const int H = e.cfg.hidden, S = Sq > Sk ? Sq : Sk, Mq = posts * Sq, Mc = posts * Sk;
+    const int H = e.cfg.hidden, Mq = posts * Sq, Mc = posts * Sk;
     const size_t Z = e.esz();
     const float p_att = e.train ? e.cfg.p_attn : 0.f, p_hid = e.train ? e.cfg.p_hidden : 0.f;
     char* dd = p_hid > 0.f ? e.ws + a.dd : e.ws + a.dpre;
     CHECK_RC(mmhip_op_cross_att_block_bwd(e.dt(), dy, keybias, e.ws + w.qkv.wT, e.ws + w.o.wT, e.P + o.ln_w, posts, Sq, Sk, e.cfg.heads, p_att, p_hid, block_seed(e, blk),
                                           e.ws + a.qkv, e.ws + a.att, e.wsp<float>(a.lse), e.ws + a.pre, e.wsp<float>(a.mean), e.wsp<float>(a.rstd), e.G + o.ln_w, e.G + o.ln_b,
-                                          e.ws + a.dpre, dd, e.ws + a.dattq, e.ws + a.datt, e.ws + a.dqkv, e.ws + a.dq, e.ws + a.dkv, e.ws + a.dxq, e.ws + a.dxc, s));
-    tn.add(dd, H, Sq < S ? e.ws + a.attq : e.ws + a.att, H, e.G + o.o_w, Mq, H, H, e.G + o.o_b);
-    if (Sq < S) tn.add(e.ws + a.dq, H, xq, H, e.G + o.qkv_w, Mq, H, H, e.G + o.qkv_b);
-    else tn.add(e.ws + a.dqkv, 3 * H, xq, H, e.G + o.qkv_w, Mq, H, H, e.G + o.qkv_b);
-    if (Sk < S) tn.add(e.ws + a.dkv, 2 * H, xc, H, e.G + o.qkv_w + (size_t)H * H, Mc, 2 * H, H, e.G + o.qkv_b + H);
-    else tn.add(e.ws + a.dqkv + (size_t)H * Z, 3 * H, xc, H, e.G + o.qkv_w + (size_t)H * H, Mc, 2 * H, H, e.G + o.qkv_b + H);
+                                          e.ws + a.dpre, dd, nullptr, e.ws + a.datt, e.ws + a.dqkv, nullptr, nullptr, e.ws + a.dxq, e.ws + a.dxc, s));
+    // weight-gradient operands as the block left them: att [Mq, H]; dQ = rows [0, Mq) of dqkv's columns [0, H), [dK | dV] = rows [0, Mc) of its columns [H, 3H)
+    tn.add(dd, H, e.ws + a.att, H, e.G + o.o_w, Mq, H, H, e.G + o.o_b);
+    tn.add(e.ws + a.dqkv, 3 * H, xq, H, e.G + o.qkv_w, Mq, H, H, e.G + o.qkv_b);
+    tn.add(e.ws + a.dqkv + (size_t)H * Z, 3 * H, xc, H, e.G + o.qkv_w + (size_t)H * H, Mc, 2 * H, H, e.G + o.qkv_b + H);
     return 0;
 }
 // y += x over [rows, H] (the two gradient contributions a stream's tensor receives in a cross-modality layer)

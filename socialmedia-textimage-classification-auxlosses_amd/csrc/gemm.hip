@@ -289,16 +289,15 @@ void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += to_f<T>(r[e]);
             }
-            const int mc = a.c_rps > 0 ? (m / a.c_rps) * a.c_rps_stride + m % a.c_rps : m;      // per-post padded output layout (GemmNTArgs::c_rps)
             if (fl & GEMM_OUT_F32) {
-                float* c = (float*)a.C + (size_t)mc * a.ldc + n;
+                float* c = (float*)a.C + (size_t)m * a.ldc + n;
                 *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
             } else {
                 v8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = from_f<T>(v[e]);
-                *reinterpret_cast<v8*>((T*)a.C + (size_t)mc * a.ldc + n) = o;
+                *reinterpret_cast<v8*>((T*)a.C + (size_t)m * a.ldc + n) = o;
             }
         }
     }
@@ -628,7 +627,7 @@ static void launch_nt_t(const GemmNTArgs& a, hipStream_t s) {
 static int splitk_slices(const GemmNTArgs& a) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("MMHIP_SPLITK"); on = e ? atoi(e) : 1; }
-    if (!on || !a.splitk_ws || a.tile || a.c_rps || a.M > 128 || a.K < 1536 || a.K % 384 || a.N % 128 || (a.flags & (GEMM_TANH | GEMM_QGELU))) return 0;
+    if (!on || !a.splitk_ws || a.tile || a.M > 128 || a.K < 1536 || a.K % 384 || a.N % 128 || (a.flags & (GEMM_TANH | GEMM_QGELU))) return 0;
     return a.K / 384;
 }
 template <typename T>
@@ -670,7 +669,6 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MMHIP_NT_TILE"); env = e ? atoi(e) : 0; }
     int t = a.tile ? a.tile : env;
-    if (a.c_rps && t >= 13 && t <= 18) t = 0;
     if ((t == 13 || t == 15) && a.N % 256) t = 0;
     if ((t == 17 || t == 18 || t == 6) && a.N % 192) t = 0;
     if ((t == 14 || t == 16 || t == 1 || t == 9) && a.N % 128) t = 0;
@@ -684,7 +682,7 @@ static int choose_nt_tile(const GemmNTArgs& a) {
     static int nt8 = -1, nt8_minm = -1;
     if (nt8 < 0) { const char* e = getenv("MMHIP_NT8"); nt8 = e ? atoi(e) : 1; }
     if (nt8_minm < 0) { const char* e = getenv("MMHIP_NT8_MINM"); nt8_minm = e ? atoi(e) : 12000; }
-    if (nt8 && !a.c_rps && a.M >= nt8_minm && a.N % 128 == 0 && a.K % 64 == 0) {
+    if (nt8 && a.M >= nt8_minm && a.N % 128 == 0 && a.K % 64 == 0) {
         const long tm = (a.M + 255) / 256;
         const long t256 = a.N % 256 == 0 ? tm * (a.N / 256) : 0, t128 = tm * (a.N / 128);
         const double u256 = t256 ? (double)t256 / (double)(((t256 + 255) / 256) * 256) : 0.0;
@@ -757,8 +755,6 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, int dtype, hipStream_t s) {
 }
 static hipError_t launch_gemm_nt_untimed(const GemmNTArgs& a, int dtype, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
-    if (a.c_rps > 0 && (dtype == DT_F32 || !nt_fast_ok(a) || a.force_slow || debug_force_slow() || a.c_rps_stride < a.c_rps || (a.flags & GEMM_OUT_PAIR)))
-        return hipErrorInvalidValue;          // the row remap lives in gemm_nt_kernel's epilogue only
     if (dtype == DT_F32) return launch_gemm_nt_x3(a, s);
     if (nt_fast_ok(a) && !a.force_slow && !debug_force_slow()) {
         if (const int slices = splitk_slices(a)) {

@@ -51,9 +51,6 @@ struct GemmNTArgs {
     int nprod;                // plane pairs only: MFMA products per k slice -- 0 / 3: hi.hi + lo.hi + hi.lo (parity on the result); 2: hi.hi + lo.hi (B rounded
                               // to its hi plane); 1: hi.hi only (both operands rounded to bf16, pair / fp32 epilogue kept).  The engine's backward policy
                               // (mmhip_set_backward_products): north_star's 1e-3 is on logits and loss, the gradient bound is stated in DESIGN.md 4c
-    int c_rps, c_rps_stride;  // > 0: output row m lands in row (m / c_rps) * c_rps_stride + m % c_rps of C -- the rows of a post written into a
-                              // per-post padded layout (cross attention: Sq rows of a post inside its S-row block of the packed q|k|v buffer).
-                              // gemm_nt_kernel tiles only (launch_gemm_nt routes such a problem there or fails); bias / aux / residual rows stay m
 };
 struct GemmNTPair { GemmNTArgs p[2]; int count; int gw; };      // gw: N-tiles per column group of the tile walk (0 = 8)      // gemm8.hip: one or two problems of equal N and K per launch
 static constexpr int GEMM_TN_MAX_GROUP = 8;

@@ -170,12 +170,13 @@ def test_cross_attention_with_text_longer_than_boxes_matches_the_oracle():
     print("early cross orientation: worst gradient error", worst)
 
 
-@pytest.mark.parametrize("Sq,Sk", [(36, 48), (48, 36), (40, 40)])
+@pytest.mark.parametrize("Sq,Sk", [(36, 48), (48, 36), (40, 40), (128, 36), (36, 128), (70, 3)])
 def test_cross_attention_block_takes_no_padding_passes(Sq, Sk):
-    """round 4: with a 16-bit dtype the cross-attention block operator writes its projections straight into the posts' S-row blocks
-    (GemmNTArgs::c_rps) and tells the attention kernels the live row counts (Sq_live / Sk_live) -- no clear, no row copies.  Every work
-    buffer is poisoned with NaN before the call: a single read of a padding row would surface in y / dxq / dxc / the weight-gradient
-    operands.  Reference: the same block in torch fp32 on the same bf16-rounded operands (HF LxmertCrossAttentionLayer arithmetic)."""
+    """round 5: the cross-attention block works on COMPACT tensors -- the projections write Mq = posts * Sq query rows and Mc = posts * Sk key / value
+    rows, the attention kernels are told the two row pitches and lengths (AttnArgs::q_rps / kv_rps / ctx_rps, Sq_live / Sk_live) and skip key tiles
+    past Sk -- no clear, no row remap, no row copies (round 4: S-row blocks with a remapping GEMM epilogue; round 3: padded copies).  Every work
+    buffer is poisoned with NaN before the call: a single read of a row that no projection wrote would surface in y / dxq / dxc / the
+    weight-gradient operands.  Reference: the same block in torch fp32 on the same bf16-rounded operands (HF LxmertCrossAttentionLayer arithmetic)."""
     from smtc_amd import _lib
     lib = _lib.lib()
     dev = torch.device("cuda:0")
@@ -222,10 +223,10 @@ def test_cross_attention_block_takes_no_padding_passes(Sq, Sk):
     for name, got, ref, tol in (("y", y, y_ref, 3e-2), ("dxq", dxq, Xq.grad, 4e-2), ("dxc", dxc, Xc.grad, 4e-2)):
         assert torch.isfinite(got.float()).all(), name
         assert rel(got, ref.detach()) < tol, (name, rel(got, ref.detach()))
-    # the operands the weight-gradient GEMMs read: compact copies (or the packed tensors themselves where nothing is padded), live rows only
-    src_q = dq if Sq < S else dqkv[:, :H]
-    src_kv = dkv if Sk < S else dqkv[:, H:]
-    src_att = attq if Sq < S else att
+    # the operands the weight-gradient GEMMs read, where the block left them: rows [0, Mq) of dqkv's Q columns, rows [0, Mc) of its K | V columns, att [Mq, H];
+    # the scratch tensors of the earlier forms (attq, dq, dkv) must not have been touched
+    src_q, src_kv, src_att = dqkv[:posts * Sq, :H], dqkv[:posts * Sk, H:], att[:posts * Sq]
+    assert torch.isnan(attq.float()).all() and torch.isnan(dq.float()).all() and torch.isnan(dkv.float()).all()
     assert torch.isfinite(src_q.float()).all() and torch.isfinite(src_kv.float()).all() and torch.isfinite(src_att.float()).all()
     dWq = src_q.float().T @ d_xq.float()
     assert rel(dWq, W.grad[:H]) < 4e-2
@@ -235,9 +236,9 @@ def test_cross_attention_block_takes_no_padding_passes(Sq, Sk):
 
 
 @pytest.mark.parametrize("Sq,Sk", [(128, 36), (36, 128), (20, 100), (33, 1)])
-def test_cross_attention_direct_and_padded_forms_agree_with_dropout_on(Sq, Sk):
-    """the 16-bit form (rows written in place, live-row counts) against the fp32 / parity form (clear, project, copy rows in) of the same
-    operator with dropout ON in both places: the two share the element-index convention of the masks (indices of the padded S x S layout), so
+def test_cross_attention_16bit_and_parity_forms_agree_with_dropout_on(Sq, Sk):
+    """the 16-bit kernels against the parity-mode (fp32 tensors, three bf16 products) kernels of the same compact cross-attention operator with dropout ON
+    in both places: the two share the element-index convention of the masks (indices of the S x S layout, S = max(Sq, Sk), whatever the row pitch), so
     they must drop the same attention probabilities and the same hidden units and agree to bf16 accuracy -- outputs and both input gradients"""
     from smtc_amd import _lib
     lib = _lib.lib()
