@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of one training step from a rocprofv3 --kernel-trace CSV: per-queue busy time, union busy time, gaps with no
 kernel on the chip, and the phases (forward = up to the first backward kernel, backward, optimizer).
-usage: timeline.py <dir-or-csv> [step_index_from_end]"""
+usage: [TIMELINE_WINDOW=a,b] timeline.py <dir-or-csv> [step_index_from_end]"""
 import csv
 import glob
 import os
@@ -34,6 +34,11 @@ def main():
         seg.pop(0)
     t0, t1 = seg[0][0], max(e[1] for e in seg)
     print("step span %.3f ms, %d kernels" % ((t1 - t0) / 1e6, len(seg)))
+    if os.environ.get("TIMELINE_WINDOW"):          # "a,b" in ms from the step's start: every kernel that overlaps the window (start, duration, queue, name)
+        wa, wb = (float(x) * 1e6 for x in os.environ["TIMELINE_WINDOW"].split(","))
+        for s_, e_, n_, q_ in sorted(seg):
+            if e_ - t0 >= wa and s_ - t0 <= wb:
+                print("    %8.3f ms  %7.1f us  q%s  %s" % ((s_ - t0) / 1e6, (e_ - s_) / 1e3, q_, n_[:110]))
     byq = {}
     for s, e, n, q in seg:
         byq.setdefault(q, []).append((s, e, n))
