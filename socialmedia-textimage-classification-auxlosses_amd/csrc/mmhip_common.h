@@ -135,7 +135,7 @@ __device__ __forceinline__ float mm_gelu(float x) {
     p = fmaf(p, a, 4.586065114e-01f);
     p = fmaf(p, a, 1.151219487e+00f);
     p = fmaf(p, a, 9.999963641e-01f);
-    return __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f) - a * __builtin_amdgcn_exp2f(-p);
+    return fmaf(x, 0.f, __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f) - a * __builtin_amdgcn_exp2f(-p));          // + 0 x: v_med3_f32 drops a NaN operand, GELU(NaN) must stay NaN (the overflow guard)
 }
 // two values at a time: the polynomial as v_pk_fma_f32 (hipcc does not pack the scalar form -- its constants are 32-bit literals of v_fmaak_f32)
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -152,7 +152,8 @@ __device__ __forceinline__ void mm_gelu2(float& x0, float& x1) {
     p = __builtin_elementwise_fma(p, a, (f32x2_t){9.999963641e-01f, 9.999963641e-01f});
     const f32x2_t t = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};
     const f32x2_t r = {__builtin_amdgcn_fmed3f(x0, 0.f, 3.0e38f), __builtin_amdgcn_fmed3f(x1, 0.f, 3.0e38f)};
-    const f32x2_t o = __builtin_elementwise_fma(-a, t, r);
+    const f32x2_t x = {x0, x1};
+    const f32x2_t o = __builtin_elementwise_fma(x, (f32x2_t){0.f, 0.f}, __builtin_elementwise_fma(-a, t, r));      // + 0 x: v_med3_f32 drops a NaN operand; GELU(NaN) stays NaN
     x0 = o[0];
     x1 = o[1];
 }
@@ -172,7 +173,7 @@ __device__ __forceinline__ f32x2_t mm_gelu_grad2(float x0, float x1) {
     const f32x2_t T = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};
     const f32x2_t ph = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
     const f32x2_t h = (f32x2_t){0.5f, 0.5f} - __builtin_elementwise_fma(-a, ph, T);
-    return (f32x2_t){0.5f + copysignf(h[0], x0), 0.5f + copysignf(h[1], x1)};
+    return (f32x2_t){fmaf(x0, 0.f, 0.5f + copysignf(h[0], x0)), fmaf(x1, 0.f, 0.5f + copysignf(h[1], x1))};          // (+ 0 x: NaN in, NaN out)
 }
 __device__ __forceinline__ float mm_qgelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float mm_gelu_grad(float x) {

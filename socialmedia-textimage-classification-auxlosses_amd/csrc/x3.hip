@@ -57,6 +57,44 @@ __device__ __forceinline__ void store4_any(const GemmNTArgs& a, int m, int n, co
 }
 
 // ------------------------------------------------------------------------------------------------ NT
+// epilogue of four consecutive columns n .. n+3 of row m (bias already added): the flags of gemm.hip's fused epilogue on fp32 / plane-pair tensors
+__device__ __forceinline__ void x3_epilogue4(const GemmNTArgs& a, int fl, int m, int n, float (&v)[4]) {
+    if (fl & GEMM_AUX_PRE) *reinterpret_cast<f32x4*>((float*)a.aux + (size_t)m * a.ldaux + n) = f32x4{v[0], v[1], v[2], v[3]};
+    if (fl & GEMM_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) mm_gelu2(v[e], v[e + 1]);
+    }
+    if (fl & GEMM_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+    }
+    if (fl & GEMM_QGELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = mm_qgelu(v[e]);
+    }
+    if (fl & GEMM_MUL_GELU_GRAD) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>((const float*)a.mul_in + (size_t)m * a.ldmul + n);
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) { const f32x2_t gg = mm_gelu_grad2(u[e], u[e + 1]); v[e] *= gg[0]; v[e + 1] *= gg[1]; }
+    }
+    if ((fl & GEMM_DROPOUT) && a.drop.thresh16) {
+        const uint32_t e0 = (uint32_t)m * (uint32_t)(a.drop_row_mul ? a.drop_row_mul : 1) * (uint32_t)a.N + (uint32_t)n;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            bool k0, k1;
+            mm_keep2(e0 + e, a.drop, k0, k1);
+            v[e] = k0 ? v[e] * a.drop.keep_scale : 0.f;
+            v[e + 1] = k1 ? v[e + 1] * a.drop.keep_scale : 0.f;
+        }
+    }
+    if (fl & GEMM_RESIDUAL) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>((const float*)a.residual + (size_t)m * a.ldres + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
+    store4_any(a, m, n, v);
+}
+
 // C[M,N] = epilogue(A[M,K] . B[N,K]^T), all fp32 in memory (or plane pairs, see frag_any).  Block = 4 waves (2 x 2), 128 x 128 tile, wave 64 x 64.
 // Swapped MFMA operands (D = B_frag . A_frag^T): D row = n offset 4*(lane>>4) + reg, D column = m offset lane&15, so a
 // lane holds 4 consecutive columns of one output row -> 16-byte stores and the same fused epilogue as gemm.hip.
@@ -108,41 +146,72 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmNTArgs a) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[e];
-            if (fl & GEMM_AUX_PRE) *reinterpret_cast<f32x4*>((float*)a.aux + (size_t)m * a.ldaux + n) = f32x4{v[0], v[1], v[2], v[3]};
-            if (fl & GEMM_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) mm_gelu2(v[e], v[e + 1]);
-            }
-            if (fl & GEMM_TANH) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-            }
-            if (fl & GEMM_QGELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = mm_qgelu(v[e]);
-            }
-            if (fl & GEMM_MUL_GELU_GRAD) {
-                const f32x4 u = *reinterpret_cast<const f32x4*>((const float*)a.mul_in + (size_t)m * a.ldmul + n);
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) { const f32x2_t gg = mm_gelu_grad2(u[e], u[e + 1]); v[e] *= gg[0]; v[e + 1] *= gg[1]; }
-            }
-            if ((fl & GEMM_DROPOUT) && a.drop.thresh16) {
-                const uint32_t e0 = (uint32_t)m * (uint32_t)(a.drop_row_mul ? a.drop_row_mul : 1) * (uint32_t)a.N + (uint32_t)n;
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    bool k0, k1;
-                    mm_keep2(e0 + e, a.drop, k0, k1);
-                    v[e] = k0 ? v[e] * a.drop.keep_scale : 0.f;
-                    v[e + 1] = k1 ? v[e + 1] * a.drop.keep_scale : 0.f;
-                }
-            }
-            if (fl & GEMM_RESIDUAL) {
-                const f32x4 r = *reinterpret_cast<const f32x4*>((const float*)a.residual + (size_t)m * a.ldres + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += r[e];
-            }
-            store4_any(a, m, n, v);
+            x3_epilogue4(a, fl, m, n, v);
         }
+    }
+}
+
+// Few rows (M <= 128: the CLS-row GEMMs of the last text layer, 64 x 768 x 3072 and the like).  The 128 x 128 kernel above puts such a problem on
+// N / 128 = 6 workgroups with half their waves idle and walks all of K behind one prefetched step: 138 us for 64 x 768 x 3072 (round 5,
+// profiles/r05_nt_shapes_bf16x3_bwd1.txt).  Here a workgroup takes a 64 x 64 tile and its four waves a QUARTER OF K each (same fragments, same
+// products); the four partial tiles meet in LDS and wave w finishes fragment column w through the same epilogue.  Deterministic (fixed order of the
+// four partial sums).  K % 128 == 0, N % 64 == 0.
+__global__ __launch_bounds__(256) void gemm_nt_x3_small_kernel(GemmNTArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char x3s_smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(x3s_smem);          // [wave][fragment i * 4 + j][lane]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, kc = lane >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    size_t arow[4], brow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { arow[i] = (size_t)min(m0 + i * 16 + l15, a.M - 1); brow[i] = (size_t)min(n0 + i * 16 + l15, a.N - 1); }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int h1 = a.nprod == 1;
+    const int kq = a.K >> 2, kb = w * kq, ke = kb + kq;
+    Frag3 na[4], nb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { na[i] = frag_any(a.A, arow[i], a.lda, kb + kc * 8, a.a_pair, a.a_lo, h1); nb[i] = frag_any(a.B, brow[i], a.ldb, kb + kc * 8, a.b_pair, a.b_lo, h1); }
+#pragma unroll 1
+    for (int k0 = kb; k0 < ke; k0 += 32) {
+        Frag3 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { af[i] = na[i]; bf[i] = nb[i]; }
+        if (k0 + 32 < ke) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                na[i] = frag_any(a.A, arow[i], a.lda, k0 + 32 + kc * 8, a.a_pair, a.a_lo, h1);
+                nb[i] = frag_any(a.B, brow[i], a.ldb, k0 + 32 + kc * 8, a.b_pair, a.b_lo, h1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mma3(bf[j], af[i], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[(w * 16 + i * 4 + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+    const int fl = a.flags, j = w, n = n0 + j * 16 + 4 * kc;
+    if (n >= a.N) return;
+    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (fl & GEMM_BIAS) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + i * 16 + l15;
+        f32x4 t = red[(0 * 16 + i * 4 + j) * 64 + lane];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { const f32x4 p = red[(q * 16 + i * 4 + j) * 64 + lane]; t[0] += p[0]; t[1] += p[1]; t[2] += p[2]; t[3] += p[3]; }
+        if (m >= a.M) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = t[e] + b4[e];
+        x3_epilogue4(a, fl, m, n, v);
     }
 }
 
@@ -245,7 +314,13 @@ hipError_t launch_gemm_nt_x3(const GemmNTArgs& a, hipStream_t s) {
                       (!a.a_pair || (a.a_lo % 8 == 0 && a.lda % 8 == 0)) && (!a.b_pair || (a.b_lo % 8 == 0 && a.ldb % 8 == 0)) && (!(a.flags & GEMM_OUT_PAIR) || a.c_lo % 4 == 0) &&
                       (!(a.flags & GEMM_RESIDUAL) || (a.ldres % 4 == 0 && al(a.residual))) && (!(a.flags & GEMM_AUX_PRE) || (a.ldaux % 4 == 0 && al(a.aux))) &&
                       (!(a.flags & GEMM_MUL_GELU_GRAD) || (a.ldmul % 4 == 0 && al(a.mul_in))) && (!(a.flags & GEMM_BIAS) || al(a.bias));
-    if (fast) hipLaunchKernelGGL(gemm_nt_x3_kernel, dim3((a.N + 127) / 128, (a.M + 127) / 128), dim3(256), 0, s, a);
+    static int small_on = -1;
+    if (small_on < 0) { const char* e = getenv("MMHIP_X3_SMALL"); small_on = e ? atoi(e) : 1; }
+    if (fast && small_on && a.M <= 128 && a.K % 128 == 0 && a.N % 64 == 0) {          // few rows: K split over the waves of a 64 x 64 tile (MMHIP_X3_SMALL=0: the 128 x 128 kernel)
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt_x3_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); done = true; }
+        hipLaunchKernelGGL(gemm_nt_x3_small_kernel, dim3(a.N / 64, (a.M + 63) / 64), dim3(256), 64 * 1024, s, a);
+    } else if (fast) hipLaunchKernelGGL(gemm_nt_x3_kernel, dim3((a.N + 127) / 128, (a.M + 127) / 128), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(slow_nt_f32_kernel, dim3((a.N + 255) / 256, a.M), dim3(256), 0, s, a);
     return hipGetLastError();
 }

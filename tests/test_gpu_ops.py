@@ -136,6 +136,11 @@ def test_gelu_epilogue_is_the_erf_gelu(dt, slow):
     ref = xd * 0.5 * torch.erfc(-xd / math.sqrt(2.0))
     err = (C_.double().cpu() - ref).abs()
     assert (err <= 6e-7 + 1.2e-7 * ref.abs()).all(), err.max().item()
+    # a NaN pre-activation stays NaN (the division-free form clamps with v_med3_f32, which drops a NaN operand: the kernel adds 0 * x back)
+    A[1, 3] = float("nan")
+    call("mmhip_op_gemm_nt", code, ptr(A), N, ptr(B), N, ptr(C_), N, M, N, N, None, 1, None, 0, None, 0, 0.0, 0, 0, None, 0, 0 if dt == "x3" else 1, slow, stream())
+    torch.cuda.synchronize()
+    assert torch.isnan(C_[1, 3]).item() and torch.isfinite(C_[0]).all().item()
 
 
 @pytest.mark.parametrize("dt,slow", [("bf16", 0), ("bf16", 16), ("bf16", 224), ("f16", 256), ("x3", 0)])
@@ -255,7 +260,8 @@ def test_attention_fwd_bwd(dt, posts, S, heads, masked, p):
 
 
 # ---- parity mode (dtype code MMHIP_F32 at the op level): the same operators on fp32 tensors
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (200, 128, 64), (1000, 768, 768), (96, 48, 40), (8192, 2304, 768), (64, 768, 3072), (300, 132, 96), (130, 512, 768), (12608, 768, 3072), (700, 384, 192)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (200, 128, 64), (1000, 768, 768), (96, 48, 40), (8192, 2304, 768), (64, 768, 3072), (300, 132, 96), (130, 512, 768), (12608, 768, 3072), (700, 384, 192),
+                                   (64, 3072, 768), (128, 768, 768), (100, 192, 256), (5, 64, 128), (128, 2304, 3072)])          # the last five: few rows, K split over a workgroup's waves (gemm_nt_x3_small_kernel)
 def test_x3_gemm_nt(M, N, K):
     test_gemm_nt_epilogues("x3", M, N, K, 0)
 
