@@ -153,66 +153,55 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmNTArgs a) {
 
 // Few rows (M <= 128: the CLS-row GEMMs of the last text layer, 64 x 768 x 3072 and the like).  The 128 x 128 kernel above puts such a problem on
 // N / 128 = 6 workgroups with half their waves idle and walks all of K behind one prefetched step: 138 us for 64 x 768 x 3072 (round 5,
-// profiles/r05_nt_shapes_bf16x3_bwd1.txt).  Here a workgroup takes a 64 x 64 tile and its four waves a QUARTER OF K each (same fragments, same
-// products); the four partial tiles meet in LDS and wave w finishes fragment column w through the same epilogue.  Deterministic (fixed order of the
-// four partial sums).  K % 128 == 0, N % 64 == 0.
+// profiles/r05_nt_shapes_bf16x3_bwd1.txt).  Here a workgroup takes a 64-row x 16-column tile (N / 16 = 48 ... 192 workgroups) and its four waves a
+// QUARTER OF K each (same fragments, same products); the four partial tiles meet in 16 KB of LDS -- little enough to sit on a CU beside a 128 KB
+// workgroup of the other tower's GEMM (a first version with 64 x 64 tiles and 64 KB waited for whole CUs) -- and wave w finishes row fragment w through
+// the same epilogue.  Deterministic (fixed order of the four partial sums).  K % 128 == 0, N % 16 == 0.
 __global__ __launch_bounds__(256) void gemm_nt_x3_small_kernel(GemmNTArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char x3s_smem[];
-    f32x4* red = reinterpret_cast<f32x4*>(x3s_smem);          // [wave][fragment i * 4 + j][lane]
+    __shared__ f32x4 red[4][4][64];          // [wave][row fragment][lane]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int l15 = lane & 15, kc = lane >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    size_t arow[4], brow[4];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 16;
+    size_t arow[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { arow[i] = (size_t)min(m0 + i * 16 + l15, a.M - 1); brow[i] = (size_t)min(n0 + i * 16 + l15, a.N - 1); }
-    f32x4 acc[4][4];
+    for (int i = 0; i < 4; ++i) arow[i] = (size_t)min(m0 + i * 16 + l15, a.M - 1);
+    const size_t brow = (size_t)min(n0 + l15, a.N - 1);
+    f32x4 acc[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int h1 = a.nprod == 1;
     const int kq = a.K >> 2, kb = w * kq, ke = kb + kq;
-    Frag3 na[4], nb[4];
+    Frag3 na[4], nb;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { na[i] = frag_any(a.A, arow[i], a.lda, kb + kc * 8, a.a_pair, a.a_lo, h1); nb[i] = frag_any(a.B, brow[i], a.ldb, kb + kc * 8, a.b_pair, a.b_lo, h1); }
+    for (int i = 0; i < 4; ++i) na[i] = frag_any(a.A, arow[i], a.lda, kb + kc * 8, a.a_pair, a.a_lo, h1);
+    nb = frag_any(a.B, brow, a.ldb, kb + kc * 8, a.b_pair, a.b_lo, h1);
 #pragma unroll 1
     for (int k0 = kb; k0 < ke; k0 += 32) {
-        Frag3 af[4], bf[4];
+        Frag3 af[4], bf = nb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { af[i] = na[i]; bf[i] = nb[i]; }
+        for (int i = 0; i < 4; ++i) af[i] = na[i];
         if (k0 + 32 < ke) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                na[i] = frag_any(a.A, arow[i], a.lda, k0 + 32 + kc * 8, a.a_pair, a.a_lo, h1);
-                nb[i] = frag_any(a.B, brow[i], a.ldb, k0 + 32 + kc * 8, a.b_pair, a.b_lo, h1);
-            }
+            for (int i = 0; i < 4; ++i) na[i] = frag_any(a.A, arow[i], a.lda, k0 + 32 + kc * 8, a.a_pair, a.a_lo, h1);
+            nb = frag_any(a.B, brow, a.ldb, k0 + 32 + kc * 8, a.b_pair, a.b_lo, h1);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mma3(bf[j], af[i], acc[i][j]);
+        for (int i = 0; i < 4; ++i) acc[i] = mma3(bf, af[i], acc[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) red[(w * 16 + i * 4 + j) * 64 + lane] = acc[i][j];
+    for (int i = 0; i < 4; ++i) red[w][i][lane] = acc[i];
     __syncthreads();
-    const int fl = a.flags, j = w, n = n0 + j * 16 + 4 * kc;
-    if (n >= a.N) return;
+    const int fl = a.flags, i = w, n = n0 + 4 * kc, m = m0 + i * 16 + l15;
+    f32x4 t = red[0][i][lane];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) { const f32x4 p = red[q][i][lane]; t[0] += p[0]; t[1] += p[1]; t[2] += p[2]; t[3] += p[3]; }
+    if (n >= a.N || m >= a.M) return;
     f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (fl & GEMM_BIAS) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+    float v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + i * 16 + l15;
-        f32x4 t = red[(0 * 16 + i * 4 + j) * 64 + lane];
-#pragma unroll
-        for (int q = 1; q < 4; ++q) { const f32x4 p = red[(q * 16 + i * 4 + j) * 64 + lane]; t[0] += p[0]; t[1] += p[1]; t[2] += p[2]; t[3] += p[3]; }
-        if (m >= a.M) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = t[e] + b4[e];
-        x3_epilogue4(a, fl, m, n, v);
-    }
+    for (int e = 0; e < 4; ++e) v[e] = t[e] + b4[e];
+    x3_epilogue4(a, fl, m, n, v);
 }
 
 // generic fp32 NT for shapes the tiled kernel does not take (K % 32, N % 4, unaligned): plain fp32 FMA, same epilogue
@@ -316,10 +305,8 @@ hipError_t launch_gemm_nt_x3(const GemmNTArgs& a, hipStream_t s) {
                       (!(a.flags & GEMM_MUL_GELU_GRAD) || (a.ldmul % 4 == 0 && al(a.mul_in))) && (!(a.flags & GEMM_BIAS) || al(a.bias));
     static int small_on = -1;
     if (small_on < 0) { const char* e = getenv("MMHIP_X3_SMALL"); small_on = e ? atoi(e) : 1; }
-    if (fast && small_on && a.M <= 128 && a.K % 128 == 0 && a.N % 64 == 0) {          // few rows: K split over the waves of a 64 x 64 tile (MMHIP_X3_SMALL=0: the 128 x 128 kernel)
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute((const void*)gemm_nt_x3_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); done = true; }
-        hipLaunchKernelGGL(gemm_nt_x3_small_kernel, dim3(a.N / 64, (a.M + 63) / 64), dim3(256), 64 * 1024, s, a);
+    if (fast && small_on && a.M <= 128 && a.K % 128 == 0 && a.N % 16 == 0) {          // few rows: K split over the waves of a 64 x 16 tile (MMHIP_X3_SMALL=0: the 128 x 128 kernel)
+        hipLaunchKernelGGL(gemm_nt_x3_small_kernel, dim3(a.N / 16, (a.M + 63) / 64), dim3(256), 0, s, a);
     } else if (fast) hipLaunchKernelGGL(gemm_nt_x3_kernel, dim3((a.N + 127) / 128, (a.M + 127) / 128), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(slow_nt_f32_kernel, dim3((a.N + 255) / 256, a.M), dim3(256), 0, s, a);
     return hipGetLastError();
